@@ -1,0 +1,174 @@
+/*
+ * hipsoxr.h — native C ABI of the MI355X (gfx950) sample-rate converter.
+ *
+ * This is the drop-in boundary for the ONE hot path this repository accelerates:
+ * libsoxr's constant-rate `soxr_process` underneath python-soxr's
+ * `soxr.resample` / `ResampleStream.resample_chunk`.
+ *
+ * Every entry point names the reference interface it replaces (paths are relative to the
+ * reference checkout, dofuuz/python-soxr):
+ *
+ *   hipsoxr_stream_create   <- soxr_create        call sites src/soxr_ext.cpp:76-78, :230-232, :305-307
+ *   hipsoxr_stream_process  <- soxr_process       call sites src/soxr_ext.cpp:118-121, :163-166, :245-248,
+ *                                                            :253-256, :328-331, :339-342
+ *   hipsoxr_oneshot         <- soxr_oneshot       call site  src/soxr_ext.cpp:385-389
+ *   hipsoxr_stream_delete   <- soxr_delete        src/soxr_ext.cpp:86, :260, :346
+ *   hipsoxr_stream_clear    <- soxr_clear         src/soxr_ext.cpp:195
+ *   hipsoxr_stream_delay    <- soxr_delay         src/soxr_ext.cpp:157, :191
+ *   hipsoxr_stream_num_clips<- soxr_num_clips     src/soxr_ext.cpp:190
+ *   hipsoxr_stream_engine   <- soxr_engine        src/soxr_ext.cpp:192
+ *   hipsoxr_stream_set_io_ratio <- soxr_set_io_ratio src/soxr_ext.cpp:201
+ *   hipsoxr_version         <- soxr_version       src/csoxr_version.cpp:6-8
+ *   datatype / recipe constants <- soxr_datatype_t, SOXR_QQ..SOXR_VHQ  src/soxr_ext.cpp:32-46, :447-451
+ *
+ * Additions that have no counterpart in the reference (it has no GPU, no batch axis):
+ *   hipsoxr_plan_*          the shared, immutable filter bank (what soxr_create designs per handle),
+ *                           so that many streams / ranks share one bank (and RCCL can broadcast it);
+ *   hipsoxr_run_device      device-pointer, batched, stateless launch of the hot path — the
+ *                           entry the benchmark times (host-pointer soxr_process is PCIe-bound).
+ *
+ * Conventions (same as libsoxr): errors are static `const char *` strings, NULL == success;
+ * handles are owned by the caller; input buffers are borrowed for the duration of the call and
+ * fully consumed; output buffers are caller-allocated.  Distinct handles may be used concurrently
+ * from different threads; one handle must not be.
+ *
+ * Plain C, no torch / HIP types in any signature (streams are passed as `void *` = hipStream_t).
+ */
+#ifndef HIPSOXR_H
+#define HIPSOXR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPSOXR_API __attribute__((visibility("default")))
+
+typedef const char *hipsoxr_error_t; /* NULL == success (reference: src/soxr_ext.cpp:80-82) */
+
+/* Same numbering as libsoxr's soxr_datatype_t (reference: src/soxr_ext.cpp:35-46). */
+typedef enum {
+    HIPSOXR_FLOAT32_I = 0, /* interleaved [frame][channel] */
+    HIPSOXR_FLOAT64_I = 1,
+    HIPSOXR_INT32_I = 2,
+    HIPSOXR_INT16_I = 3,
+    HIPSOXR_FLOAT32_S = 4, /* split: one contiguous buffer per channel */
+    HIPSOXR_FLOAT64_S = 5,
+    HIPSOXR_INT32_S = 6,
+    HIPSOXR_INT16_S = 7
+} hipsoxr_datatype_t;
+
+/* Quality recipes — libsoxr values (reference: src/soxr_ext.cpp:447-451). */
+#define HIPSOXR_QQ 0UL
+#define HIPSOXR_LQ 1UL
+#define HIPSOXR_MQ 2UL
+#define HIPSOXR_HQ 4UL
+#define HIPSOXR_VHQ 6UL
+
+/* Stream flags. */
+#define HIPSOXR_VR 32UL        /* quality-spec flag: variable rate (reference: src/soxr_ext.cpp:74) */
+#define HIPSOXR_NO_DITHER 8UL  /* io-spec flag: disable int16 TPDF dither */
+
+/* Element types used by device jobs (layout is given by strides, not by the type). */
+typedef enum { HIPSOXR_F32 = 0, HIPSOXR_F64 = 1, HIPSOXR_I32 = 2, HIPSOXR_I16 = 3 } hipsoxr_elem_t;
+
+/* Kernel selector for hipsoxr_run_device. */
+typedef enum {
+    HIPSOXR_KERNEL_AUTO = 0,
+    HIPSOXR_KERNEL_GATHER = 1, /* one lane per output sample, operands gathered through L1/L2 */
+    HIPSOXR_KERNEL_TILE = 2    /* period-tiled: input slab in LDS, coefficients on the scalar path */
+} hipsoxr_kernel_t;
+
+typedef struct hipsoxr_plan hipsoxr_plan_t;     /* immutable: ratio + polyphase bank (host + device) */
+typedef struct hipsoxr_stream hipsoxr_stream_t; /* stateful converter: the `soxr_t` counterpart */
+
+/* ---- library ---------------------------------------------------------------------------- */
+HIPSOXR_API const char *hipsoxr_version(void);
+HIPSOXR_API int hipsoxr_device_count(void); /* 0 when no HIP device is visible (never throws) */
+
+/* ---- plan: what soxr_create designs (filter bank for in_rate -> out_rate at a recipe) ---- */
+typedef struct {
+    double in_rate, out_rate;
+    unsigned long recipe;
+    int64_t L, M;          /* out/in = L/M in lowest terms: L phases, phase step M              */
+    int32_t taps;          /* taps per phase (even, multiple of 8)                               */
+    int32_t interpolated;  /* 0: exact rational bank                                             */
+    double precision_bits; /* 0 (QQ), 16, 20, 28                                                 */
+    double passband_end;   /* fraction of the lower rate's Nyquist                                */
+    double stopband_begin;
+    double att_db;         /* design stop-band attenuation                                        */
+    double kaiser_beta;
+    uint64_t bank_elems;   /* L * taps                                                            */
+} hipsoxr_plan_info_t;
+
+HIPSOXR_API hipsoxr_error_t hipsoxr_plan_create(double in_rate, double out_rate,
+                                                unsigned long recipe, hipsoxr_plan_t **out);
+HIPSOXR_API void hipsoxr_plan_delete(hipsoxr_plan_t *);
+HIPSOXR_API hipsoxr_error_t hipsoxr_plan_info(const hipsoxr_plan_t *, hipsoxr_plan_info_t *info);
+/* Copy the float64 bank, phase-major [L][taps], into dst (n = L*taps doubles). */
+HIPSOXR_API hipsoxr_error_t hipsoxr_plan_get_bank(const hipsoxr_plan_t *, double *dst, size_t n);
+/* Replace the bank (e.g. with the one RCCL-broadcast from rank 0); device tables are rebuilt. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *, const double *src, size_t n);
+/* Total output frames for `in_len` input frames: floor(in_len*L/M + 1/2). */
+HIPSOXR_API uint64_t hipsoxr_plan_out_len(const hipsoxr_plan_t *, uint64_t in_len);
+
+/* ---- device job: the hot path on device-resident buffers (batched, stateless) ------------- */
+typedef struct {
+    const void *in;  /* device pointer */
+    void *out;       /* device pointer */
+    int32_t elem;    /* hipsoxr_elem_t of in and out */
+    int32_t kernel;  /* hipsoxr_kernel_t */
+    uint32_t n_clips, n_channels;
+    /* strides in ELEMENTS: address(clip, frame, ch) = base + clip*cs + frame*fs + ch*chs */
+    int64_t in_clip_stride, in_frame_stride, in_chan_stride;
+    int64_t out_clip_stride, out_frame_stride, out_chan_stride;
+    int64_t in_abs0;   /* absolute stream index of in[frame 0] (0 for a whole signal)            */
+    int64_t in_frames; /* frames present at `in`; the signal is zero outside [in_abs0, +frames)  */
+    int64_t out_k0;    /* absolute index of the first output frame to produce                    */
+    int64_t out_frames;/* output frames to produce (per clip)                                    */
+    uint64_t *clip_counter; /* device counter of saturated integer outputs, or NULL            */
+    uint32_t dither;        /* 1: TPDF dither on int16 output                                    */
+    uint32_t dither_seed;
+} hipsoxr_job_t;
+
+/* Enqueue the job on `hip_stream` (a hipStream_t; NULL = default stream). Asynchronous. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_run_device(hipsoxr_plan_t *, const hipsoxr_job_t *job,
+                                               void *hip_stream);
+
+/* ---- stream: the soxr_t counterpart (host pointers, state carried across calls) ----------- */
+HIPSOXR_API hipsoxr_error_t hipsoxr_stream_create(double in_rate, double out_rate,
+                                                  unsigned num_channels,
+                                                  hipsoxr_datatype_t io_type, /* itype == otype */
+                                                  unsigned long recipe, unsigned long flags,
+                                                  hipsoxr_stream_t **out);
+/* Share an existing plan (no filter design); the plan must outlive the stream. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_stream_create_with_plan(hipsoxr_plan_t *, unsigned num_channels,
+                                                            hipsoxr_datatype_t io_type,
+                                                            unsigned long flags,
+                                                            hipsoxr_stream_t **out);
+/* soxr_process semantics: `in` = T const* (interleaved) or T const* const* (split); in == NULL
+ * marks end of input (flush; call until *odone == 0); ilen == 0 with in != NULL drains only.
+ * All of `ilen` is always consumed.  At most `olen` frames are written; *odone = frames written. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *, const void *in, size_t ilen,
+                                                   void *out, size_t olen, size_t *odone);
+HIPSOXR_API void hipsoxr_stream_delete(hipsoxr_stream_t *);
+HIPSOXR_API hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *);
+HIPSOXR_API double hipsoxr_stream_delay(hipsoxr_stream_t *);
+HIPSOXR_API size_t hipsoxr_stream_num_clips(hipsoxr_stream_t *);
+HIPSOXR_API const char *hipsoxr_stream_engine(hipsoxr_stream_t *);
+HIPSOXR_API hipsoxr_error_t hipsoxr_stream_set_io_ratio(hipsoxr_stream_t *, double io_ratio,
+                                                        size_t slew_len);
+HIPSOXR_API hipsoxr_plan_t *hipsoxr_stream_plan(hipsoxr_stream_t *);
+
+/* ---- one-shot (create + process all + flush + delete), host pointers ---------------------- */
+HIPSOXR_API hipsoxr_error_t hipsoxr_oneshot(double in_rate, double out_rate, unsigned num_channels,
+                                            const void *in, size_t ilen, void *out, size_t olen,
+                                            size_t *odone, hipsoxr_datatype_t io_type,
+                                            unsigned long recipe, unsigned long flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPSOXR_H */

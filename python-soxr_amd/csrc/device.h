@@ -1,0 +1,24 @@
+// device.h — interface between the host engine (engine.cpp) and the HIP side (kernels.hip).
+#pragma once
+#include "../../include/hipsoxr.h"
+#include "plan.h"
+
+namespace hipsoxr {
+
+// Build (once per precision) the device tables of a plan.  prec: 0 = f32 engine, 1 = f64 engine.
+const char *device_bank_ensure(Plan *p, int prec);
+void device_bank_release(Plan *p);
+
+// Engine precision used for an element type: f32 for f32/i16, f64 for f64/i32.
+inline int engine_prec(int elem) { return (elem == HIPSOXR_F32 || elem == HIPSOXR_I16) ? 0 : 1; }
+inline size_t elem_size(int elem)
+{
+    return elem == HIPSOXR_F32 ? 4 : elem == HIPSOXR_F64 ? 8 : elem == HIPSOXR_I32 ? 4 : 2;
+}
+
+// Enqueue one job (validated by the caller) on `stream`.
+const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream);
+
+int device_count();
+
+} // namespace hipsoxr

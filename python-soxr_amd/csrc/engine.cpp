@@ -1,0 +1,405 @@
+// engine.cpp — host engine behind the C ABI (include/hipsoxr.h): plans, device jobs, and the
+// stateful stream that mirrors libsoxr's soxr_t as python-soxr drives it
+// (reference: CSoxr in src/soxr_ext.cpp:49-205 and the three one-shot drivers :208-402).
+//
+// State carried across soxr_process calls lives on the device: the not-yet-retired tail of the
+// input (a linear staging buffer in the I/O dtype and layout) plus two absolute counters
+// (frames received, frames emitted).  Because every output sample is a pure function of absolute
+// positions, emitted output is independent of how the input was chunked.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "device.h"
+
+using namespace hipsoxr;
+
+struct hipsoxr_plan {
+    Plan p;
+};
+
+namespace hipsoxr {
+Plan::~Plan() { device_bank_release(this); }
+} // namespace hipsoxr
+
+struct hipsoxr_stream {
+    hipsoxr_plan *plan = nullptr;
+    bool own_plan = false;
+    unsigned ch = 1;
+    int elem = HIPSOXR_F32;
+    bool split = false;
+    unsigned long flags = 0;
+    bool ended = false;
+    uint64_t n_in_total = 0, k_done = 0;
+    // device staging of pending input: frames [in_base, in_base + in_fill)
+    void *d_in = nullptr, *d_in_alt = nullptr;
+    size_t in_cap = 0, alt_cap = 0; // frames
+    int64_t in_base = 0;
+    size_t in_fill = 0;
+    void *d_out = nullptr;
+    size_t out_cap = 0; // frames
+    uint64_t *d_clips = nullptr;
+    hipStream_t st = nullptr;
+    char engine_name[32] = {0};
+};
+
+#define HIP_TRY(expr)                                       \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) return hipGetErrorString(e_); \
+    } while (0)
+
+static const char *kNoDevice = "no HIP device available (hipsoxr has no CPU fallback)";
+
+// ------------------------------------------------------------------------------------------------
+// library / plan
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *hipsoxr_version(void) { return "hipsoxr-0.1.0 (gfx950)"; }
+
+int hipsoxr_device_count(void) { return device_count(); }
+
+hipsoxr_error_t hipsoxr_plan_create(double in_rate, double out_rate, unsigned long recipe,
+                                    hipsoxr_plan_t **out)
+{
+    if (!out) return "null argument";
+    *out = nullptr;
+    hipsoxr_plan *h = new (std::nothrow) hipsoxr_plan();
+    if (!h) return "out of memory";
+    if (const char *e = plan_design(in_rate, out_rate, recipe, &h->p)) {
+        delete h;
+        return e;
+    }
+    *out = h;
+    return nullptr;
+}
+
+void hipsoxr_plan_delete(hipsoxr_plan_t *h) { delete h; }
+
+hipsoxr_error_t hipsoxr_plan_info(const hipsoxr_plan_t *h, hipsoxr_plan_info_t *info)
+{
+    if (!h || !info) return "null argument";
+    const Plan &p = h->p;
+    info->in_rate = p.in_rate; info->out_rate = p.out_rate; info->recipe = p.recipe;
+    info->L = p.L; info->M = p.M; info->taps = p.T; info->interpolated = 0;
+    info->precision_bits = p.q.bits; info->passband_end = p.q.passband_end;
+    info->stopband_begin = p.q.stopband_begin; info->att_db = p.att_db; info->kaiser_beta = p.beta;
+    info->bank_elems = (uint64_t)p.bank.size();
+    return nullptr;
+}
+
+hipsoxr_error_t hipsoxr_plan_get_bank(const hipsoxr_plan_t *h, double *dst, size_t n)
+{
+    if (!h || !dst) return "null argument";
+    if (n != h->p.bank.size()) return "bank size mismatch";
+    std::memcpy(dst, h->p.bank.data(), n * sizeof(double));
+    return nullptr;
+}
+
+hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *h, const double *src, size_t n)
+{
+    if (!h || !src) return "null argument";
+    if (n != h->p.bank.size()) return "bank size mismatch";
+    device_bank_release(&h->p);
+    std::memcpy(h->p.bank.data(), src, n * sizeof(double));
+    return nullptr;
+}
+
+uint64_t hipsoxr_plan_out_len(const hipsoxr_plan_t *h, uint64_t in_len)
+{
+    return h ? plan_out_len(h->p, in_len) : 0;
+}
+
+hipsoxr_error_t hipsoxr_run_device(hipsoxr_plan_t *h, const hipsoxr_job_t *job, void *hip_stream)
+{
+    if (!h || !job) return "null argument";
+    if (job->elem < 0 || job->elem > 3) return "invalid element type";
+    if (job->out_frames < 0 || job->in_frames < 0 || job->out_k0 < 0) return "invalid job extent";
+    if (job->out_frames > 0 && (!job->in || !job->out) && job->in_frames > 0) return "null buffer";
+    if (device_count() <= 0) return kNoDevice;
+    return launch_job(&h->p, *job, hip_stream);
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// stream internals
+// ------------------------------------------------------------------------------------------------
+static inline size_t esz(const hipsoxr_stream *s) { return elem_size(s->elem); }
+
+// Number of outputs computable from the first N input frames without zero-extension:
+// output k needs inputs up to floor(k*M/L) + T/2.
+static uint64_t k_avail(const Plan &p, uint64_t N)
+{
+    const int64_t H = p.T / 2;
+    if ((int64_t)N - 1 - H < 0) return 0;
+    unsigned __int128 Q = (unsigned __int128)(N - 1 - (uint64_t)H);
+    unsigned __int128 v = ((Q + 1) * (unsigned __int128)p.L - 1) / (unsigned __int128)p.M;
+    return (uint64_t)v + 1;
+}
+
+// Move the still-needed tail of the staged input to the front of the alternate buffer.
+static const char *stream_compact(hipsoxr_stream *s, size_t want_cap)
+{
+    const Plan &p = s->plan->p;
+    int64_t n0, ph;
+    locate(p, (int64_t)s->k_done, &n0, &ph);
+    int64_t keep_from = std::max<int64_t>(n0, s->in_base);
+    keep_from = std::min<int64_t>(keep_from, s->in_base + (int64_t)s->in_fill);
+    const size_t drop = (size_t)(keep_from - s->in_base), keep = s->in_fill - drop;
+    const size_t cap = std::max(want_cap, s->in_cap);
+    if (drop == 0 && cap == s->in_cap) return nullptr;
+    if (s->alt_cap < cap || !s->d_in_alt) {
+        if (s->d_in_alt) HIP_TRY(hipFree(s->d_in_alt));
+        s->d_in_alt = nullptr;
+        HIP_TRY(hipMalloc(&s->d_in_alt, cap * s->ch * esz(s)));
+        s->alt_cap = cap;
+    }
+    if (keep) {
+        if (!s->split) {
+            HIP_TRY(hipMemcpyAsync(s->d_in_alt, (char *)s->d_in + drop * s->ch * esz(s),
+                                   keep * s->ch * esz(s), hipMemcpyDeviceToDevice, s->st));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(s->d_in_alt, s->alt_cap * esz(s), (char *)s->d_in + drop * esz(s),
+                                     s->in_cap * esz(s), keep * esz(s), s->ch,
+                                     hipMemcpyDeviceToDevice, s->st));
+        }
+    }
+    std::swap(s->d_in, s->d_in_alt);
+    std::swap(s->in_cap, s->alt_cap);
+    s->in_base = keep_from;
+    s->in_fill = keep;
+    return nullptr;
+}
+
+static const char *stream_append(hipsoxr_stream *s, const void *in, size_t ilen)
+{
+    if (s->in_fill + ilen > s->in_cap) {
+        // retire consumed input first; grow (power of two) only if that is not enough
+        const Plan &p = s->plan->p;
+        int64_t n0, ph;
+        locate(p, (int64_t)s->k_done, &n0, &ph);
+        int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base),
+                                              s->in_base + (int64_t)s->in_fill);
+        size_t keep = s->in_fill - (size_t)(keep_from - s->in_base);
+        size_t need = keep + ilen, cap = std::max<size_t>(s->in_cap, 1024);
+        while (cap < need) cap <<= 1;
+        if (const char *e = stream_compact(s, cap)) return e;
+    }
+    if (!s->split) {
+        HIP_TRY(hipMemcpyAsync((char *)s->d_in + s->in_fill * s->ch * esz(s), in,
+                               ilen * s->ch * esz(s), hipMemcpyHostToDevice, s->st));
+    } else {
+        const void *const *chans = (const void *const *)in;
+        for (unsigned c = 0; c < s->ch; ++c)
+            HIP_TRY(hipMemcpyAsync((char *)s->d_in + ((size_t)c * s->in_cap + s->in_fill) * esz(s),
+                                   chans[c], ilen * esz(s), hipMemcpyHostToDevice, s->st));
+    }
+    s->in_fill += ilen;
+    s->n_in_total += ilen;
+    return nullptr;
+}
+
+// Emit up to olen frames (host destination).  `out_off` = frame offset into the caller's buffers.
+static const char *stream_emit(hipsoxr_stream *s, void *out, size_t olen, size_t *odone)
+{
+    const Plan &p = s->plan->p;
+    const uint64_t k_end = s->ended ? plan_out_len(p, s->n_in_total) : k_avail(p, s->n_in_total);
+    size_t n = 0;
+    if (k_end > s->k_done) n = (size_t)std::min<uint64_t>(k_end - s->k_done, olen);
+    *odone = n;
+    if (n == 0) {
+        HIP_TRY(hipStreamSynchronize(s->st)); // the caller's input buffer is borrowed only for the call
+        return nullptr;
+    }
+    if (n > s->out_cap) {
+        size_t cap = 1024;
+        while (cap < n) cap <<= 1;
+        if (s->d_out) HIP_TRY(hipFree(s->d_out));
+        s->d_out = nullptr;
+        HIP_TRY(hipMalloc(&s->d_out, cap * s->ch * esz(s)));
+        s->out_cap = cap;
+    }
+    hipsoxr_job_t j;
+    std::memset(&j, 0, sizeof j);
+    j.in = s->d_in; j.out = s->d_out; j.elem = s->elem; j.kernel = HIPSOXR_KERNEL_AUTO;
+    j.n_clips = 1; j.n_channels = s->ch;
+    if (!s->split) {
+        j.in_frame_stride = s->ch; j.in_chan_stride = 1;
+        j.out_frame_stride = s->ch; j.out_chan_stride = 1;
+    } else {
+        j.in_frame_stride = 1; j.in_chan_stride = (int64_t)s->in_cap;
+        j.out_frame_stride = 1; j.out_chan_stride = (int64_t)s->out_cap;
+    }
+    j.in_abs0 = s->in_base; j.in_frames = (int64_t)s->in_fill;
+    j.out_k0 = (int64_t)s->k_done; j.out_frames = (int64_t)n;
+    j.clip_counter = s->d_clips;
+    j.dither = (s->elem == HIPSOXR_I16 && !(s->flags & HIPSOXR_NO_DITHER)) ? 1u : 0u;
+    j.dither_seed = 0;
+    if (s->in_fill == 0) { // nothing staged yet (e.g. flush of an empty stream): any valid pointer
+        j.in = s->d_out;
+    }
+    if (const char *e = launch_job(&s->plan->p, j, s->st)) return e;
+    if (!s->split) {
+        HIP_TRY(hipMemcpyAsync(out, s->d_out, n * s->ch * esz(s), hipMemcpyDeviceToHost, s->st));
+    } else {
+        void *const *chans = (void *const *)out;
+        for (unsigned c = 0; c < s->ch; ++c)
+            HIP_TRY(hipMemcpyAsync(chans[c], (char *)s->d_out + (size_t)c * s->out_cap * esz(s),
+                                   n * esz(s), hipMemcpyDeviceToHost, s->st));
+    }
+    HIP_TRY(hipStreamSynchronize(s->st));
+    s->k_done += n;
+    return nullptr;
+}
+
+static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr_datatype_t io,
+                              unsigned long flags, hipsoxr_stream **out)
+{
+    if (ch < 1) return "invalid channel count";
+    if ((int)io < 0 || (int)io > 7) return "invalid io datatype";
+    if (flags & HIPSOXR_VR) return "variable-rate (SOXR_VR) resampling is not implemented";
+    if (device_count() <= 0) return kNoDevice;
+    hipsoxr_stream *s = new (std::nothrow) hipsoxr_stream();
+    if (!s) return "out of memory";
+    s->plan = plan; s->own_plan = own; s->ch = ch;
+    s->elem = (int)io & 3; s->split = ((int)io & 4) != 0; s->flags = flags;
+    const char *err = nullptr;
+    do {
+        if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
+            err = "hipStreamCreate failed"; break;
+        }
+        if (hipMalloc((void **)&s->d_clips, sizeof(uint64_t)) != hipSuccess) {
+            err = "hipMalloc failed"; break;
+        }
+        if (hipMemsetAsync(s->d_clips, 0, sizeof(uint64_t), s->st) != hipSuccess) {
+            err = "hipMemset failed"; break;
+        }
+        err = device_bank_ensure(&plan->p, engine_prec(s->elem));
+    } while (0);
+    std::snprintf(s->engine_name, sizeof s->engine_name, "hip-gfx950-%s",
+                  engine_prec(s->elem) == 0 ? "f32" : "f64");
+    if (err) {
+        hipsoxr_stream_delete(s);
+        return err;
+    }
+    *out = s;
+    return nullptr;
+}
+
+extern "C" {
+
+hipsoxr_error_t hipsoxr_stream_create(double in_rate, double out_rate, unsigned num_channels,
+                                      hipsoxr_datatype_t io_type, unsigned long recipe,
+                                      unsigned long flags, hipsoxr_stream_t **out)
+{
+    if (!out) return "null argument";
+    *out = nullptr;
+    hipsoxr_plan_t *plan = nullptr;
+    if (const char *e = hipsoxr_plan_create(in_rate, out_rate, recipe, &plan)) return e;
+    if (const char *e = stream_new(plan, false, num_channels, io_type, flags, out)) {
+        hipsoxr_plan_delete(plan);
+        return e;
+    }
+    (*out)->own_plan = true;
+    return nullptr;
+}
+
+hipsoxr_error_t hipsoxr_stream_create_with_plan(hipsoxr_plan_t *plan, unsigned num_channels,
+                                                hipsoxr_datatype_t io_type, unsigned long flags,
+                                                hipsoxr_stream_t **out)
+{
+    if (!out || !plan) return "null argument";
+    *out = nullptr;
+    return stream_new(plan, false, num_channels, io_type, flags, out);
+}
+
+void hipsoxr_stream_delete(hipsoxr_stream_t *s)
+{
+    if (!s) return;
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    if (s->d_in) (void)hipFree(s->d_in);
+    if (s->d_in_alt) (void)hipFree(s->d_in_alt);
+    if (s->d_out) (void)hipFree(s->d_out);
+    if (s->d_clips) (void)hipFree(s->d_clips);
+    if (s->st) (void)hipStreamDestroy(s->st);
+    if (s->own_plan) delete s->plan;
+    delete s;
+}
+
+hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size_t ilen, void *out,
+                                       size_t olen, size_t *odone)
+{
+    if (!s || !odone) return "null argument";
+    *odone = 0;
+    if (in == nullptr) {
+        s->ended = true; // end of input: flush
+    } else if (ilen > 0) {
+        if (s->ended) return "Input after last input";
+        if (const char *e = stream_append(s, in, ilen)) return e;
+    }
+    if (olen == 0 || out == nullptr) {
+        if (in && ilen) HIP_TRY(hipStreamSynchronize(s->st)); // host buffer is borrowed only for the call
+        return nullptr;
+    }
+    return stream_emit(s, out, olen, odone);
+}
+
+hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
+{
+    if (!s) return "null argument";
+    s->ended = false; s->n_in_total = 0; s->k_done = 0; s->in_base = 0; s->in_fill = 0;
+    HIP_TRY(hipMemsetAsync(s->d_clips, 0, sizeof(uint64_t), s->st));
+    HIP_TRY(hipStreamSynchronize(s->st));
+    return nullptr;
+}
+
+double hipsoxr_stream_delay(hipsoxr_stream_t *s)
+{
+    if (!s) return 0.;
+    const Plan &p = s->plan->p;
+    double d = (double)s->n_in_total * (double)p.L / (double)p.M - (double)s->k_done;
+    return d > 0. ? d : 0.;
+}
+
+size_t hipsoxr_stream_num_clips(hipsoxr_stream_t *s)
+{
+    if (!s) return 0;
+    uint64_t v = 0;
+    if (hipMemcpyAsync(&v, s->d_clips, sizeof v, hipMemcpyDeviceToHost, s->st) != hipSuccess) return 0;
+    (void)hipStreamSynchronize(s->st);
+    return (size_t)v;
+}
+
+const char *hipsoxr_stream_engine(hipsoxr_stream_t *s) { return s ? s->engine_name : ""; }
+
+hipsoxr_error_t hipsoxr_stream_set_io_ratio(hipsoxr_stream_t *, double, size_t)
+{
+    return "variable-rate (SOXR_VR) resampling is not implemented";
+}
+
+hipsoxr_plan_t *hipsoxr_stream_plan(hipsoxr_stream_t *s) { return s ? s->plan : nullptr; }
+
+hipsoxr_error_t hipsoxr_oneshot(double in_rate, double out_rate, unsigned num_channels,
+                                const void *in, size_t ilen, void *out, size_t olen, size_t *odone,
+                                hipsoxr_datatype_t io_type, unsigned long recipe,
+                                unsigned long flags)
+{
+    if (!odone) return "null argument";
+    *odone = 0;
+    hipsoxr_stream_t *s = nullptr;
+    if (const char *e = hipsoxr_stream_create(in_rate, out_rate, num_channels, io_type, recipe, flags, &s))
+        return e;
+    const char *err = nullptr;
+    if (ilen) err = stream_append(s, in, ilen);
+    s->ended = true; // whole signal known: a single launch covers body and tail
+    if (!err && olen && out) err = stream_emit(s, out, olen, odone);
+    else if (!err) err = (hipStreamSynchronize(s->st) == hipSuccess) ? nullptr : "hip sync failed";
+    hipsoxr_stream_delete(s);
+    return err;
+}
+
+} // extern "C"

@@ -1,0 +1,615 @@
+// kernels.hip — the soxr_process hot path on CDNA4 (gfx950).  Hand-written HIP, no MFMA.
+//
+// Replaces the inner product libsoxr runs inside soxr_process (reference call sites
+// src/soxr_ext.cpp:163-166, :245-248, :328-331):
+//     y[k] = sum_j bank[(k*M) mod L][j] * x[floor(k*M/L) - (T/2-1) + j]
+// followed by the conversion to the I/O type (round-half-even, saturate, clip count, TPDF dither
+// for int16).
+//
+// CANONICAL ARITHMETIC (shared with oracle/soxr_oracle.c *_port, bit for bit):
+//     accL = 0; for j = 0 .. T/2-1 ascending : accL = fma(c[j], x[j], accL)
+//     accR = 0; for j = T-1 .. T/2 descending: accR = fma(c[j], x[j], accR)
+//     y = accL + accR
+// in the engine precision Real (float for f32/i16 I/O, double for f64/i32 I/O).  Each output
+// sample is one pair of serial FMA chains that depends on nothing but its own taps, so results are
+// independent of chunking, tiling, launch geometry and kernel choice (the bit-exact invariances of
+// reference tests test_divide_match / test_stream_length).  Zero-padded table entries contribute
+// fma(0, x, acc) == acc exactly for finite x.
+//
+// Two kernels:
+//   k_gather  one lane per output sample; coefficients gathered from the tap-major bank
+//             [T][Lpad] (lanes of a wave read neighbouring phases of one tap row), input read
+//             straight from global memory (a wave touches ~64*M/L consecutive samples per tap).
+//             Handles every ratio / layout / length; used for small jobs (streaming chunks).
+//   k_tile    throughput kernel.  A workgroup stages the input of 64 consecutive periods
+//             (period = L outputs <- M inputs) of one channel in LDS (coalesced read, row stride
+//             padded so that lane-per-period reads are bank-conflict free).  Each wavefront owns a
+//             tile of RT consecutive output phases; ALL 64 LANES SHARE THE TILE'S COEFFICIENTS,
+//             which therefore travel on the scalar path (s_load from the constant address space
+//             into SGPRs, used directly as v_fmac operands) — the inner loop is one ds_read_b128
+//             per 4*RT FMAs and no cross-lane reduction at all.
+//
+// Why not the "one wavefront per output + __shfl reduction" shape: 6 DPP/shuffle steps plus two
+// LDS reads per ~4.6 FMAs caps VALU utilisation near 30 %; a 1-D FIR at 296 taps/output is
+// VALU-bound on MI355X (592 flop per 8.35 B), so FMA issue rate is what matters.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "device.h"
+
+namespace hipsoxr {
+
+// ---------------------------------------------------------------------------------------------
+// conversions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+// TPDF dither in (-1, 1) LSB: pure function of (seed, channel, absolute output index).
+__device__ __forceinline__ float dither_tpdf(uint32_t seed, uint32_t ch, int64_t k)
+{
+    uint64_t z = mix64((uint64_t)k * 0x9E3779B97F4A7C15ULL + (((uint64_t)ch << 32) | seed));
+    int32_t u1 = (int32_t)(z & 0xFFFFFF), u2 = (int32_t)((z >> 24) & 0xFFFFFF);
+    return (float)(u1 - u2) * (1.f / 16777216.f);
+}
+
+struct OutCtx {
+    uint64_t *clip_counter;
+    uint32_t dither, seed;
+};
+
+template <typename Real>
+__device__ __forceinline__ void store_out(float *p, Real v, const OutCtx &, uint32_t, int64_t)
+{
+    *p = (float)v;
+}
+template <typename Real>
+__device__ __forceinline__ void store_out(double *p, Real v, const OutCtx &, uint32_t, int64_t)
+{
+    *p = (double)v;
+}
+template <typename Real>
+__device__ __forceinline__ void store_out(int16_t *p, Real v, const OutCtx &c, uint32_t ch, int64_t k)
+{
+    float a = (float)v;
+    if (c.dither) a = a + dither_tpdf(c.seed, ch, k);
+    float r = __builtin_rintf(a);
+    bool clip = false;
+    if (r > 32767.f) { r = 32767.f; clip = true; }
+    else if (r < -32768.f) { r = -32768.f; clip = true; }
+    if (clip && c.clip_counter) atomicAdd((unsigned long long *)c.clip_counter, 1ULL);
+    *p = (int16_t)r;
+}
+template <typename Real>
+__device__ __forceinline__ void store_out(int32_t *p, Real v, const OutCtx &c, uint32_t, int64_t)
+{
+    double r = __builtin_rint((double)v);
+    bool clip = false;
+    if (r > 2147483647.) { r = 2147483647.; clip = true; }
+    else if (r < -2147483648.) { r = -2147483648.; clip = true; }
+    if (clip && c.clip_counter) atomicAdd((unsigned long long *)c.clip_counter, 1ULL);
+    *p = (int32_t)r;
+}
+
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---------------------------------------------------------------------------------------------
+// k_gather
+// ---------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const void *in;
+    void *out;
+    const void *bank; // tap-major [T][Lpad] Real
+    int64_t Lpad, L, M;
+    int32_t T;
+    uint32_t n_clips, n_channels;
+    int64_t ics, ifs, ichs, ocs, ofs, ochs;
+    int64_t in_abs0, in_frames;
+    int64_t out_k0, out_frames;
+    int64_t d0, p0; // out_k0*M = L*d0 + p0
+    OutCtx oc;
+    int32_t ch_fast; // 1: consecutive threads = consecutive channels of one frame
+};
+
+template <typename IO, typename Real>
+__global__ void __launch_bounds__(256) k_gather(GatherArgs a)
+{
+    int64_t idx;
+    uint32_t ch, clip;
+    if (a.ch_fast) {
+        int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        idx = e / a.n_channels;
+        ch = (uint32_t)(e - idx * a.n_channels);
+        clip = blockIdx.y;
+    } else {
+        idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        ch = blockIdx.y % a.n_channels;
+        clip = blockIdx.y / a.n_channels;
+    }
+    if (idx >= a.out_frames) return;
+    // position: (out_k0 + idx)*M = L*d + p
+    const int64_t t = a.p0 + idx * a.M;
+    const int64_t q = t / a.L;
+    const int64_t p = t - q * a.L;
+    const int64_t n0 = a.d0 + q - (a.T / 2 - 1);  // absolute index of tap 0's input sample
+    const int64_t loc0 = n0 - a.in_abs0;          // its index relative to in[frame 0]
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    const Real *c = (const Real *)a.bank + p;
+    const int32_t T = a.T, H = T / 2;
+    Real accL = 0, accR = 0;
+    if (loc0 >= 0 && loc0 + T <= a.in_frames) {
+        const IO *xp = xin + loc0 * a.ifs;
+        for (int j = 0; j < H; ++j)
+            accL = fma_r(c[(int64_t)j * a.Lpad], (Real)xp[(int64_t)j * a.ifs], accL);
+        for (int j = T - 1; j >= H; --j)
+            accR = fma_r(c[(int64_t)j * a.Lpad], (Real)xp[(int64_t)j * a.ifs], accR);
+    } else {
+        for (int j = 0; j < H; ++j) {
+            int64_t l = loc0 + j;
+            Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+            accL = fma_r(c[(int64_t)j * a.Lpad], xv, accL);
+        }
+        for (int j = T - 1; j >= H; --j) {
+            int64_t l = loc0 + j;
+            Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+            accR = fma_r(c[(int64_t)j * a.Lpad], xv, accR);
+        }
+    }
+    IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + idx * a.ofs + (int64_t)ch * a.ochs;
+    store_out<Real>(yo, accL + accR, a.oc, ch, a.out_k0 + idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tile
+// ---------------------------------------------------------------------------------------------
+// Geometry (host-built, see build_tile_tables): the plan's period may be replicated c times so
+// that Lc = c*L >= RT; "period" below means the replicated period (Lc outputs <- Mc inputs).
+//   tile rt covers outputs r = rt*RT .. rt*RT+RT-1 of a period; for row r
+//       n_r = floor(r*M/L) - (T/2-1)   (first input, relative to the period's first input)
+//       p_r = (r*M) mod L              (phase)
+//   left  half-chain: inputs i = eL0 + ii            (ascending),  table L[ii][rr]
+//   right half-chain: inputs i = eR0 + 3 - ii        (descending), table R[ii][rr]
+//   (e-coordinates are relative to i_min, the first input sample kept in LDS.)
+struct TileArgs {
+    const void *in;
+    void *out;
+    const void *tab;     // [n_rt][2][I_h][RT] Real, constant address space
+    const int32_t *e0;   // [n_rt][2]  (eL0, eR0)
+    int64_t Lc, Mc;      // replicated period
+    int32_t n_rt, I_h, n_waves;
+    int32_t pad, i_min, x_count; // LDS row padding; first staged input; samples staged per tile
+    uint32_t n_clips, n_channels;
+    int64_t ics, ifs, ichs, ocs, ofs, ochs;
+    int64_t in_abs0, in_frames;
+    int64_t out_k0, out_frames;
+    int64_t b_first;     // absolute (replicated) period index handled by lane 0 of block x = 0
+    OutCtx oc;
+};
+
+template <typename IO, typename Real, int RT, bool ALIGNED>
+__global__ void __launch_bounds__(512) k_tile(TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Real *xs = reinterpret_cast<Real *>(smem_raw);
+
+    const uint32_t col = blockIdx.y;
+    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64; // first period of this workgroup
+    const int32_t Mc = (int32_t)a.Mc, pad = a.pad;
+
+    // ---- stage the input slab: samples [bw*Mc + i_min, +x_count), zero outside the signal ----
+    {
+        const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+        const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
+        for (int32_t n = threadIdx.x; n < a.x_count; n += blockDim.x) {
+            int64_t l = loc_base + n;
+            Real v = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+            xs[n + pad * (n / Mc)] = v;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = a.n_waves; // == blockDim.x / 64, passed as an argument so it stays scalar
+    const Real *xl = xs + lane * (Mc + pad);
+    const int64_t b = bw + lane; // this lane's period
+    typedef const __attribute__((address_space(4))) Real *CPtr;
+
+    for (int rt_ = wave; rt_ < a.n_rt; rt_ += n_waves) {
+        // keep the tile index (and everything derived from it) provably wave-uniform: the
+        // coefficient loads below must be scalar (s_load), not per-lane
+        const int rt = __builtin_amdgcn_readfirstlane(rt_);
+        const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]);
+        const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
+        CPtr tL = (CPtr)((const Real *)a.tab + (size_t)(rt * 2 + 0) * a.I_h * RT);
+        CPtr tR = (CPtr)((const Real *)a.tab + (size_t)(rt * 2 + 1) * a.I_h * RT);
+        Real accL[RT], accR[RT];
+#pragma unroll
+        for (int rr = 0; rr < RT; ++rr) { accL[rr] = 0; accR[rr] = 0; }
+
+        // left half: ascending inputs
+        {
+            int32_t e = eL0, padoff = pad * (e / Mc), next = (e / Mc + 1) * Mc;
+            for (int32_t q = 0; q < a.I_h; q += 4) {
+                Real x0, x1, x2, x3;
+                if (ALIGNED) {
+                    const Real *px = xl + e + padoff;
+                    x0 = px[0]; x1 = px[1]; x2 = px[2]; x3 = px[3];
+                } else {
+                    // a chunk may straddle row-padding points: resolve each sample separately
+                    const int32_t e1 = e + 1, e2 = e + 2, e3 = e + 3;
+                    if (pad) {
+                        x0 = xl[e + pad * (e / Mc)];
+                        x1 = xl[e1 + pad * (e1 / Mc)];
+                        x2 = xl[e2 + pad * (e2 / Mc)];
+                        x3 = xl[e3 + pad * (e3 / Mc)];
+                    } else {
+                        x0 = xl[e]; x1 = xl[e1]; x2 = xl[e2]; x3 = xl[e3];
+                    }
+                }
+                CPtr t = tL + (size_t)q * RT;
+#pragma unroll
+                for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[0 * RT + rr], x0, accL[rr]);
+#pragma unroll
+                for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[1 * RT + rr], x1, accL[rr]);
+#pragma unroll
+                for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[2 * RT + rr], x2, accL[rr]);
+#pragma unroll
+                for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[3 * RT + rr], x3, accL[rr]);
+                e += 4;
+                if (e >= next) { padoff += pad; next += Mc; }
+            }
+        }
+        // right half: descending inputs (chunk = 4 ascending addresses consumed high to low)
+        {
+            int32_t e = eR0, padoff = pad * (e / Mc), lo = (e / Mc) * Mc;
+            for (int32_t q = 0; q < a.I_h; q += 4) {
+                Real x0, x1, x2, x3;
+                if (ALIGNED) {
+                    const Real *px = xl + e + padoff;
+                    x0 = px[0]; x1 = px[1]; x2 = px[2]; x3 = px[3];
+                } else {
+                    const int32_t e1 = e + 1, e2 = e + 2, e3 = e + 3;
+                    if (pad) {
+                        x0 = xl[e + pad * (e / Mc)];
+                        x1 = xl[e1 + pad * (e1 / Mc)];
+                        x2 = xl[e2 + pad * (e2 / Mc)];
+                        x3 = xl[e3 + pad * (e3 / Mc)];
+                    } else {
+                        x0 = xl[e]; x1 = xl[e1]; x2 = xl[e2]; x3 = xl[e3];
+                    }
+                }
+                CPtr t = tR + (size_t)q * RT;
+#pragma unroll
+                for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[0 * RT + rr], x3, accR[rr]);
+#pragma unroll
+                for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[1 * RT + rr], x2, accR[rr]);
+#pragma unroll
+                for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[2 * RT + rr], x1, accR[rr]);
+#pragma unroll
+                for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[3 * RT + rr], x0, accR[rr]);
+                e -= 4;
+                if (e < lo) { padoff -= pad; lo -= Mc; }
+            }
+        }
+        // store: output k = b*Lc + rt*RT + rr
+        const int64_t kbase = b * a.Lc + (int64_t)rt * RT;
+        IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+#pragma unroll
+        for (int rr = 0; rr < RT; ++rr) {
+            const int64_t k = kbase + rr, idx = k - a.out_k0;
+            if (rt * RT + rr < a.Lc && idx >= 0 && idx < a.out_frames)
+                store_out<Real>(yo + idx * a.ofs, accL[rr] + accR[rr], a.oc, ch, k);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: device tables
+// ---------------------------------------------------------------------------------------------
+#define HIP_TRY(expr)                                                    \
+    do {                                                                 \
+        hipError_t e_ = (expr);                                          \
+        if (e_ != hipSuccess) return hipGetErrorString(e_);              \
+    } while (0)
+
+int device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline int32_t floor4(int32_t v) { return v >= 0 ? (v / 4) * 4 : -(((-v) + 3) / 4) * 4; }
+
+struct TileGeom {
+    int RT = 16, c = 1;
+    bool aligned = false;
+    int32_t n_rt = 0, I_h = 0, pad = 0, i_min = 0, x_count = 0;
+    int64_t Lc = 0, Mc = 0;
+    size_t lds_bytes = 0;
+    std::vector<int32_t> e0;
+    bool ok = false;
+};
+
+// Tile geometry + (optionally) tables for one precision.
+template <typename Real>
+static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab)
+{
+    TileGeom g;
+    const int64_t L = p.L, M = p.M;
+    const int32_t T = p.T, H = T / 2;
+    g.RT = 16;
+    // replicate short periods so that a period holds at least one full tile
+    int c = 1;
+    while (L * c < g.RT && c < 64) c *= 2;
+    // prefer an input period that is a multiple of 4 (b128 LDS reads) when the slab stays small
+    if (M % 2 == 0 || M * 4 <= 256)
+        while ((M * c) % 4 != 0 && M * c * 2 <= 256 && c < 64) c *= 2;
+    g.c = c;
+    g.Lc = L * c; g.Mc = M * c;
+    if (g.Mc > 8192 || g.Lc > 16384) return g; // period too long for an LDS-resident slab
+    g.aligned = (g.Mc % 4 == 0);
+    const int32_t Mc = (int32_t)g.Mc;
+    if (g.aligned) { // row stride = 4*odd words -> conflict-free ds_read_b128 across lanes
+        g.pad = ((Mc / 4) % 2 == 0) ? 4 : 0;
+    } else {         // row stride odd -> conflict-free ds_read_b32
+        g.pad = (Mc % 2 == 0) ? 1 : 0;
+    }
+    g.n_rt = (int32_t)((g.Lc + g.RT - 1) / g.RT);
+    auto n_of = [&](int64_t r) { return (int32_t)((r * M) / L) - (H - 1); };
+    auto p_of = [&](int64_t r) { return (r * M) % L; };
+    std::vector<int32_t> i0L(g.n_rt), i1R(g.n_rt);
+    int32_t I_h = 0;
+    for (int rt = 0; rt < g.n_rt; ++rt) {
+        int64_t r0 = (int64_t)rt * g.RT, r1 = std::min<int64_t>(r0 + g.RT, g.Lc) - 1;
+        int32_t a0 = n_of(r0), a1 = n_of(r1) + T - 1;
+        if (g.aligned) {
+            a0 = floor4(a0);
+            a1 = floor4(a1) + 3; // smallest value >= a1 that is == 3 (mod 4)
+        }
+        i0L[rt] = a0; i1R[rt] = a1;
+        int32_t IL = n_of(r1) + H - a0;        // inputs a0 .. n_r1+H-1
+        int32_t IR = a1 - (n_of(r0) + H) + 1;  // inputs n_r0+H .. a1
+        I_h = std::max(I_h, std::max(IL, IR));
+    }
+    I_h = (I_h + 3) / 4 * 4;
+    g.I_h = I_h;
+    int32_t i_min = INT32_MAX, i_max = INT32_MIN;
+    for (int rt = 0; rt < g.n_rt; ++rt) {
+        i_min = std::min(i_min, std::min(i0L[rt], i1R[rt] - I_h + 1));
+        i_max = std::max(i_max, std::max(i0L[rt] + I_h - 1, i1R[rt]));
+    }
+    if (g.aligned) { i_min = floor4(i_min); i_max = floor4(i_max) + 3; }
+    g.i_min = i_min;
+    g.x_count = 63 * Mc + (i_max - i_min + 1);
+    g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / Mc + 1) + 4) * sizeof(Real);
+    g.e0.resize((size_t)g.n_rt * 2);
+    for (int rt = 0; rt < g.n_rt; ++rt) {
+        g.e0[rt * 2 + 0] = i0L[rt] - i_min;
+        g.e0[rt * 2 + 1] = i1R[rt] - 3 - i_min;
+    }
+    if (g.lds_bytes > 160 * 1024) return g;
+    g.ok = true;
+    if (tab) {
+        tab->assign((size_t)g.n_rt * 2 * I_h * g.RT, (Real)0);
+        for (int rt = 0; rt < g.n_rt; ++rt) {
+            Real *tl = tab->data() + (size_t)(rt * 2 + 0) * I_h * g.RT;
+            Real *tr = tab->data() + (size_t)(rt * 2 + 1) * I_h * g.RT;
+            for (int rr = 0; rr < g.RT; ++rr) {
+                int64_t r = (int64_t)rt * g.RT + rr;
+                if (r >= g.Lc) continue;
+                const int32_t nr = n_of(r);
+                const double *cp = p.bank.data() + (size_t)(p_of(r) * T);
+                for (int ii = 0; ii < I_h; ++ii) {
+                    int32_t jl = i0L[rt] + ii - nr;
+                    if (jl >= 0 && jl < H) tl[(size_t)ii * g.RT + rr] = (Real)cp[jl];
+                    int32_t jr = i1R[rt] - ii - nr;
+                    if (jr >= H && jr < T) tr[(size_t)ii * g.RT + rr] = (Real)cp[jr];
+                }
+            }
+        }
+    }
+    return g;
+}
+
+template <typename Real>
+static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out)
+{
+    const int64_t L = p->L;
+    const int32_t T = p->T;
+    d.Lpad = (L + 15) / 16 * 16;
+    std::vector<Real> tm((size_t)T * d.Lpad, (Real)0);
+    for (int64_t ph = 0; ph < L; ++ph)
+        for (int j = 0; j < T; ++j) tm[(size_t)j * d.Lpad + ph] = (Real)p->bank[(size_t)(ph * T + j)];
+    HIP_TRY(hipMalloc(&d.tap_major, tm.size() * sizeof(Real)));
+    HIP_TRY(hipMemcpy(d.tap_major, tm.data(), tm.size() * sizeof(Real), hipMemcpyHostToDevice));
+
+    std::vector<Real> tab;
+    TileGeom g = build_tile_tables<Real>(*p, &tab);
+    if (g.ok) {
+        HIP_TRY(hipMalloc(&d.tile_tab, tab.size() * sizeof(Real)));
+        HIP_TRY(hipMemcpy(d.tile_tab, tab.data(), tab.size() * sizeof(Real), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&d.tile_i0, g.e0.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(d.tile_i0, g.e0.data(), g.e0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        d.RT = g.RT; d.n_rt = g.n_rt; d.I_h = g.I_h;
+    }
+    *geom_out = g;
+    return nullptr;
+}
+
+// geometry is cheap to recompute; keep it beside the bank in a side table keyed by (plan, prec)
+static std::mutex g_geom_mu;
+static std::vector<std::pair<std::pair<const Plan *, int>, TileGeom>> g_geoms;
+
+static TileGeom *geom_find(const Plan *p, int prec)
+{
+    for (auto &e : g_geoms)
+        if (e.first.first == p && e.first.second == prec) return &e.second;
+    return nullptr;
+}
+
+const char *device_bank_ensure(Plan *p, int prec)
+{
+    std::lock_guard<std::mutex> lk(p->mu);
+    DeviceBank &d = p->dev[prec];
+    if (d.ready) return nullptr;
+    if (device_count() <= 0) return "no HIP device available (hipsoxr has no CPU fallback)";
+    TileGeom g;
+    const char *e = prec == 0 ? bank_upload<float>(p, d, &g) : bank_upload<double>(p, d, &g);
+    if (e) return e;
+    {
+        std::lock_guard<std::mutex> lk2(g_geom_mu);
+        g_geoms.push_back({{p, prec}, g});
+    }
+    d.ready = true;
+    return nullptr;
+}
+
+void device_bank_release(Plan *p)
+{
+    for (int i = 0; i < 2; ++i) {
+        DeviceBank &d = p->dev[i];
+        if (d.tap_major) (void)hipFree(d.tap_major);
+        if (d.tile_tab) (void)hipFree(d.tile_tab);
+        if (d.tile_i0) (void)hipFree(d.tile_i0);
+        d = DeviceBank();
+    }
+    std::lock_guard<std::mutex> lk2(g_geom_mu);
+    for (size_t i = 0; i < g_geoms.size();)
+        if (g_geoms[i].first.first == p) g_geoms.erase(g_geoms.begin() + i);
+        else ++i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------
+template <typename IO, typename Real>
+static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
+{
+    const DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
+    // split so that idx*M stays far below 2^63 and grid.x below 2^31
+    const int64_t max_chunk = (int64_t)1 << 30;
+    for (int64_t done = 0; done < j.out_frames; done += max_chunk) {
+        GatherArgs a;
+        const int64_t k0 = j.out_k0 + done;
+        const int64_t nf = std::min<int64_t>(max_chunk, j.out_frames - done);
+        a.in = j.in;
+        a.out = (char *)j.out + (size_t)(done * j.out_frame_stride) * sizeof(IO);
+        a.bank = d.tap_major; a.Lpad = d.Lpad; a.L = p->L; a.M = p->M; a.T = p->T;
+        a.n_clips = j.n_clips; a.n_channels = j.n_channels;
+        a.ics = j.in_clip_stride; a.ifs = j.in_frame_stride; a.ichs = j.in_chan_stride;
+        a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
+        a.in_abs0 = j.in_abs0; a.in_frames = j.in_frames;
+        a.out_k0 = k0; a.out_frames = nf;
+        __int128 kM = (__int128)k0 * p->M;
+        a.d0 = (int64_t)(kM / p->L); a.p0 = (int64_t)(kM % p->L);
+        a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed;
+        a.ch_fast = (j.n_channels > 1 && j.in_chan_stride == 1) ? 1 : 0;
+        dim3 grid, block(256);
+        if (a.ch_fast) {
+            int64_t e = nf * (int64_t)j.n_channels;
+            grid = dim3((unsigned)((e + 255) / 256), j.n_clips, 1);
+            if (j.n_clips > 65535) return "too many clips for one launch (max 65535)";
+        } else {
+            uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
+            if (cols > 65535) {
+                // fold: launch per clip group
+                return "too many (clip, channel) columns for one launch (max 65535)";
+            }
+            grid = dim3((unsigned)((nf + 255) / 256), (unsigned)cols, 1);
+        }
+        hipLaunchKernelGGL((k_gather<IO, Real>), grid, block, 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return nullptr;
+}
+
+template <typename IO, typename Real>
+static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const TileGeom &g)
+{
+    const DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
+    TileArgs a;
+    a.in = j.in; a.out = j.out; a.tab = d.tile_tab; a.e0 = d.tile_i0;
+    a.Lc = g.Lc; a.Mc = g.Mc; a.n_rt = g.n_rt; a.I_h = g.I_h;
+    a.pad = g.pad; a.i_min = g.i_min; a.x_count = g.x_count;
+    a.n_clips = j.n_clips; a.n_channels = j.n_channels;
+    a.ics = j.in_clip_stride; a.ifs = j.in_frame_stride; a.ichs = j.in_chan_stride;
+    a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
+    a.in_abs0 = j.in_abs0; a.in_frames = j.in_frames;
+    a.out_k0 = j.out_k0; a.out_frames = j.out_frames;
+    a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed;
+    // periods touched: floor(k0/Lc) .. floor((k0+n-1)/Lc)
+    const int64_t b_lo = j.out_k0 / g.Lc, b_hi = (j.out_k0 + j.out_frames - 1) / g.Lc;
+    a.b_first = b_lo;
+    const int64_t n_blocks = (b_hi - b_lo + 1 + 63) / 64;
+    const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
+    if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";
+    if (n_blocks > 2147483647LL) return "job too long for one launch";
+    // waves per workgroup: spread the n_rt tiles evenly, 4..8 waves
+    int nw = g.n_rt < 4 ? g.n_rt : 4;
+    {
+        int best = nw, best_waste = 1 << 30;
+        for (int w = std::min(g.n_rt, 8); w >= std::min(g.n_rt, 4); --w) {
+            int rounds = (g.n_rt + w - 1) / w, waste = rounds * w - g.n_rt;
+            if (waste < best_waste) { best_waste = waste; best = w; }
+        }
+        nw = best;
+    }
+    a.n_waves = nw;
+    dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
+    auto kern = g.aligned ? k_tile<IO, Real, 16, true> : k_tile<IO, Real, 16, false>;
+    if (g.lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)g.lds_bytes));
+    hipLaunchKernelGGL(kern, grid, block, g.lds_bytes, st, a);
+    HIP_TRY(hipGetLastError());
+    return nullptr;
+}
+
+template <typename IO, typename Real>
+static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
+{
+    const int prec = sizeof(Real) == 4 ? 0 : 1;
+    TileGeom g;
+    {
+        std::lock_guard<std::mutex> lk(g_geom_mu);
+        TileGeom *gp = geom_find(p, prec);
+        if (gp) g = *gp;
+    }
+    int kernel = j.kernel;
+    if (kernel == HIPSOXR_KERNEL_TILE && !g.ok) return "tile kernel unavailable for this plan";
+    if (kernel == HIPSOXR_KERNEL_AUTO) {
+        // the tile kernel pays off once a job spans a few thousand outputs per column
+        const bool big = g.ok && j.out_frames >= 16 * g.Lc && j.out_frames >= 4096;
+        kernel = big ? HIPSOXR_KERNEL_TILE : HIPSOXR_KERNEL_GATHER;
+    }
+    if (kernel == HIPSOXR_KERNEL_TILE) return launch_tile<IO, Real>(p, j, st, g);
+    return launch_gather<IO, Real>(p, j, st);
+}
+
+const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream)
+{
+    if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return nullptr;
+    const int prec = engine_prec(j.elem);
+    if (const char *e = device_bank_ensure(p, prec)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    switch (j.elem) {
+    case HIPSOXR_F32: return launch_typed<float, float>(p, j, st);
+    case HIPSOXR_F64: return launch_typed<double, double>(p, j, st);
+    case HIPSOXR_I32: return launch_typed<int32_t, double>(p, j, st);
+    case HIPSOXR_I16: return launch_typed<int16_t, float>(p, j, st);
+    }
+    return "invalid element type";
+}
+
+} // namespace hipsoxr

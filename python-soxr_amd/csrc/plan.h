@@ -1,0 +1,62 @@
+// plan.h — immutable conversion plan: rational ratio, polyphase bank, device tables.
+//
+// A plan is what libsoxr's soxr_create designs per handle (reference call sites
+// src/soxr_ext.cpp:76-78, :230-232, :305-307), factored out so that any number of streams, batch
+// jobs and ranks share one bank.
+#pragma once
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace hipsoxr {
+
+struct QualitySpec {
+    double bits;           // 0 (QQ cubic), 16, 20, 28
+    double passband_end;   // fraction of the lower rate's Nyquist
+    double stopband_begin; // ditto
+};
+
+// Device-resident tables for one engine precision (float or double).
+struct DeviceBank {
+    void *tap_major = nullptr;   // [T][Lpad]   (gather kernel: lanes read neighbouring phases)
+    int64_t Lpad = 0;
+    // tile kernel: per output-tile skewed, zero-padded half tables (see kernels.hip)
+    void *tile_tab = nullptr;    // [n_rt][2][I_h][RT]
+    int32_t RT = 0, n_rt = 0, I_h = 0;
+    std::vector<int32_t> tile_i0L_host, tile_i0R_host;
+    int32_t *tile_i0 = nullptr;  // [n_rt][2] device: first input offset (rel. to period start) of each half
+    bool ready = false;
+};
+
+struct Plan {
+    double in_rate = 0, out_rate = 0;
+    unsigned long recipe = 0;
+    QualitySpec q{};
+    int64_t L = 1, M = 1; // out/in = L/M
+    int32_t T = 8;        // taps per phase
+    double att_db = 0, beta = 0;
+    std::vector<double> bank; // [L][T], float64
+    // device side (lazily built on first use, per precision: 0 = f32, 1 = f64)
+    DeviceBank dev[2];
+    std::mutex mu;
+    int device = -1;
+
+    ~Plan();
+};
+
+// Returns nullptr on success, else a static error string.
+const char *quality_spec(unsigned long recipe, QualitySpec *q);
+const char *reduce_ratio(double in_rate, double out_rate, int64_t *L, int64_t *M);
+const char *plan_design(double in_rate, double out_rate, unsigned long recipe, Plan *p);
+uint64_t plan_out_len(const Plan &p, uint64_t n_in);
+
+// Position of output k: first tap's absolute input index n0 and phase p.
+inline void locate(const Plan &pl, int64_t k, int64_t *n0, int64_t *p)
+{
+    __int128 kM = (__int128)k * pl.M;
+    *n0 = (int64_t)(kM / pl.L) - (pl.T / 2 - 1);
+    *p = (int64_t)(kM % pl.L);
+}
+
+} // namespace hipsoxr

@@ -1,0 +1,122 @@
+"""Device-resident, batched entry points — what the reference cannot express (it has no GPU and no
+batch axis; its only "batch" is the channel axis, src/soxr/__init__.py:22).
+
+`Plan` owns the shared filter bank (what soxr_create designs per handle).  `resample_tensor`
+runs the hot path on torch tensors that already live in HBM, with no host round trip; this is the
+path bench.py times.  torch is used only for device memory and streams.
+"""
+import ctypes as _C
+
+import numpy as np
+
+from . import _native as _n
+from . import _quality_to_enum
+
+
+class Plan:
+    """Immutable conversion plan: ratio L/M, polyphase bank, device tables (built lazily)."""
+
+    def __init__(self, in_rate, out_rate, quality="HQ"):
+        if in_rate <= 0 or out_rate <= 0:
+            raise ValueError("Sample rate should be over 0")
+        self._h = _C.c_void_p()
+        _n.check(_n.lib.hipsoxr_plan_create(float(in_rate), float(out_rate), _quality_to_enum(quality),
+                                            _C.byref(self._h)))
+        info = _n.PlanInfo()
+        _n.check(_n.lib.hipsoxr_plan_info(self._h, _C.byref(info)))
+        self.in_rate, self.out_rate = info.in_rate, info.out_rate
+        self.L, self.M, self.taps = int(info.L), int(info.M), int(info.taps)
+        self.precision_bits, self.passband_end = info.precision_bits, info.passband_end
+        self.stopband_begin, self.att_db, self.kaiser_beta = info.stopband_begin, info.att_db, info.kaiser_beta
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _n.lib.hipsoxr_plan_delete(h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def out_len(self, n_in):
+        return int(_n.lib.hipsoxr_plan_out_len(self._h, int(n_in)))
+
+    def bank(self):
+        """float64 bank, phase-major [L][taps]."""
+        b = np.empty((self.L, self.taps), np.float64)
+        _n.check(_n.lib.hipsoxr_plan_get_bank(self._h, b.ctypes.data, b.size))
+        return b
+
+    def set_bank(self, bank):
+        """Install a bank (e.g. the one broadcast from rank 0 over RCCL); device tables rebuild."""
+        b = np.ascontiguousarray(bank, np.float64)
+        _n.check(_n.lib.hipsoxr_plan_set_bank(self._h, b.ctypes.data, b.size))
+
+    def run(self, in_ptr, out_ptr, elem, n_clips, n_channels, in_frames, out_frames, in_strides,
+            out_strides, stream=None, kernel=_n.KERNEL_AUTO, in_abs0=0, out_k0=0, clip_counter=None,
+            dither=False, dither_seed=0):
+        """Raw launch: device pointers (ints), strides = (clip, frame, channel) in elements."""
+        j = _n.Job()
+        j.in_, j.out, j.elem, j.kernel = in_ptr, out_ptr, elem, kernel
+        j.n_clips, j.n_channels = n_clips, n_channels
+        j.in_clip_stride, j.in_frame_stride, j.in_chan_stride = in_strides
+        j.out_clip_stride, j.out_frame_stride, j.out_chan_stride = out_strides
+        j.in_abs0, j.in_frames, j.out_k0, j.out_frames = in_abs0, in_frames, out_k0, out_frames
+        j.clip_counter = clip_counter
+        j.dither, j.dither_seed = int(bool(dither)), dither_seed
+        _n.check(_n.lib.hipsoxr_run_device(self._h, _C.byref(j), stream))
+
+
+_TORCH_ELEM = None
+
+
+def _torch_elem(dtype):
+    global _TORCH_ELEM
+    import torch
+    if _TORCH_ELEM is None:
+        _TORCH_ELEM = {torch.float32: _n.F32, torch.float64: _n.F64, torch.int32: _n.I32,
+                       torch.int16: _n.I16}
+    try:
+        return _TORCH_ELEM[dtype]
+    except KeyError:
+        raise TypeError(f"Data type must be one of [float32, float64, int16, int32], not {dtype}")
+
+
+def resample_tensor(plan, x, out=None, kernel=_n.KERNEL_AUTO, dither=False, clip_counter=None):
+    """Resample a device tensor on the current torch stream, asynchronously.
+
+    x : [frames] | [frames, channels] | [clips, frames, channels] torch tensor on a HIP device
+        (any strides; channel-last is the python-soxr [frame, channel] convention).
+    Returns a tensor of the same rank with plan.out_len(frames) frames (`out` may be supplied).
+    """
+    import torch
+    if not x.is_cuda:
+        raise RuntimeError("resample_tensor needs a device tensor (soxr_amd has no CPU fallback)")
+    elem = _torch_elem(x.dtype)
+    x3 = x
+    if x.ndim == 1:
+        x3 = x[None, :, None]
+    elif x.ndim == 2:
+        x3 = x[None]
+    elif x.ndim != 3:
+        raise ValueError("Input must be 1-D, 2-D or 3-D")
+    clips, frames, ch = x3.shape
+    n_out = plan.out_len(frames)
+    if out is None:
+        out = torch.empty((clips, n_out, ch), dtype=x.dtype, device=x.device)
+        o3 = out
+    else:
+        o3 = out if out.ndim == 3 else (out[None, :, None] if out.ndim == 1 else out[None])
+        if tuple(o3.shape) != (clips, n_out, ch):
+            raise ValueError(f"out has shape {tuple(out.shape)}, expected frames={n_out}")
+    cc = clip_counter.data_ptr() if clip_counter is not None else None
+    if n_out and clips and ch:
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        plan.run(x3.data_ptr(), o3.data_ptr(), elem, clips, ch, frames, n_out, tuple(x3.stride()),
+                 tuple(o3.stride()), stream=stream, kernel=kernel, clip_counter=cc, dither=dither)
+    if x.ndim == 1:
+        return o3[0, :, 0]
+    if x.ndim == 2:
+        return o3[0]
+    return o3

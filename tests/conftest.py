@@ -1,0 +1,61 @@
+"""Shared test plumbing.
+
+* `-m "not gpu"`: oracle vs the reference's known-answer tests and the committed golden vectors,
+  host logic (plan/bank design, length rules, argument validation), and that the C-ABI library
+  loads and exports every symbol include/hipsoxr.h declares.  No compute calls.
+* `-m gpu`: the parity tests proper — HIP path (through the C ABI) vs the oracle.
+
+Nothing here reads /root/reference at run time.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "python-soxr_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the product library and the oracle are built artefacts; build them if a fresh checkout lacks them
+    lib = os.path.join(PKG, "soxr_amd", "libhipsoxr.so")
+    ora = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(ora)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def pytest_report_header(config):
+    # the reference prints versions and engine ids in the header (tests/conftest.py:5-16)
+    try:
+        import soxr_amd
+        from soxr_amd import _native
+        return [f"soxr_amd {soxr_amd.__version__}, native {soxr_amd.__libsoxr_version__}, "
+                f"HIP devices visible: {_native.device_count()}"]
+    except Exception as e:  # pragma: no cover
+        return [f"soxr_amd not importable: {e}"]
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def soxr():
+    import soxr_amd
+    return soxr_amd
+
+
+def has_gpu():
+    try:
+        from soxr_amd import _native
+        return _native.device_count() > 0
+    except Exception:
+        return False

@@ -1,0 +1,121 @@
+"""GPU parity: the HIP path (called through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bars (written here, as the task requires):
+  * BIT-EXACT vs the oracle's canonical-order port, for every I/O dtype (float32, float64, int16,
+    int32), both kernels, both layouts;
+  * float paths additionally within 1e-6 relative RMS of the oracle's float64 reference
+    (BASELINE.json north_star tolerance);
+  * the two kernels agree bit for bit with each other.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RATES = [(48000, 44100), (44100, 16000), (44100, 32000), (32000, 44100), (48000, 22050), (8000, 48000),
+         (44100, 22050), (22050, 32000), (100, 200)]
+DTYPES = [np.float32, np.float64, np.int16, np.int32]
+
+
+def _signal(rng, n, ch, dtype):
+    if np.issubdtype(dtype, np.integer):
+        x = (rng.standard_normal((n, ch)) * 5000).astype(dtype)  # scaling of tests/test_resample.py:125
+    else:
+        x = (rng.standard_normal((n, ch)) * 0.25).astype(dtype)
+    return x
+
+
+def _rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-300)
+
+
+@pytest.mark.parametrize("in_rate,out_rate", RATES)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_resample_bit_exact_vs_port(soxr, oracle, in_rate, out_rate, dtype):
+    rng = np.random.default_rng(1234)
+    x = _signal(rng, 6000, 2, dtype)
+    for q in ("VHQ", "HQ"):
+        y = soxr.resample(x, in_rate, out_rate, quality=q)
+        want = oracle.resample(x, in_rate, out_rate, q, mode="port")
+        assert y.dtype == x.dtype and y.shape == want.shape
+        assert np.array_equal(y, want), f"{q}: max diff {np.abs(y.astype(np.float64) - want).max()}"
+        if np.issubdtype(dtype, np.floating):
+            ref = oracle.resample(x, in_rate, out_rate, q, mode="ref")
+            assert _rel_rms(y, ref) <= 1e-6
+
+
+@pytest.mark.parametrize("quality", ["VHQ", "HQ", "MQ", "LQ", "QQ"])
+def test_all_qualities_mono(soxr, oracle, quality):
+    rng = np.random.default_rng(7)
+    x = _signal(rng, 20000, 1, np.float32)[:, 0]
+    y = soxr.resample(x, 48000, 44100, quality=quality)
+    assert np.array_equal(y, oracle.resample(x, 48000, 44100, quality, mode="port"))
+    assert _rel_rms(y, oracle.resample(x, 48000, 44100, quality, mode="ref")) <= 1e-6
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(48000, 44100), (44100, 16000), (44100, 22050), (8000, 48000),
+                                              (32000, 44100)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_tile_kernel_equals_gather_kernel(oracle, in_rate, out_rate, dtype):
+    """Both kernels implement the same canonical order -> identical bits, and both equal the oracle."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(99)
+    x = _signal(rng, 50000, 3, dtype)
+    plan = dev.Plan(in_rate, out_rate, "VHQ")
+    xt = torch.from_numpy(x).cuda()
+    yg = dev.resample_tensor(plan, xt, kernel=1).cpu().numpy()
+    yt = dev.resample_tensor(plan, xt, kernel=2).cpu().numpy()
+    want = oracle.resample(x, in_rate, out_rate, "VHQ", mode="port", dither=False)
+    assert np.array_equal(yg, want)
+    assert np.array_equal(yt, want)
+
+
+def test_split_layout_and_strided_channels(soxr, oracle):
+    rng = np.random.default_rng(5)
+    x = _signal(rng, 15013, 7, np.float32)
+    want = oracle.resample(x, 44100, 32000, "HQ", mode="port")
+    assert np.array_equal(soxr.resample(x, 44100, 32000), want)                       # C order
+    assert np.array_equal(soxr.resample(np.asfortranarray(x), 44100, 32000), want)    # split
+    assert np.array_equal(soxr.resample(x[:, :3], 44100, 32000), want[:, :3])         # strided slice
+    assert np.array_equal(soxr.resample(np.asfortranarray(x)[:, :3], 44100, 32000), want[:, :3])
+    assert np.array_equal(soxr.resample(x[:, 0], 44100, 32000), want[:, 0])           # 1-D strided
+
+
+@pytest.mark.parametrize("length", [0, 1, 2, 99, 100, 101, 1000])
+def test_short_inputs(soxr, oracle, length):
+    rng = np.random.default_rng(length)
+    x = _signal(rng, length, 2, np.float32)
+    y = soxr.resample(x, 44100, 32000)
+    want = oracle.resample(x, 44100, 32000, "HQ", mode="port")
+    assert y.shape == want.shape
+    assert np.array_equal(y, want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("chunk", [17, 509, 4410])
+def test_stream_equals_oneshot_equals_oracle(soxr, oracle, dtype, chunk):
+    rng = np.random.default_rng(chunk)
+    x = _signal(rng, 30011, 2, dtype)
+    rs = soxr.ResampleStream(44100, 16000, 2, dtype=dtype, quality="VHQ")
+    parts = []
+    for i in range(0, len(x), chunk):
+        parts.append(rs.resample_chunk(x[i:i + chunk], last=(i + chunk >= len(x))))
+    y = np.concatenate(parts)
+    want = oracle.resample(x, 44100, 16000, "VHQ", mode="port")
+    assert np.array_equal(y, want)
+    assert np.array_equal(soxr.resample(x, 44100, 16000, quality="VHQ"), want)
+
+
+def test_int_clipping_and_counter(soxr, oracle):
+    x = np.full((4000, 1), 32767, np.int16)
+    x[::2] = -32768  # full-scale Nyquist-rate square wave -> overshoot around the edges
+    x[1000:3000] = 32767
+    rs = soxr.ResampleStream(44100, 48000, 1, dtype="int16", quality="HQ")
+    y = rs.resample_chunk(x, last=True)
+    want, clips = oracle.resample(x, 44100, 48000, "HQ", mode="port", return_clips=True)
+    assert np.array_equal(y, want)
+    assert rs.num_clips() == clips
+    assert clips > 0
