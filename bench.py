@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path (BASELINE.json: "Msamples/sec VHQ 48k->44.1k
+float32; achieved HBM GB/s vs roofline @1/2/4/8 GPU").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (one hipsoxr_run_device launch) over one batch of synthetic
+input that is already resident in HBM.  Workload (config.workload):
+  * default: BASELINE.json configs[1] — VHQ 48000->44100 float32, 60 s mono, per GPU;
+  * the same JSON line also carries `batch_shard`: the per-GPU shard of configs[3]
+    (1024 independent 10 s clips over 8 GPUs = 128 clips per GPU), timed the same way.
+Multi-GPU: the path shards by independent clips — every rank resamples its own clips, no data-path
+collective; the only collective is the RCCL broadcast of the shared filter bank from rank 0 at plan
+time (outside the timed region).  Per-GPU work is fixed as N grows -> "scaling": "weak".
+
+Msamples/s = input samples consumed per second.  `roofline` is computed from the
+ALGORITHMIC bytes of one launch (4 B in + 4 B out per sample: 8.354 B per output sample at
+48k->44.1k) divided by the average launch duration measured with HIP events on the launch stream.
+`cpu_baseline` times the oracle (single-thread C restatement, kind "port" — libsoxr itself is not
+available in this image) on rank 0 over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "python-soxr_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+IN_RATE, OUT_RATE, QUALITY = 48000, 44100, "VHQ"
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
+
+
+def shard(n_units, world, rank):
+    """Contiguous block partition of n_units independent clips over `world` ranks."""
+    base, rem = divmod(n_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_bank(plan, rank, world, device):
+    """RCCL broadcast (over xGMI) of the float64 bank from rank 0; every other rank installs it."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return
+    bank = torch.from_numpy(plan.bank()).to(device) if rank == 0 else \
+        torch.empty((plan.L, plan.taps), dtype=torch.float64, device=device)
+    dist.broadcast(bank, src=0)
+    if rank != 0:
+        plan.set_bank(bank.cpu().numpy())
+
+
+def time_workload(plan, x, steps, warmup, world, device, kernel=0):
+    """W warm-up launches, then exactly K timed launches bracketed by barrier + synchronize.
+    Returns (wall seconds for K steps [max over ranks], mean launch duration from HIP events [s])."""
+    import torch
+    import torch.distributed as dist
+    from soxr_amd import device as dev
+    y = dev.resample_tensor(plan, x, kernel=kernel)
+    for _ in range(warmup):
+        dev.resample_tensor(plan, x, out=y, kernel=kernel)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # torch's current stream == the stream the kernels are launched on
+    for _ in range(steps):
+        dev.resample_tensor(plan, x, out=y, kernel=kernel)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    kern = ev0.elapsed_time(ev1) * 1e-3 / steps
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall, kern, y
+
+
+def cpu_baseline(seconds_in=60, budget_s=12.0):
+    """Oracle (float64 CPU restatement, one thread) on the same 60 s mono workload, repeated for
+    ~budget_s seconds."""
+    import numpy as np
+    from oracle import oracle
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(IN_RATE * seconds_in) * 0.25).astype(np.float32)
+    pl = oracle.plan(IN_RATE, OUT_RATE, QUALITY)
+    oracle.resample_channel(pl, x[:48000].astype(np.float64), "ref")  # warm up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        oracle.resample_channel(pl, x.astype(np.float64), "ref")
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": len(x) / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{seconds_in} s mono float32 48k->44.1k VHQ x{n} passes, float64 accumulate, "
+                      f"oracle/soxr_oracle.c (libsoxr itself is absent from this image)",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seconds", type=int, default=60, help="length of the mono clip (configs[1])")
+    ap.add_argument("--batch-clips", type=int, default=1024, help="clips in the sharded batch (configs[3])")
+    ap.add_argument("--batch-gpus", type=int, default=8, help="GPU count the batch is defined on")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-batch", action="store_true")
+    ap.add_argument("--kernel", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from soxr_amd import device as dev
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    plan = dev.Plan(IN_RATE, OUT_RATE, QUALITY)
+    broadcast_bank(plan, rank, world, device)
+
+    # ---- configs[1]: 60 s mono float32, one clip per GPU ------------------------------------
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + rank)
+    n_in = IN_RATE * args.seconds
+    x = torch.randn(n_in, device=device, dtype=torch.float32, generator=g) * 0.25
+    wall, kern, y = time_workload(plan, x, args.steps, args.warmup, world, device, args.kernel)
+    n_out = y.shape[0]
+    algo_bytes = 4.0 * (n_in + n_out)
+    flops = 2.0 * plan.taps * n_out
+    value = world * n_in * args.steps / wall / 1e6
+
+    result = {
+        "metric": "Msamples/sec VHQ 48k->44.1k float32 (input samples/s)",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: VHQ 48000->44100 float32, {args.seconds} s mono, "
+                               f"one clip per GPU, device-resident",
+                   "quality": QUALITY, "in_rate": IN_RATE, "out_rate": OUT_RATE,
+                   "taps_per_phase": plan.taps, "phases": plan.L, "frames_in": n_in, "frames_out": n_out,
+                   "parallelism": f"independent clips per rank x{world}; RCCL bank broadcast at plan time"},
+        "roofline": {"bound": "hbm", "achieved": algo_bytes / kern / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": algo_bytes / kern / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_tile<float,float,16>", "launch_us": kern * 1e6,
+                     "algorithmic_bytes_per_launch": algo_bytes,
+                     "valu_tflops": flops / kern / 1e12,
+                     "valu_frac": flops / kern / 1e12 / VALU_PEAK_TFLOPS},
+    }
+
+    # ---- configs[3] shard: 1024 x 10 s clips over 8 GPUs -> 128 clips per GPU ----------------
+    if not args.no_batch:
+        lo, hi = shard(args.batch_clips, args.batch_gpus, rank % args.batch_gpus)
+        clips = hi - lo
+        xb = torch.randn((clips, IN_RATE * 10, 1), device=device, dtype=torch.float32, generator=g) * 0.25
+        bsteps = max(5, args.steps // 10)
+        bwall, bkern, yb = time_workload(plan, xb, bsteps, max(2, args.warmup // 10), world, device,
+                                         args.kernel)
+        b_in, b_out = clips * IN_RATE * 10, clips * yb.shape[1]
+        bbytes = 4.0 * (b_in + b_out)
+        bflops = 2.0 * plan.taps * b_out
+        result["batch_shard"] = {
+            "workload": f"BASELINE configs[3] shard: {clips} independent 10 s clips per GPU "
+                        f"({args.batch_clips} clips / {args.batch_gpus} GPUs), VHQ 48k->44.1k float32",
+            "value": world * b_in * bsteps / bwall / 1e6, "unit": "Msamples/s", "steps": bsteps,
+            "ms_per_step": bwall / bsteps * 1e3,
+            "roofline": {"bound": "hbm", "achieved": bbytes / bkern / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bbytes / bkern / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "launch_us": bkern * 1e6, "valu_tflops": bflops / bkern / 1e12,
+                         "valu_frac": bflops / bkern / 1e12 / VALU_PEAK_TFLOPS}}
+        del xb, yb
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(args.seconds)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

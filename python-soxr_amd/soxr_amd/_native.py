@@ -16,6 +16,30 @@ if not os.path.exists(LIB_PATH):
         "(python-soxr_amd/build.sh, or `python -c 'import __graft_entry__ as g; g.build()'`). "
         "soxr_amd has no CPU fallback.")
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 (SONAME
+    libamdhip64.so.7, found through RPATH $ORIGIN as `libamdhip64.so`); libhipsoxr.so needs
+    `libamdhip64.so.7`.  If the system copy were loaded for us and torch's copy for torch, the
+    process would hold two runtimes and only the first to initialise would see the GPU.  Loading
+    torch's copy first (when torch is installed) makes both resolve to the same object."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch's runtime is already loaded; the SONAME match picks it up
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand)
+            except OSError:
+                pass
+
+
+_preload_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 # datatypes (libsoxr numbering)

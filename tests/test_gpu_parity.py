@@ -67,9 +67,13 @@ def test_tile_kernel_equals_gather_kernel(oracle, in_rate, out_rate, dtype):
     plan = dev.Plan(in_rate, out_rate, "VHQ")
     xt = torch.from_numpy(x).cuda()
     yg = dev.resample_tensor(plan, xt, kernel=1).cpu().numpy()
-    yt = dev.resample_tensor(plan, xt, kernel=2).cpu().numpy()
     want = oracle.resample(x, in_rate, out_rate, "VHQ", mode="port", dither=False)
     assert np.array_equal(yg, want)
+    try:
+        yt = dev.resample_tensor(plan, xt, kernel=2).cpu().numpy()
+    except RuntimeError as e:  # the input slab of 64 periods does not fit LDS (e.g. f64, M = 441)
+        assert "tile kernel unavailable" in str(e)
+        pytest.skip("tile kernel unavailable for this plan/precision; gather kernel checked")
     assert np.array_equal(yt, want)
 
 
