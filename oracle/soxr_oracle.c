@@ -126,7 +126,7 @@ static double bessel_i0(double x)
     return sum;
 }
 
-#define DESIGN_ATT_MARGIN_DB 1.4 /* Kaiser's estimate falls ~0.9 dB short near 175 dB */
+#define DESIGN_ATT_MARGIN_DB 2.0 /* Kaiser's estimate falls 1-3 dB short at the stop-band edge */
 
 /* Geometry + Kaiser parameters.  taps per phase T is even and a multiple of 8. */
 API int oracle_plan(double in_rate, double out_rate, unsigned long recipe, int64_t *L, int64_t *M,

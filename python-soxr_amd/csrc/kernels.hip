@@ -194,8 +194,69 @@ struct TileArgs {
     OutCtx oc;
 };
 
+// Stage the input slab of one workgroup: samples [bw*Mc + i_min, +x_count) of column (clip, ch)
+// into LDS as Real, row-padded (address n + pad*(n/Mc)), zero outside the signal.
+template <typename IO, typename Real, bool ALIGNED>
+__device__ __forceinline__ void stage_slab(const TileArgs &a, Real *xs, uint32_t clip, uint32_t ch,
+                                           int64_t bw)
+{
+    const int32_t Mc = (int32_t)a.Mc, pad = a.pad;
+    {
+        const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+        const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
+        bool vec = false;
+        if constexpr (ALIGNED && sizeof(IO) == 4 && sizeof(Real) == 4) {
+            // 16-byte global loads when the slab start is 16-byte aligned in memory
+            vec = a.ifs == 1 && ((loc_base & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0);
+        }
+        if (vec) {
+            if constexpr (ALIGNED && sizeof(IO) == 4 && sizeof(Real) == 4) {
+                const int32_t n4 = a.x_count >> 2; // x_count is a multiple of 4 in the aligned geometry
+                for (int32_t q = threadIdx.x; q < n4; q += blockDim.x) {
+                    const int32_t n = q << 2;
+                    const int64_t l = loc_base + n;
+                    Real v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                    if (l >= 0 && l + 3 < a.in_frames) {
+                        typedef IO __attribute__((ext_vector_type(4))) IO4;
+                        const IO4 t = *reinterpret_cast<const IO4 *>(xin + l);
+                        v0 = (Real)t.x; v1 = (Real)t.y; v2 = (Real)t.z; v3 = (Real)t.w;
+                    } else {
+                        if (l >= 0 && l < a.in_frames) v0 = (Real)xin[l];
+                        if (l + 1 >= 0 && l + 1 < a.in_frames) v1 = (Real)xin[l + 1];
+                        if (l + 2 >= 0 && l + 2 < a.in_frames) v2 = (Real)xin[l + 2];
+                        if (l + 3 >= 0 && l + 3 < a.in_frames) v3 = (Real)xin[l + 3];
+                    }
+                    float4 o; o.x = v0; o.y = v1; o.z = v2; o.w = v3;
+                    *reinterpret_cast<float4 *>(xs + n + pad * (n / Mc)) = o;
+                }
+            }
+        } else {
+            for (int32_t n = threadIdx.x; n < a.x_count; n += blockDim.x) {
+                int64_t l = loc_base + n;
+                Real v = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+                xs[n + pad * (n / Mc)] = v;
+            }
+        }
+    }
+}
+
+// 4 consecutive staged samples of this lane's row.  The aligned form is one ds_read_b128
+// (conflict-free: the row stride is 4*odd words).
+template <typename Real> struct Quad { Real v[4]; };
+__device__ __forceinline__ Quad<float> lds_quad_aligned(const float *p)
+{
+    const float4 t = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(p, 16));
+    return Quad<float>{{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ Quad<double> lds_quad_aligned(const double *p)
+{
+    const double2 a = *reinterpret_cast<const double2 *>(__builtin_assume_aligned(p, 16));
+    const double2 b = *reinterpret_cast<const double2 *>(__builtin_assume_aligned(p + 2, 16));
+    return Quad<double>{{a.x, a.y, b.x, b.y}};
+}
+
 template <typename IO, typename Real, int RT, bool ALIGNED>
-__global__ void __launch_bounds__(512) k_tile(TileArgs a)
+__global__ void __launch_bounds__(1024) k_tile(TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Real *xs = reinterpret_cast<Real *>(smem_raw);
@@ -205,16 +266,7 @@ __global__ void __launch_bounds__(512) k_tile(TileArgs a)
     const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64; // first period of this workgroup
     const int32_t Mc = (int32_t)a.Mc, pad = a.pad;
 
-    // ---- stage the input slab: samples [bw*Mc + i_min, +x_count), zero outside the signal ----
-    {
-        const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-        const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
-        for (int32_t n = threadIdx.x; n < a.x_count; n += blockDim.x) {
-            int64_t l = loc_base + n;
-            Real v = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-            xs[n + pad * (n / Mc)] = v;
-        }
-    }
+    stage_slab<IO, Real, ALIGNED>(a, xs, clip, ch, bw);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -223,6 +275,11 @@ __global__ void __launch_bounds__(512) k_tile(TileArgs a)
     const Real *xl = xs + lane * (Mc + pad);
     const int64_t b = bw + lane; // this lane's period
     typedef const __attribute__((address_space(4))) Real *CPtr;
+
+    // whole workgroup inside the requested output range? (uniform) -> stores need no per-sample test
+    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
+    IO *const yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs +
+                   (b * a.Lc - a.out_k0) * a.ofs; // this lane's period start (may be out of range)
 
     for (int rt_ = wave; rt_ < a.n_rt; rt_ += n_waves) {
         // keep the tile index (and everything derived from it) provably wave-uniform: the
@@ -240,31 +297,26 @@ __global__ void __launch_bounds__(512) k_tile(TileArgs a)
         {
             int32_t e = eL0, padoff = pad * (e / Mc), next = (e / Mc + 1) * Mc;
             for (int32_t q = 0; q < a.I_h; q += 4) {
-                Real x0, x1, x2, x3;
+                Quad<Real> x;
                 if (ALIGNED) {
-                    const Real *px = xl + e + padoff;
-                    x0 = px[0]; x1 = px[1]; x2 = px[2]; x3 = px[3];
+                    x = lds_quad_aligned(xl + e + padoff);
                 } else {
                     // a chunk may straddle row-padding points: resolve each sample separately
                     const int32_t e1 = e + 1, e2 = e + 2, e3 = e + 3;
                     if (pad) {
-                        x0 = xl[e + pad * (e / Mc)];
-                        x1 = xl[e1 + pad * (e1 / Mc)];
-                        x2 = xl[e2 + pad * (e2 / Mc)];
-                        x3 = xl[e3 + pad * (e3 / Mc)];
+                        x.v[0] = xl[e + pad * (e / Mc)];
+                        x.v[1] = xl[e1 + pad * (e1 / Mc)];
+                        x.v[2] = xl[e2 + pad * (e2 / Mc)];
+                        x.v[3] = xl[e3 + pad * (e3 / Mc)];
                     } else {
-                        x0 = xl[e]; x1 = xl[e1]; x2 = xl[e2]; x3 = xl[e3];
+                        x.v[0] = xl[e]; x.v[1] = xl[e1]; x.v[2] = xl[e2]; x.v[3] = xl[e3];
                     }
                 }
                 CPtr t = tL + (size_t)q * RT;
 #pragma unroll
-                for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[0 * RT + rr], x0, accL[rr]);
+                for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[1 * RT + rr], x1, accL[rr]);
-#pragma unroll
-                for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[2 * RT + rr], x2, accL[rr]);
-#pragma unroll
-                for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[3 * RT + rr], x3, accL[rr]);
+                    for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[ii * RT + rr], x.v[ii], accL[rr]);
                 e += 4;
                 if (e >= next) { padoff += pad; next += Mc; }
             }
@@ -273,42 +325,43 @@ __global__ void __launch_bounds__(512) k_tile(TileArgs a)
         {
             int32_t e = eR0, padoff = pad * (e / Mc), lo = (e / Mc) * Mc;
             for (int32_t q = 0; q < a.I_h; q += 4) {
-                Real x0, x1, x2, x3;
+                Quad<Real> x;
                 if (ALIGNED) {
-                    const Real *px = xl + e + padoff;
-                    x0 = px[0]; x1 = px[1]; x2 = px[2]; x3 = px[3];
+                    x = lds_quad_aligned(xl + e + padoff);
                 } else {
                     const int32_t e1 = e + 1, e2 = e + 2, e3 = e + 3;
                     if (pad) {
-                        x0 = xl[e + pad * (e / Mc)];
-                        x1 = xl[e1 + pad * (e1 / Mc)];
-                        x2 = xl[e2 + pad * (e2 / Mc)];
-                        x3 = xl[e3 + pad * (e3 / Mc)];
+                        x.v[0] = xl[e + pad * (e / Mc)];
+                        x.v[1] = xl[e1 + pad * (e1 / Mc)];
+                        x.v[2] = xl[e2 + pad * (e2 / Mc)];
+                        x.v[3] = xl[e3 + pad * (e3 / Mc)];
                     } else {
-                        x0 = xl[e]; x1 = xl[e1]; x2 = xl[e2]; x3 = xl[e3];
+                        x.v[0] = xl[e]; x.v[1] = xl[e1]; x.v[2] = xl[e2]; x.v[3] = xl[e3];
                     }
                 }
                 CPtr t = tR + (size_t)q * RT;
 #pragma unroll
-                for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[0 * RT + rr], x3, accR[rr]);
+                for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[1 * RT + rr], x2, accR[rr]);
-#pragma unroll
-                for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[2 * RT + rr], x1, accR[rr]);
-#pragma unroll
-                for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[3 * RT + rr], x0, accR[rr]);
+                    for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[ii * RT + rr], x.v[3 - ii], accR[rr]);
                 e -= 4;
                 if (e < lo) { padoff -= pad; lo -= Mc; }
             }
         }
         // store: output k = b*Lc + rt*RT + rr
-        const int64_t kbase = b * a.Lc + (int64_t)rt * RT;
-        IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+        const int32_t r0 = rt * RT;
+        IO *const yt = yo + (int64_t)r0 * a.ofs;
+        if (interior && r0 + RT <= a.Lc) {
 #pragma unroll
-        for (int rr = 0; rr < RT; ++rr) {
-            const int64_t k = kbase + rr, idx = k - a.out_k0;
-            if (rt * RT + rr < a.Lc && idx >= 0 && idx < a.out_frames)
-                store_out<Real>(yo + idx * a.ofs, accL[rr] + accR[rr], a.oc, ch, k);
+            for (int rr = 0; rr < RT; ++rr)
+                store_out<Real>(yt + rr * a.ofs, accL[rr] + accR[rr], a.oc, ch, b * a.Lc + r0 + rr);
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < RT; ++rr) {
+                const int64_t k = b * a.Lc + r0 + rr, idx = k - a.out_k0;
+                if (r0 + rr < a.Lc && idx >= 0 && idx < a.out_frames)
+                    store_out<Real>(yt + rr * a.ofs, accL[rr] + accR[rr], a.oc, ch, k);
+            }
         }
     }
 }
@@ -555,11 +608,11 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
     if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";
     if (n_blocks > 2147483647LL) return "job too long for one launch";
-    // waves per workgroup: spread the n_rt tiles evenly, 4..8 waves
-    int nw = g.n_rt < 4 ? g.n_rt : 4;
-    {
-        int best = nw, best_waste = 1 << 30;
-        for (int w = std::min(g.n_rt, 8); w >= std::min(g.n_rt, 4); --w) {
+    // waves per workgroup: one tile per wave when n_rt <= 16, else the even split with most waves
+    int nw = g.n_rt;
+    if (g.n_rt > 16) {
+        int best = 16, best_waste = 1 << 30;
+        for (int w = 16; w >= 8; --w) {
             int rounds = (g.n_rt + w - 1) / w, waste = rounds * w - g.n_rt;
             if (waste < best_waste) { best_waste = waste; best = w; }
         }
@@ -567,7 +620,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     }
     a.n_waves = nw;
     dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
-    auto kern = g.aligned ? k_tile<IO, Real, 16, true> : k_tile<IO, Real, 16, false>;
+    void (*kern)(TileArgs) = g.aligned ? k_tile<IO, Real, 16, true> : k_tile<IO, Real, 16, false>;
     if (g.lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)g.lds_bytes));

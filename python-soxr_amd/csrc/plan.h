@@ -24,7 +24,6 @@ struct DeviceBank {
     // tile kernel: per output-tile skewed, zero-padded half tables (see kernels.hip)
     void *tile_tab = nullptr;    // [n_rt][2][I_h][RT]
     int32_t RT = 0, n_rt = 0, I_h = 0;
-    std::vector<int32_t> tile_i0L_host, tile_i0R_host;
     int32_t *tile_i0 = nullptr;  // [n_rt][2] device: first input offset (rel. to period start) of each half
     bool ready = false;
 };

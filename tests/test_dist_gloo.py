@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes exercise exactly what bench.py does across
+ranks — contiguous clip sharding with no data-path collective, plus the one collective the path
+has (broadcast of the shared filter bank from rank 0).  The per-clip arithmetic is stood in for by
+the oracle (there is no GPU here); what is under test is the partition / broadcast logic."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_clips, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "python-soxr_amd"))
+    import torch
+    import torch.distributed as dist
+    import bench
+    from oracle import oracle
+    from soxr_amd import device as dev
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = dev.Plan(48000, 44100, "HQ")
+    if rank != 0:                       # prove the broadcast is what installs the bank
+        plan.set_bank(np.zeros((plan.L, plan.taps)))
+    bench.broadcast_bank(plan, rank, world, torch.device("cpu"))
+    bank = plan.bank()
+    lo, hi = bench.shard(n_clips, world, rank)
+    opl = oracle.plan(48000, 44100, "HQ")
+    outs = {}
+    for clip in range(lo, hi):          # each rank resamples only its own clips
+        x = (np.random.default_rng(100 + clip).standard_normal(2000) * 0.25).astype(np.float32)
+        outs[clip] = oracle.resample_channel(opl, x, "port_f32", bank=bank)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), bank=bank, lo=lo, hi=hi,
+             **{f"clip{c}": v for c, v in outs.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [7, 8])
+def test_two_rank_sharding_and_bank_broadcast(tmp_path, n_clips, oracle):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, n_clips, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(world)]
+    # both ranks hold rank 0's bank, bit for bit, and it is the designed bank
+    assert np.array_equal(r[0]["bank"], r[1]["bank"])
+    assert np.array_equal(r[0]["bank"], oracle.plan(48000, 44100, "HQ").bank)
+    # shards are disjoint, contiguous and cover every clip
+    assert int(r[0]["lo"]) == 0 and int(r[0]["hi"]) == int(r[1]["lo"]) and int(r[1]["hi"]) == n_clips
+    # the union of per-rank results equals the unsharded computation
+    opl = oracle.plan(48000, 44100, "HQ")
+    for clip in range(n_clips):
+        x = (np.random.default_rng(100 + clip).standard_normal(2000) * 0.25).astype(np.float32)
+        want = oracle.resample_channel(opl, x, "port_f32")
+        owner = 0 if clip < int(r[0]["hi"]) else 1
+        assert np.array_equal(r[owner][f"clip{clip}"], want)
+
+
+def test_shard_partition_properties():
+    sys.path.insert(0, ROOT)
+    import bench
+    for n in (0, 1, 7, 128, 1024, 1025):
+        for world in (1, 2, 3, 4, 8):
+            parts = [bench.shard(n, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert bench.shard(1024, 8, 3) == (384, 512)

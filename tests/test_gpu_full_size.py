@@ -1,0 +1,94 @@
+"""BASELINE.json's full-size configurations on the device-resident path, checked through
+size-independent properties (the oracle would take minutes at these sizes) plus spot windows that
+ARE compared with the oracle bit for bit:
+  * shift invariance: delaying the input by M samples delays the output by exactly L samples, bit
+    for bit (every output is a pure function of its own taps);
+  * channel / clip independence: a multichannel or batched launch equals per-column launches;
+  * linearity within float rounding;
+  * random output windows equal the oracle's canonical-order port exactly.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _windows_match_oracle(oracle, plan_args, x_np, y_np, rng, n_windows=6, width=300):
+    pl = oracle.plan(*plan_args)
+    for k0 in [0, len(y_np) - width] + list(rng.integers(0, len(y_np) - width, n_windows)):
+        k0 = int(k0)
+        want = oracle.resample_channel(pl, x_np, "port_f32", k0=k0, n_out=width)
+        assert np.array_equal(y_np[k0:k0 + width], want), f"window at {k0}"
+
+
+def test_config1_vhq_60s_mono(oracle):
+    import torch
+    from soxr_amd import device as dev
+    plan = dev.Plan(48000, 44100, "VHQ")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(2880000, device="cuda", generator=g) * 0.25
+    y = dev.resample_tensor(plan, x)
+    assert y.shape[0] == 2646000
+    # shift invariance, exact
+    xs = torch.cat([torch.zeros(plan.M * 5, device="cuda"), x])
+    ys = dev.resample_tensor(plan, xs)
+    assert torch.equal(ys[plan.L * 5 + 2000:plan.L * 5 + 2000 + 2600000], y[2000:2602000])
+    # both kernels, exact
+    assert torch.equal(y, dev.resample_tensor(plan, x, kernel=1))
+    # linearity
+    x2 = torch.randn(2880000, device="cuda", generator=g) * 0.25
+    lin = dev.resample_tensor(plan, 0.5 * x - 2.0 * x2)
+    comb = 0.5 * y - 2.0 * dev.resample_tensor(plan, x2)
+    assert (lin - comb).abs().max().item() < 2e-6
+    # oracle windows, exact
+    _windows_match_oracle(oracle, (48000, 44100, "VHQ"), x.cpu().numpy(), y.cpu().numpy(),
+                          np.random.default_rng(0))
+
+
+def test_config2_vhq_8ch_44k1_16k(oracle):
+    import torch
+    from soxr_amd import device as dev
+    plan = dev.Plan(44100, 16000, "VHQ")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((2646000, 8), device="cuda", generator=g) * 0.25
+    y = dev.resample_tensor(plan, x)
+    assert tuple(y.shape) == (960000, 8)
+    for c in (0, 5, 7):   # channel independence: interleaved launch == planar mono launch
+        assert torch.equal(y[:, c], dev.resample_tensor(plan, x[:, c].contiguous()))
+    assert torch.equal(y, dev.resample_tensor(plan, x, kernel=1))
+    _windows_match_oracle(oracle, (44100, 16000, "VHQ"), x[:, 3].cpu().numpy(), y[:, 3].cpu().numpy(),
+                          np.random.default_rng(1), n_windows=3, width=100)
+
+
+def test_config3_batch_of_clips(oracle):
+    """One GPU's shard of the 1024-clip batch (128 x 10 s): batched launch == per-clip launches."""
+    import torch
+    from soxr_amd import device as dev
+    plan = dev.Plan(48000, 44100, "VHQ")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn((128, 480000, 1), device="cuda", generator=g) * 0.25
+    y = dev.resample_tensor(plan, x)
+    assert tuple(y.shape) == (128, 441000, 1)
+    for clip in (0, 63, 127):
+        assert torch.equal(y[clip, :, 0], dev.resample_tensor(plan, x[clip, :, 0].contiguous()))
+    _windows_match_oracle(oracle, (48000, 44100, "VHQ"), x[77, :, 0].cpu().numpy(), y[77, :, 0].cpu().numpy(),
+                          np.random.default_rng(2), n_windows=3)
+
+
+@pytest.mark.parametrize("chunk", [441, 4410, 96000])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_config4_int16_stream(soxr, oracle, chunk, channels):
+    rng = np.random.default_rng(5)
+    n = 2646000 if chunk >= 4410 else 441000      # 60 s (10 s for the smallest chunk: 1000 launches)
+    x = (rng.standard_normal((n, channels)) * 5000).astype(np.int16)
+    rs = soxr.ResampleStream(44100, 16000, channels, dtype="int16", quality="VHQ")
+    parts = [rs.resample_chunk(x[i:i + chunk], last=(i + chunk >= n)) for i in range(0, n, chunk)]
+    y = np.concatenate(parts)
+    assert y.shape[0] == n * 160 // 441
+    one = soxr.resample(x, 44100, 16000, quality="VHQ")
+    assert np.array_equal(y, one)                  # state carried across launches changes nothing
+    pl = oracle.plan(44100, 16000, "VHQ")
+    for k0 in (0, 123456 % (len(y) - 200), len(y) - 200):
+        v = oracle.resample_channel(pl, x[:, 0].astype(np.float32), "port_f32", k0=k0, n_out=200)
+        q, _ = oracle.quantize(v, np.int16, channel=0, k0=k0, dither=True, seed=0)
+        assert np.array_equal(y[k0:k0 + 200, 0], q)

@@ -1,0 +1,155 @@
+"""The behavioural contract python-soxr's own test-suite pins, re-expressed against
+soxr_amd on the GPU: dtype preservation, exact lengths, bit-exact equality of the one-shot, divided,
+split-channel and streamed drivers, known-answer tones for all recipes, integer paths within the
+reference's 2 LSB, thread safety.  Our own bars are tighter where noted (integer paths are
+deterministic here, so they are compared exactly)."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def tone2(freq, rate, seconds):
+    n = int(rate * seconds)
+    s = np.sin(2 * np.pi * freq / rate * np.arange(n)) * np.hanning(n)
+    return np.stack([s, np.zeros_like(s)], axis=-1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16, np.int32])
+def test_dtype_is_preserved(soxr, dtype):
+    x = np.random.default_rng(0).standard_normal(100).astype(dtype)
+    y = soxr.resample(x, 100, 200)
+    assert y.dtype == x.dtype and y.shape == (200,)
+
+
+def test_list_input_becomes_float32(soxr):
+    y = soxr.resample([0.0, 1.0, 0.0, -1.0] * 25, 100, 200)
+    assert y.dtype == np.float32 and y.shape == (200,)
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(44100, 32000), (32000, 44100)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_drivers_agree_bit_for_bit(soxr, in_rate, out_rate, dtype):
+    x = np.random.default_rng(1).standard_normal((25999, 2)).astype(dtype)
+    one = soxr._resample_oneshot(x, in_rate, out_rate)
+    assert np.array_equal(one, soxr.resample(x, in_rate, out_rate))
+    assert np.array_equal(one, soxr.resample(np.asfortranarray(x), in_rate, out_rate))
+    assert np.array_equal(one, soxr._resample_divided(x, in_rate, out_rate))               # chunked driver
+    assert np.array_equal(one, soxr._resample_divided(np.asfortranarray(x), in_rate, out_rate))
+    assert np.array_equal(one, soxr._resample_divided(x, in_rate, out_rate, div_frames=1000))
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(44100, 32000), (32000, 44100)])
+@pytest.mark.parametrize("length", [0, 1, 2, 99, 100, 101, 31999, 32000, 32001, 34829, 44100, 48001, 66150, 166151])
+def test_lengths_and_sliced_inputs(soxr, in_rate, out_rate, length):
+    x = np.random.default_rng(2).standard_normal((166151, 2)).astype(np.float32)
+    xf = np.asfortranarray(x)
+    one = soxr._resample_oneshot(x[:length], in_rate, out_rate)
+    assert one.shape == (int(np.floor(length * out_rate / in_rate + 0.5)), 2)
+    assert np.array_equal(one, soxr.resample(x[:length], in_rate, out_rate))
+    assert np.array_equal(one, soxr.resample(xf[:length], in_rate, out_rate))
+    assert np.array_equal(one, soxr._resample_divided(x[:length], in_rate, out_rate))
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3, 5, 7, 24, 49])
+def test_channel_slices(soxr, channels):
+    x = np.random.default_rng(3).standard_normal((15013, 49)).astype(np.float32)
+    one = soxr._resample_oneshot(x[:, :channels], 44100, 32000)
+    assert one.shape[1] == channels
+    assert np.array_equal(one, soxr.resample(x[:, :channels], 44100, 32000))
+    assert np.array_equal(one, soxr.resample(np.asfortranarray(x)[:, :channels], 44100, 32000))
+
+
+def _stream(soxr, x, in_rate, out_rate, chunk, dtype, quality="HQ"):
+    rs = soxr.ResampleStream(in_rate, out_rate, x.shape[1], dtype=dtype, quality=quality)
+    parts = [np.empty((0, x.shape[1]), dtype)]
+    if len(x) == 0:
+        parts.append(rs.resample_chunk(x, last=True))
+    for i in range(0, len(x), chunk):
+        parts.append(rs.resample_chunk(x[i:i + chunk], last=(i + chunk >= len(x))))
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(44100, 32000), (32000, 44100)])
+@pytest.mark.parametrize("chunk", [17, 509, 44100])
+@pytest.mark.parametrize("length", [0, 100, 31999, 44100])
+@pytest.mark.parametrize("dtype", ["float32", np.float64])
+def test_stream_is_chunk_invariant(soxr, in_rate, out_rate, chunk, length, dtype):
+    x = np.random.default_rng(4).standard_normal((length, 1)).astype(dtype)
+    assert np.array_equal(soxr._resample_oneshot(x, in_rate, out_rate),
+                          _stream(soxr, x, in_rate, out_rate, chunk, np.dtype(dtype)))
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(48000, 22050), (8000, 48000)])
+@pytest.mark.parametrize("chunk", [50, 101])
+@pytest.mark.parametrize("length", [1, 101, 32000, 44101])
+@pytest.mark.parametrize("dtype", ["int32", np.int16])
+def test_stream_int(soxr, in_rate, out_rate, chunk, length, dtype):
+    x = (np.random.default_rng(5).standard_normal((length, 2)) * 5000).astype(dtype)
+    one = soxr._resample_oneshot(x, in_rate, out_rate)
+    st = _stream(soxr, x, in_rate, out_rate, chunk, np.dtype(dtype))
+    assert np.allclose(one, st, atol=2)       # the reference's bar
+    assert np.array_equal(one, st)            # ours: dither is position-keyed, so exactly equal
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(44100, 22050), (22050, 32000)])
+@pytest.mark.parametrize("quality", ["VHQ", "HQ", "SOXR_MQ", "lq", "soxr_qq"])
+def test_known_answer_tone(soxr, in_rate, out_rate, quality):
+    x, want = tone2(32.0, in_rate, 2.0), tone2(32.0, out_rate, 2.0)
+    q = soxr.VHQ if quality == "VHQ" else quality
+    for xx in (x, x.astype(np.float32)):
+        assert np.allclose(want, soxr.resample(xx, in_rate, out_rate, quality=q), atol=1e-4)
+        assert np.allclose(want, soxr.resample(np.asfortranarray(xx), in_rate, out_rate, quality=q), atol=1e-4)
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(48000, 24000), (32000, 44100)])
+@pytest.mark.parametrize("dtype", [np.int32, np.int16])
+def test_known_answer_tone_int(soxr, in_rate, out_rate, dtype):
+    x = (tone2(32.0, in_rate, 2.0) * 16384).astype(dtype)
+    want = (tone2(32.0, out_rate, 2.0) * 16384).astype(dtype)
+    got = soxr.resample(x, in_rate, out_rate)
+    assert np.allclose(want, got, atol=2)
+    assert np.array_equal(got, soxr.resample(np.asfortranarray(x), in_rate, out_rate))
+    assert np.array_equal(got, soxr._resample_oneshot(x, in_rate, out_rate))
+
+
+@pytest.mark.parametrize("n_tasks", [2, 5, 12, 32])
+def test_threads(soxr, n_tasks):
+    """Distinct handles are usable concurrently (the reference releases the GIL; ctypes does too)."""
+    x = np.random.default_rng(6).standard_normal((75999, 2)).astype(np.float32)
+    xi = (np.random.default_rng(7).standard_normal((70001, 2)) * 5000).astype(np.int16)
+    with ThreadPoolExecutor() as pool:
+        fl = list(pool.map(lambda a: soxr.resample(a, 44100, 32000), [x] * n_tasks))
+        it = list(pool.map(lambda a: soxr.resample(a, 32000, 48000), [xi] * n_tasks))
+    assert all(np.array_equal(fl[0], r) for r in fl[1:])
+    assert all(np.array_equal(it[0], r) for r in it[1:])     # deterministic dither: exactly equal
+
+
+def test_stream_protocol(soxr):
+    rs = soxr.ResampleStream(44100, 16000, 2, dtype="int16", quality="VHQ")
+    assert rs.engine().startswith("hip-gfx950")
+    assert rs.delay() == 0.0 and rs.num_clips() == 0
+    with pytest.raises(TypeError):
+        rs.resample_chunk(np.zeros((10, 2), np.float32))        # dtype mismatch
+    with pytest.raises(TypeError):
+        rs.resample_chunk([[0, 0]])                             # not an ndarray
+    with pytest.raises(ValueError):
+        rs.resample_chunk(np.zeros((10, 3), np.int16))          # channel mismatch
+    with pytest.raises(ValueError):
+        rs.resample_chunk(np.zeros((2, 2, 2), np.int16))
+    x = (np.random.default_rng(8).standard_normal((10000, 2)) * 3000).astype(np.int16)
+    y0 = rs.resample_chunk(x[:5000])
+    assert rs.delay() > 0
+    y1 = rs.resample_chunk(x[5000:], last=True)
+    assert rs.delay() == pytest.approx(0.0, abs=1.0)
+    with pytest.raises(RuntimeError):
+        rs.resample_chunk(x[:10])                               # input after last input
+    full = np.concatenate([y0, y1])
+    rs.clear()                                                  # same config, fresh signal
+    again = rs.resample_chunk(x, last=True)
+    assert np.array_equal(full, again)
+    assert np.array_equal(full, soxr.resample(x, 44100, 16000, quality="VHQ"))
+    with pytest.raises(RuntimeError):
+        soxr.ResampleStream(44100, 16000, 1, vr=True)           # variable rate: not implemented
