@@ -33,6 +33,8 @@ for p in (ROOT, os.path.join(ROOT, "python-soxr_amd")):
         sys.path.insert(0, p)
 
 IN_RATE, OUT_RATE, QUALITY = 48000, 44100, "VHQ"
+KERNEL_NAMES = {0: "auto (k_tile_mfma<float> for this workload)", 1: "k_gather<float,float>",
+                2: "k_tile_mfma<float>", 3: "k_tile<float,float,16,true>", 4: "k_tile_mfma<float>"}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
@@ -166,7 +168,7 @@ def main():
                    "parallelism": f"independent clips per rank x{world}; RCCL bank broadcast at plan time"},
         "roofline": {"bound": "hbm", "achieved": algo_bytes / kern / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo_bytes / kern / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_tile<float,float,16>", "launch_us": kern * 1e6,
+                     "kernel": KERNEL_NAMES.get(args.kernel, "auto"), "launch_us": kern * 1e6,
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "valu_tflops": flops / kern / 1e12,
                      "valu_frac": flops / kern / 1e12 / VALU_PEAK_TFLOPS},

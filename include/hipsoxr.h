@@ -78,7 +78,9 @@ typedef enum { HIPSOXR_F32 = 0, HIPSOXR_F64 = 1, HIPSOXR_I32 = 2, HIPSOXR_I16 = 
 typedef enum {
     HIPSOXR_KERNEL_AUTO = 0,
     HIPSOXR_KERNEL_GATHER = 1, /* one lane per output sample, operands gathered through L1/L2 */
-    HIPSOXR_KERNEL_TILE = 2    /* period-tiled: input slab in LDS, coefficients on the scalar path */
+    HIPSOXR_KERNEL_TILE = 2,   /* period-tiled, best variant for the engine (MFMA f32, else VALU) */
+    HIPSOXR_KERNEL_TILE_VALU = 3, /* period-tiled: input slab in LDS, coefficients on the scalar path */
+    HIPSOXR_KERNEL_TILE_MFMA = 4  /* period-tiled on the f32-input matrix pipe (f32 engine only) */
 } hipsoxr_kernel_t;
 
 typedef struct hipsoxr_plan hipsoxr_plan_t;     /* immutable: ratio + polyphase bank (host + device) */

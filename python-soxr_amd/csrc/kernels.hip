@@ -185,6 +185,8 @@ struct TileArgs {
     const int32_t *e0;   // [n_rt][2]  (eL0, eR0)
     int64_t Lc, Mc;      // replicated period
     int32_t n_rt, I_h, n_waves;
+    int32_t rowR, plane; // k_tile_mfma_p: plane row stride and plane stride (words)
+    int32_t dbg; // timing ablations only (HIPSOXR_DEBUG_FLAGS): 1 no staging loads, 2 no LDS reads, 4 no coefficient loads, 8 no stores
     int32_t pad, i_min, x_count; // LDS row padding; first staged input; samples staged per tile
     uint32_t n_clips, n_channels;
     int64_t ics, ifs, ichs, ocs, ofs, ochs;
@@ -195,46 +197,57 @@ struct TileArgs {
 };
 
 // Stage the input slab of one workgroup: samples [bw*Mc + i_min, +x_count) of column (clip, ch)
-// into LDS as Real, row-padded (address n + pad*(n/Mc)), zero outside the signal.
+// into LDS as Real, row-padded (address n + pad*(n/Mc)), zero outside the signal.  x_count and
+// i_min are multiples of 4 (host geometry).  Each thread first ISSUES up to UNR independent
+// 4-sample loads (16-byte global loads when the source is contiguous and aligned), then converts
+// and writes them, so that the HBM latency is paid once per batch rather than once per sample.
 template <typename IO, typename Real, bool ALIGNED>
 __device__ __forceinline__ void stage_slab(const TileArgs &a, Real *xs, uint32_t clip, uint32_t ch,
                                            int64_t bw)
 {
+    typedef IO IO4 __attribute__((ext_vector_type(4)));
+    constexpr int UNR = 4;
     const int32_t Mc = (int32_t)a.Mc, pad = a.pad;
-    {
-        const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-        const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
-        bool vec = false;
-        if constexpr (ALIGNED && sizeof(IO) == 4 && sizeof(Real) == 4) {
-            // 16-byte global loads when the slab start is 16-byte aligned in memory
-            vec = a.ifs == 1 && ((loc_base & 3) == 0) && ((reinterpret_cast<uintptr_t>(xin) & 15) == 0);
-        }
-        if (vec) {
-            if constexpr (ALIGNED && sizeof(IO) == 4 && sizeof(Real) == 4) {
-                const int32_t n4 = a.x_count >> 2; // x_count is a multiple of 4 in the aligned geometry
-                for (int32_t q = threadIdx.x; q < n4; q += blockDim.x) {
-                    const int32_t n = q << 2;
-                    const int64_t l = loc_base + n;
-                    Real v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                    if (l >= 0 && l + 3 < a.in_frames) {
-                        typedef IO __attribute__((ext_vector_type(4))) IO4;
-                        const IO4 t = *reinterpret_cast<const IO4 *>(xin + l);
-                        v0 = (Real)t.x; v1 = (Real)t.y; v2 = (Real)t.z; v3 = (Real)t.w;
-                    } else {
-                        if (l >= 0 && l < a.in_frames) v0 = (Real)xin[l];
-                        if (l + 1 >= 0 && l + 1 < a.in_frames) v1 = (Real)xin[l + 1];
-                        if (l + 2 >= 0 && l + 2 < a.in_frames) v2 = (Real)xin[l + 2];
-                        if (l + 3 >= 0 && l + 3 < a.in_frames) v3 = (Real)xin[l + 3];
-                    }
-                    float4 o; o.x = v0; o.y = v1; o.z = v2; o.w = v3;
-                    *reinterpret_cast<float4 *>(xs + n + pad * (n / Mc)) = o;
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
+    const bool vec = a.ifs == 1 && ((loc_base & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(xin) & (4 * sizeof(IO) - 1)) == 0);
+    const int32_t n4 = a.x_count >> 2;
+    const int32_t stride = (int32_t)blockDim.x;
+    for (int32_t q0 = threadIdx.x; q0 < n4; q0 += stride * UNR) {
+        IO4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int32_t q = q0 + u * stride;
+            v[u] = (IO4){0, 0, 0, 0};
+            if (q < n4) {
+                const int64_t l = loc_base + ((int64_t)q << 2);
+                if (vec && l >= 0 && l + 3 < a.in_frames) {
+                    v[u] = *reinterpret_cast<const IO4 *>(xin + l);
+                } else {
+                    if (l >= 0 && l < a.in_frames) v[u].x = xin[l * a.ifs];
+                    if (l + 1 >= 0 && l + 1 < a.in_frames) v[u].y = xin[(l + 1) * a.ifs];
+                    if (l + 2 >= 0 && l + 2 < a.in_frames) v[u].z = xin[(l + 2) * a.ifs];
+                    if (l + 3 >= 0 && l + 3 < a.in_frames) v[u].w = xin[(l + 3) * a.ifs];
                 }
             }
-        } else {
-            for (int32_t n = threadIdx.x; n < a.x_count; n += blockDim.x) {
-                int64_t l = loc_base + n;
-                Real v = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-                xs[n + pad * (n / Mc)] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int32_t q = q0 + u * stride;
+            if (q < n4) {
+                const int32_t n = q << 2, row = n / Mc, rem = n - row * Mc;
+                Real *dst = xs + n + pad * row;
+                if (ALIGNED) { // Mc % 4 == 0 and pad % 4 == 0: the quad never straddles a row
+                    typedef Real R4 __attribute__((ext_vector_type(4)));
+                    R4 o = {(Real)v[u].x, (Real)v[u].y, (Real)v[u].z, (Real)v[u].w};
+                    *reinterpret_cast<R4 *>(__builtin_assume_aligned(dst, 4 * sizeof(Real))) = o;
+                } else {
+                    dst[0] = (Real)v[u].x;
+                    dst[1 + (rem + 1 >= Mc ? pad : 0)] = (Real)v[u].y;
+                    dst[2 + (rem + 2 >= Mc ? pad : 0)] = (Real)v[u].z;
+                    dst[3 + (rem + 3 >= Mc ? pad : 0)] = (Real)v[u].w;
+                }
             }
         }
     }
@@ -367,6 +380,318 @@ __global__ void __launch_bounds__(1024) k_tile(TileArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_tile_mfma — f32 engine.  Same tiling as k_tile (64 periods x 16 output phases per wavefront),
+// executed on the f32-input matrix pipe: one v_mfma_f32_16x16x4_f32 adds, for 16 phases x 16
+// periods, the contributions of 4 consecutive input samples,
+//     D[r][j] += sum_{k=0..3} C'[r][e+k] * x[period j][e+k],
+// evaluated by the hardware as the k-ordered chain fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C))))
+// with one rounding per product (MI355X guide §3 "FP32-input MFMA": bit-for-bit an fmaf chain) —
+// i.e. exactly the canonical order.  The right half-chain maps k to DESCENDING input index.
+// It is used because this FIR is FMA-bound (592 flop per 8.35 algorithmic bytes, 3.6x the ridge):
+// both operands are per-lane VGPRs (coefficients: one coalesced 256-byte global load per chunk;
+// samples: four conflict-free ds_read_b32), so nothing has to squeeze through the SGPR file, and
+// the f32 MFMA rate equals the f32 VALU rate (64 FLOP/clk/SIMD) while leaving the VALU free for
+// addressing.  It is NOT a reshaping into a dense GEMM for low-precision throughput: same flops,
+// same f32 arithmetic, same results.
+// Operand layouts (16x16x4): A lane l = C'[row l&15][k = l>>4]; B lane l = x[period l&15][k = l>>4];
+// D lane l, reg v = D[row 4*(l>>4)+v][period l&15].
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename IO>
+__global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
+{
+    typedef float Real;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Real *xs = reinterpret_cast<Real *>(smem_raw);
+
+    const uint32_t col = blockIdx.y;
+    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64;
+    const int32_t Mc = (int32_t)a.Mc, pad = a.pad, S = Mc + pad;
+
+    if (!(a.dbg & 1)) stage_slab<IO, Real, false>(a, xs, clip, ch, bw);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int kq = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = a.n_waves;
+    const int32_t n_chunks = a.I_h >> 2;
+    const Real *xrow = xs + j * S; // period j of group 0; group g adds 16*g*S
+
+    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
+    IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+
+    for (int rt_ = wave; rt_ < a.n_rt; rt_ += n_waves) {
+        const int rt = __builtin_amdgcn_readfirstlane(rt_);
+        const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]);
+        const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
+        const size_t half_stride = (size_t)(a.I_h + 16) * 16; // + 4 chunks of prefetch slack
+        const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane;
+        const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane;
+        f32x4 accL[4], accR[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { accL[g] = (f32x4){0, 0, 0, 0}; accR[g] = (f32x4){0, 0, 0, 0}; }
+
+        // The coefficient operand of the next group of G chunks is fetched into registers while
+        // the current group's 4*G MFMAs run (one VGPR per chunk).  The prefetch pointer is made
+        // opaque so that the compiler cannot fold the software pipeline back into load-then-use.
+        constexpr int G = 4; // n_chunks is a multiple of G (host geometry); tables carry G chunks of slack
+        // left half-chain: lane k handles input e = eL0 + 4q + k (ascending)
+        {
+            int32_t e = eL0 + kq;
+            int32_t off = e + pad * (e / Mc), next = (e / Mc + 1) * Mc;
+            int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
+            Real ac[G], an[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) ac[u] = tL[u * 64];
+            for (int32_t q = 0; q < n_chunks; q += G) {
+                poff += G * 64;
+                asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
+#pragma unroll
+                for (int u = 0; u < G; ++u) an[u] = (a.dbg & 4) ? 1.0f : tL[poff + u * 64];
+                __builtin_amdgcn_sched_barrier(0); // the prefetch is issued BEFORE this group's MFMAs
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const Real *px = xrow + off;
+                    Real b0, b1, b2, b3;
+                    if (a.dbg & 2) { b0 = b1 = b2 = b3 = ac[u]; }
+                    else { b0 = px[0]; b1 = px[16 * S]; b2 = px[32 * S]; b3 = px[48 * S]; }
+                    accL[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b0, accL[0], 0, 0, 0);
+                    accL[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b1, accL[1], 0, 0, 0);
+                    accL[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b2, accL[2], 0, 0, 0);
+                    accL[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b3, accL[3], 0, 0, 0);
+                    e += 4; off += 4;
+                    if (e >= next) { off += pad; next += Mc; }
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) ac[u] = an[u];
+            }
+        }
+        // right half-chain: chunk q covers inputs [eR0 - 4q, eR0 - 4q + 3]; lane k takes the
+        // (3-k)-th of them, so that k = 0 is the highest index (descending order)
+        {
+            int32_t e = eR0 + 3 - kq;
+            int32_t off = e + pad * (e / Mc), lo = (e / Mc) * Mc;
+            int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
+            Real ac[G], an[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) ac[u] = tR[u * 64];
+            for (int32_t q = 0; q < n_chunks; q += G) {
+                poff += G * 64;
+                asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
+#pragma unroll
+                for (int u = 0; u < G; ++u) an[u] = (a.dbg & 4) ? 1.0f : tR[poff + u * 64];
+                __builtin_amdgcn_sched_barrier(0); // the prefetch is issued BEFORE this group's MFMAs
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const Real *px = xrow + off;
+                    Real b0, b1, b2, b3;
+                    if (a.dbg & 2) { b0 = b1 = b2 = b3 = ac[u]; }
+                    else { b0 = px[0]; b1 = px[16 * S]; b2 = px[32 * S]; b3 = px[48 * S]; }
+                    accR[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b0, accR[0], 0, 0, 0);
+                    accR[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b1, accR[1], 0, 0, 0);
+                    accR[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b2, accR[2], 0, 0, 0);
+                    accR[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b3, accR[3], 0, 0, 0);
+                    e -= 4; off -= 4;
+                    if (e < lo) { off -= pad; lo -= Mc; }
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) ac[u] = an[u];
+            }
+        }
+        // lane holds rows r0 + 4*kq + v (v = 0..3) of periods bw + 16g + j
+        const int32_t r0 = rt * 16 + 4 * kq;
+        if ((a.dbg & 8) && accL[0][0] != 12345.f) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t b = bw + 16 * g + j;
+            const int64_t k0 = b * a.Lc + r0;
+            IO *const yt = ybase + (k0 - a.out_k0) * a.ofs;
+            if (interior && r0 + 4 <= a.Lc) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    store_out<Real>(yt + v * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, k0 + v);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t idx = k0 + v - a.out_k0;
+                    if (r0 + v < a.Lc && idx >= 0 && idx < a.out_frames)
+                        store_out<Real>(yt + v * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, k0 + v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tile_mfma_p — the fast form of k_tile_mfma for input periods that are a multiple of 16
+// samples (48k->44.1k: Mc = 160).  Measured on MI355X (tools/ubench/mfma_rate.hip): the f32 MFMA
+// pipe sustains 145-154 TFLOP/s on its own but loses ~4 cycles per VALU instruction issued
+// beside it, so the inner loop must contain (almost) nothing but MFMAs.  Therefore:
+//   * the slab is stored K-DE-INTERLEAVED in four LDS planes (plane k holds the samples whose
+//     offset is == k mod 4), so ONE ds_read_b128 hands lane (j, k) its B operands for FOUR
+//     consecutive chunks; plane row stride R = Mc/4 + padR with R/4 odd and plane stride a
+//     multiple of 64 words makes every 16-lane read group conflict-free;
+//   * the A operands of four chunks arrive with ONE coalesced global_load_dwordx4 per lane,
+//     prefetched one group (16 MFMAs) ahead;
+//   * all offsets inside the loop are wave-uniform scalars: one v_add per 16 MFMAs.
+// Groups of 16 inputs are aligned to 16 (never straddle a slab row).  Same canonical arithmetic.
+// ---------------------------------------------------------------------------------------------
+template <typename IO>
+__global__ void __launch_bounds__(1024) k_tile_mfma_p(TileArgs a)
+{
+    typedef float Real;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Real *xs = reinterpret_cast<Real *>(smem_raw);
+
+    const uint32_t col = blockIdx.y;
+    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64;
+    const int32_t Mc = (int32_t)a.Mc, R = a.rowR, PLANE = a.plane, padR = R - Mc / 4;
+
+    // ---- stage: sample n of the slab -> plane (n & 3), index (n / Mc) * R + (n % Mc) / 4 ----
+    {
+        typedef IO IO4 __attribute__((ext_vector_type(4)));
+        constexpr int UNR = 4;
+        const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+        const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
+        const bool vec = a.ifs == 1 && ((loc_base & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(xin) & (4 * sizeof(IO) - 1)) == 0);
+        const int32_t n4 = a.x_count >> 2, stride = (int32_t)blockDim.x, Mq = Mc >> 2;
+        for (int32_t q0 = threadIdx.x; q0 < n4; q0 += stride * UNR) {
+            IO4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int32_t q = q0 + u * stride;
+                v[u] = (IO4){0, 0, 0, 0};
+                if (q < n4) {
+                    const int64_t l = loc_base + ((int64_t)q << 2);
+                    if (vec && l >= 0 && l + 3 < a.in_frames) {
+                        v[u] = *reinterpret_cast<const IO4 *>(xin + l);
+                    } else {
+                        if (l >= 0 && l < a.in_frames) v[u].x = xin[l * a.ifs];
+                        if (l + 1 >= 0 && l + 1 < a.in_frames) v[u].y = xin[(l + 1) * a.ifs];
+                        if (l + 2 >= 0 && l + 2 < a.in_frames) v[u].z = xin[(l + 2) * a.ifs];
+                        if (l + 3 >= 0 && l + 3 < a.in_frames) v[u].w = xin[(l + 3) * a.ifs];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int32_t q = q0 + u * stride;
+                if (q < n4) {
+                    const int32_t row = q / Mq, m = row * R + (q - row * Mq);
+                    xs[m] = (Real)v[u].x;
+                    xs[m + PLANE] = (Real)v[u].y;
+                    xs[m + 2 * PLANE] = (Real)v[u].z;
+                    xs[m + 3 * PLANE] = (Real)v[u].w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int kq = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = a.n_waves;
+    const int32_t n_groups = a.I_h >> 4;
+    const size_t half_stride = (size_t)(n_groups + 1) * 64; // float4 per half table (+1 group of slack)
+    const Real *xL = xs + kq * PLANE + j * R;        // left : lane k reads plane k
+    const Real *xR = xs + (3 - kq) * PLANE + j * R;  // right: lane k reads plane 3-k
+
+    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
+    IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+
+    for (int rt_ = wave; rt_ < a.n_rt; rt_ += n_waves) {
+        const int rt = __builtin_amdgcn_readfirstlane(rt_);
+        const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]); // multiples of 16
+        const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
+        const float4 *tL = (const float4 *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane;
+        const float4 *tR = (const float4 *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane;
+        f32x4 accL[4], accR[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { accL[g] = (f32x4){0, 0, 0, 0}; accR[g] = (f32x4){0, 0, 0, 0}; }
+
+        // ---- left half-chain: groups ascend; chunk c of a group = component c of every operand
+        {
+            int32_t rem = eL0 % Mc, fo = (eL0 / Mc) * R + (rem >> 2); // uniform plane offset
+            int32_t poff = 0;
+            float4 ac = tL[0], an;
+            for (int32_t grp = 0; grp < n_groups; ++grp) {
+                poff += 64;
+                asm volatile("" : "+s"(poff)); // keep the software pipeline from being re-rolled
+                an = tL[poff];
+                __builtin_amdgcn_sched_barrier(0);
+                const Real *px = xL + fo;
+                const float4 b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
+                const float4 b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
+                const float4 b2 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 32 * R, 16));
+                const float4 b3 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 48 * R, 16));
+#define HIPSOXR_MFMA4(ACC, AV, C)                                                         \
+    ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b0.C, ACC[0], 0, 0, 0);             \
+    ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b1.C, ACC[1], 0, 0, 0);             \
+    ACC[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b2.C, ACC[2], 0, 0, 0);             \
+    ACC[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b3.C, ACC[3], 0, 0, 0);
+                HIPSOXR_MFMA4(accL, ac.x, x)
+                HIPSOXR_MFMA4(accL, ac.y, y)
+                HIPSOXR_MFMA4(accL, ac.z, z)
+                HIPSOXR_MFMA4(accL, ac.w, w)
+                ac = an;
+                fo += 4; rem += 16;
+                if (rem == Mc) { rem = 0; fo += padR; }
+            }
+        }
+        // ---- right half-chain: groups descend; chunk c (highest inputs first) = component 3-c
+        {
+            int32_t rem = eR0 % Mc, fo = (eR0 / Mc) * R + (rem >> 2);
+            int32_t poff = 0;
+            float4 ac = tR[0], an;
+            for (int32_t grp = 0; grp < n_groups; ++grp) {
+                poff += 64;
+                asm volatile("" : "+s"(poff));
+                an = tR[poff];
+                __builtin_amdgcn_sched_barrier(0);
+                const Real *px = xR + fo;
+                const float4 b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
+                const float4 b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
+                const float4 b2 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 32 * R, 16));
+                const float4 b3 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 48 * R, 16));
+                HIPSOXR_MFMA4(accR, ac.x, w)
+                HIPSOXR_MFMA4(accR, ac.y, z)
+                HIPSOXR_MFMA4(accR, ac.z, y)
+                HIPSOXR_MFMA4(accR, ac.w, x)
+#undef HIPSOXR_MFMA4
+                ac = an;
+                fo -= 4; rem -= 16;
+                if (rem < 0) { rem += Mc; fo -= padR; }
+            }
+        }
+        const int32_t r0 = rt * 16 + 4 * kq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t b = bw + 16 * g + j;
+            const int64_t k0 = b * a.Lc + r0;
+            IO *const yt = ybase + (k0 - a.out_k0) * a.ofs;
+            if (interior && r0 + 4 <= a.Lc) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    store_out<Real>(yt + v * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, k0 + v);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t idx = k0 + v - a.out_k0;
+                    if (r0 + v < a.Lc && idx >= 0 && idx < a.out_frames)
+                        store_out<Real>(yt + v * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, k0 + v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: device tables
 // ---------------------------------------------------------------------------------------------
 #define HIP_TRY(expr)                                                    \
@@ -386,19 +711,95 @@ static inline int32_t floor4(int32_t v) { return v >= 0 ? (v / 4) * 4 : -(((-v) 
 
 struct TileGeom {
     int RT = 16, c = 1;
+    int variant = 0; // 0: k_tile (coefficients on the scalar path), 1: k_tile_mfma
     bool aligned = false;
     int32_t n_rt = 0, I_h = 0, pad = 0, i_min = 0, x_count = 0;
     int64_t Lc = 0, Mc = 0;
     size_t lds_bytes = 0;
+    int32_t rowR = 0, plane = 0; // variant 2 (k_tile_mfma_p)
     std::vector<int32_t> e0;
     bool ok = false;
 };
 
-// Tile geometry + (optionally) tables for one precision.
-template <typename Real>
-static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab)
+static inline int32_t floor16(int32_t v) { return v >= 0 ? (v / 16) * 16 : -(((-v) + 15) / 16) * 16; }
+
+// Geometry + coefficient table of k_tile_mfma_p (f32 engine, Mc % 16 == 0).
+// Table: [n_rt][2][n_groups + 1][64 lanes][4 chunks]; lane (row j = l & 15, k = l >> 4), chunk c:
+//   left : C'[row][i0L + 16*grp + 4*c + k]        right: C'[row][i1R - (16*grp + 4*c + k)]
+static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
 {
     TileGeom g;
+    g.variant = 2;
+    const int64_t L = p.L, M = p.M;
+    const int32_t T = p.T, H = T / 2;
+    g.RT = 16;
+    int c = 1;
+    while (L * c < g.RT && c < 64) c *= 2;
+    while ((M * c) % 16 != 0 && M * c * 2 <= 512 && c < 64) c *= 2;
+    g.c = c; g.Lc = L * c; g.Mc = M * c;
+    if (g.Mc % 16 != 0 || g.Mc > 4096 || g.Lc > 16384) return g;
+    const int32_t Mc = (int32_t)g.Mc;
+    g.n_rt = (int32_t)((g.Lc + 15) / 16);
+    auto n_of = [&](int64_t r) { return (int32_t)((r * M) / L) - (H - 1); };
+    auto p_of = [&](int64_t r) { return (r * M) % L; };
+    std::vector<int32_t> i0L(g.n_rt), i1R(g.n_rt);
+    int32_t I_h = 0;
+    for (int rt = 0; rt < g.n_rt; ++rt) {
+        int64_t r0 = (int64_t)rt * 16, r1 = std::min<int64_t>(r0 + 16, g.Lc) - 1;
+        i0L[rt] = floor16(n_of(r0));
+        i1R[rt] = floor16(n_of(r1) + T - 1) + 15;
+        I_h = std::max(I_h, std::max(n_of(r1) + H - i0L[rt], i1R[rt] - (n_of(r0) + H) + 1));
+    }
+    I_h = (I_h + 15) / 16 * 16;
+    g.I_h = I_h;
+    int32_t i_min = INT32_MAX, i_max = INT32_MIN;
+    for (int rt = 0; rt < g.n_rt; ++rt) { // +-16: the B operand of one group past either end is read too? no: only A is prefetched
+        i_min = std::min(i_min, std::min(i0L[rt], i1R[rt] - I_h + 1));
+        i_max = std::max(i_max, std::max(i0L[rt] + I_h - 1, i1R[rt]));
+    }
+    g.i_min = i_min; // multiples of 16 by construction
+    g.x_count = 63 * Mc + (i_max - i_min + 1);
+    g.rowR = Mc / 4;
+    while ((g.rowR % 8) != 4) ++g.rowR; // R/4 odd -> conflict-free ds_read_b128 across the 16 periods
+    g.pad = g.rowR - Mc / 4;
+    const int32_t rows_total = (g.x_count + Mc - 1) / Mc + 1;
+    g.plane = (rows_total * g.rowR + 63) / 64 * 64;
+    g.lds_bytes = (size_t)g.plane * 4 * sizeof(float);
+    g.e0.resize((size_t)g.n_rt * 2);
+    for (int rt = 0; rt < g.n_rt; ++rt) {
+        g.e0[rt * 2 + 0] = i0L[rt] - i_min;
+        g.e0[rt * 2 + 1] = i1R[rt] - 15 - i_min;
+    }
+    if (g.lds_bytes > 160 * 1024) return g;
+    g.ok = true;
+    if (tab) {
+        const int ng = I_h / 16;
+        tab->assign((size_t)g.n_rt * 2 * (ng + 1) * 256, 0.f);
+        for (int rt = 0; rt < g.n_rt; ++rt)
+            for (int rr = 0; rr < 16; ++rr) {
+                int64_t r = (int64_t)rt * 16 + rr;
+                if (r >= g.Lc) continue;
+                const int32_t nr = n_of(r);
+                const double *cp = p.bank.data() + (size_t)(p_of(r) * T);
+                for (int ii = 0; ii < I_h; ++ii) {
+                    const int grp = ii / 16, cc = (ii % 16) / 4, k = ii % 4, lane = k * 16 + rr;
+                    const size_t at = ((size_t)grp * 64 + lane) * 4 + cc;
+                    int32_t jl = i0L[rt] + ii - nr;
+                    if (jl >= 0 && jl < H) (*tab)[(size_t)(rt * 2 + 0) * (ng + 1) * 256 + at] = (float)cp[jl];
+                    int32_t jr = i1R[rt] - ii - nr;
+                    if (jr >= H && jr < T) (*tab)[(size_t)(rt * 2 + 1) * (ng + 1) * 256 + at] = (float)cp[jr];
+                }
+            }
+    }
+    return g;
+}
+
+// Tile geometry + (optionally) tables for one precision.
+template <typename Real>
+static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab, int variant = 0)
+{
+    TileGeom g;
+    g.variant = variant;
     const int64_t L = p.L, M = p.M;
     const int32_t T = p.T, H = T / 2;
     g.RT = 16;
@@ -406,14 +807,19 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab)
     int c = 1;
     while (L * c < g.RT && c < 64) c *= 2;
     // prefer an input period that is a multiple of 4 (b128 LDS reads) when the slab stays small
-    if (M % 2 == 0 || M * 4 <= 256)
+    if (variant == 0 && (M % 2 == 0 || M * 4 <= 256))
         while ((M * c) % 4 != 0 && M * c * 2 <= 256 && c < 64) c *= 2;
     g.c = c;
     g.Lc = L * c; g.Mc = M * c;
     if (g.Mc > 8192 || g.Lc > 16384) return g; // period too long for an LDS-resident slab
-    g.aligned = (g.Mc % 4 == 0);
+    g.aligned = variant == 0 && (g.Mc % 4 == 0);
     const int32_t Mc = (int32_t)g.Mc;
-    if (g.aligned) { // row stride = 4*odd words -> conflict-free ds_read_b128 across lanes
+    if (variant == 1) {
+        // k_tile_mfma: a 32-lane half reads x[(16 periods j)*S + (2 inputs k)] with ds_read_b32;
+        // conflict-free iff the row stride S = Mc + pad is 2*odd (mod 32).
+        g.pad = 0;
+        while (((Mc + g.pad) % 4) != 2) ++g.pad;
+    } else if (g.aligned) { // row stride = 4*odd words -> conflict-free ds_read_b128 across lanes
         g.pad = ((Mc / 4) % 2 == 0) ? 4 : 0;
     } else {         // row stride odd -> conflict-free ds_read_b32
         g.pad = (Mc % 2 == 0) ? 1 : 0;
@@ -435,17 +841,17 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab)
         int32_t IR = a1 - (n_of(r0) + H) + 1;  // inputs n_r0+H .. a1
         I_h = std::max(I_h, std::max(IL, IR));
     }
-    I_h = (I_h + 3) / 4 * 4;
+    I_h = variant == 1 ? (I_h + 15) / 16 * 16 : (I_h + 3) / 4 * 4; // k_tile_mfma works in groups of 4 chunks
     g.I_h = I_h;
     int32_t i_min = INT32_MAX, i_max = INT32_MIN;
     for (int rt = 0; rt < g.n_rt; ++rt) {
         i_min = std::min(i_min, std::min(i0L[rt], i1R[rt] - I_h + 1));
         i_max = std::max(i_max, std::max(i0L[rt] + I_h - 1, i1R[rt]));
     }
-    if (g.aligned) { i_min = floor4(i_min); i_max = floor4(i_max) + 3; }
+    i_min = floor4(i_min); i_max = floor4(i_max) + 3; // slab = whole quads (vectorised staging)
     g.i_min = i_min;
-    g.x_count = 63 * Mc + (i_max - i_min + 1);
-    g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / Mc + 1) + 4) * sizeof(Real);
+    g.x_count = (63 * Mc + (i_max - i_min + 1) + 3) / 4 * 4; // whole quads (63*Mc may be odd)
+    g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / Mc + 1) + 8) * sizeof(Real);
     g.e0.resize((size_t)g.n_rt * 2);
     for (int rt = 0; rt < g.n_rt; ++rt) {
         g.e0[rt * 2 + 0] = i0L[rt] - i_min;
@@ -454,10 +860,11 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab)
     if (g.lds_bytes > 160 * 1024) return g;
     g.ok = true;
     if (tab) {
-        tab->assign((size_t)g.n_rt * 2 * I_h * g.RT, (Real)0);
+        const size_t rows = (size_t)I_h + (variant == 1 ? 16 : 0); // prefetch slack (zeros)
+        tab->assign((size_t)g.n_rt * 2 * rows * g.RT, (Real)0);
         for (int rt = 0; rt < g.n_rt; ++rt) {
-            Real *tl = tab->data() + (size_t)(rt * 2 + 0) * I_h * g.RT;
-            Real *tr = tab->data() + (size_t)(rt * 2 + 1) * I_h * g.RT;
+            Real *tl = tab->data() + (size_t)(rt * 2 + 0) * rows * g.RT;
+            Real *tr = tab->data() + (size_t)(rt * 2 + 1) * rows * g.RT;
             for (int rr = 0; rr < g.RT; ++rr) {
                 int64_t r = (int64_t)rt * g.RT + rr;
                 if (r >= g.Lc) continue;
@@ -476,7 +883,7 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab)
 }
 
 template <typename Real>
-static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out)
+static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out, TileGeom *geom_m_out)
 {
     const int64_t L = p->L;
     const int32_t T = p->T;
@@ -497,17 +904,29 @@ static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out)
         d.RT = g.RT; d.n_rt = g.n_rt; d.I_h = g.I_h;
     }
     *geom_out = g;
+    if (sizeof(Real) == 4 && geom_m_out) {
+        std::vector<float> tabm;
+        TileGeom gm = build_mfma_planes(*p, &tabm);
+        if (!gm.ok || getenv("HIPSOXR_NO_PLANES")) gm = build_tile_tables<float>(*p, &tabm, 1);
+        if (gm.ok) {
+            HIP_TRY(hipMalloc(&d.tile_tab_m, tabm.size() * sizeof(Real)));
+            HIP_TRY(hipMemcpy(d.tile_tab_m, tabm.data(), tabm.size() * sizeof(Real), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void **)&d.tile_i0_m, gm.e0.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy(d.tile_i0_m, gm.e0.data(), gm.e0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        *geom_m_out = gm;
+    }
     return nullptr;
 }
 
 // geometry is cheap to recompute; keep it beside the bank in a side table keyed by (plan, prec)
 static std::mutex g_geom_mu;
-static std::vector<std::pair<std::pair<const Plan *, int>, TileGeom>> g_geoms;
+static std::vector<std::pair<std::pair<const Plan *, int>, TileGeom>> g_geoms; // key: (plan, prec*2+variant)
 
-static TileGeom *geom_find(const Plan *p, int prec)
+static TileGeom *geom_find(const Plan *p, int prec, int variant)
 {
     for (auto &e : g_geoms)
-        if (e.first.first == p && e.first.second == prec) return &e.second;
+        if (e.first.first == p && e.first.second == prec * 2 + variant) return &e.second;
     return nullptr;
 }
 
@@ -517,12 +936,13 @@ const char *device_bank_ensure(Plan *p, int prec)
     DeviceBank &d = p->dev[prec];
     if (d.ready) return nullptr;
     if (device_count() <= 0) return "no HIP device available (hipsoxr has no CPU fallback)";
-    TileGeom g;
-    const char *e = prec == 0 ? bank_upload<float>(p, d, &g) : bank_upload<double>(p, d, &g);
+    TileGeom g, gm;
+    const char *e = prec == 0 ? bank_upload<float>(p, d, &g, &gm) : bank_upload<double>(p, d, &g, nullptr);
     if (e) return e;
     {
         std::lock_guard<std::mutex> lk2(g_geom_mu);
-        g_geoms.push_back({{p, prec}, g});
+        g_geoms.push_back({{p, prec * 2 + 0}, g});
+        g_geoms.push_back({{p, prec * 2 + 1}, gm});
     }
     d.ready = true;
     return nullptr;
@@ -535,6 +955,8 @@ void device_bank_release(Plan *p)
         if (d.tap_major) (void)hipFree(d.tap_major);
         if (d.tile_tab) (void)hipFree(d.tile_tab);
         if (d.tile_i0) (void)hipFree(d.tile_i0);
+        if (d.tile_tab_m) (void)hipFree(d.tile_tab_m);
+        if (d.tile_i0_m) (void)hipFree(d.tile_i0_m);
         d = DeviceBank();
     }
     std::lock_guard<std::mutex> lk2(g_geom_mu);
@@ -592,7 +1014,9 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
 {
     const DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
     TileArgs a;
-    a.in = j.in; a.out = j.out; a.tab = d.tile_tab; a.e0 = d.tile_i0;
+    a.in = j.in; a.out = j.out;
+    a.tab = g.variant >= 1 ? d.tile_tab_m : d.tile_tab;
+    a.e0 = g.variant >= 1 ? d.tile_i0_m : d.tile_i0;
     a.Lc = g.Lc; a.Mc = g.Mc; a.n_rt = g.n_rt; a.I_h = g.I_h;
     a.pad = g.pad; a.i_min = g.i_min; a.x_count = g.x_count;
     a.n_clips = j.n_clips; a.n_channels = j.n_channels;
@@ -619,8 +1043,17 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         nw = best;
     }
     a.n_waves = nw;
+    {
+        static const char *df = getenv("HIPSOXR_DEBUG_FLAGS");
+        a.dbg = df ? atoi(df) : 0;
+    }
     dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
     void (*kern)(TileArgs) = g.aligned ? k_tile<IO, Real, 16, true> : k_tile<IO, Real, 16, false>;
+    if constexpr (sizeof(Real) == 4) {
+        if (g.variant == 1) kern = k_tile_mfma<IO>;
+        if (g.variant == 2) kern = k_tile_mfma_p<IO>;
+    }
+    a.rowR = g.rowR; a.plane = g.plane;
     if (g.lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)g.lds_bytes));
@@ -633,20 +1066,27 @@ template <typename IO, typename Real>
 static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
 {
     const int prec = sizeof(Real) == 4 ? 0 : 1;
-    TileGeom g;
+    TileGeom gv, gm; // VALU-tile and MFMA-tile geometries (the latter exists for the f32 engine only)
     {
         std::lock_guard<std::mutex> lk(g_geom_mu);
-        TileGeom *gp = geom_find(p, prec);
-        if (gp) g = *gp;
+        if (TileGeom *gp = geom_find(p, prec, 0)) gv = *gp;
+        if (TileGeom *gp = geom_find(p, prec, 1)) gm = *gp;
     }
     int kernel = j.kernel;
-    if (kernel == HIPSOXR_KERNEL_TILE && !g.ok) return "tile kernel unavailable for this plan";
-    if (kernel == HIPSOXR_KERNEL_AUTO) {
-        // the tile kernel pays off once a job spans a few thousand outputs per column
-        const bool big = g.ok && j.out_frames >= 16 * g.Lc && j.out_frames >= 4096;
-        kernel = big ? HIPSOXR_KERNEL_TILE : HIPSOXR_KERNEL_GATHER;
+    if (kernel == HIPSOXR_KERNEL_TILE_VALU && !gv.ok) return "tile kernel unavailable for this plan";
+    if (kernel == HIPSOXR_KERNEL_TILE_MFMA && !gm.ok) return "tile kernel unavailable for this plan";
+    if (kernel == HIPSOXR_KERNEL_TILE) {
+        if (!gv.ok && !gm.ok) return "tile kernel unavailable for this plan";
+        kernel = gm.ok ? HIPSOXR_KERNEL_TILE_MFMA : HIPSOXR_KERNEL_TILE_VALU;
     }
-    if (kernel == HIPSOXR_KERNEL_TILE) return launch_tile<IO, Real>(p, j, st, g);
+    if (kernel == HIPSOXR_KERNEL_AUTO) {
+        // a tile kernel pays off once a job spans a few thousand outputs per column
+        const TileGeom &g = gm.ok ? gm : gv;
+        const bool big = g.ok && j.out_frames >= 16 * g.Lc && j.out_frames >= 4096;
+        kernel = !big ? HIPSOXR_KERNEL_GATHER : gm.ok ? HIPSOXR_KERNEL_TILE_MFMA : HIPSOXR_KERNEL_TILE_VALU;
+    }
+    if (kernel == HIPSOXR_KERNEL_TILE_MFMA) return launch_tile<IO, Real>(p, j, st, gm);
+    if (kernel == HIPSOXR_KERNEL_TILE_VALU) return launch_tile<IO, Real>(p, j, st, gv);
     return launch_gather<IO, Real>(p, j, st);
 }
 

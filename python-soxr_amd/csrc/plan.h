@@ -24,6 +24,8 @@ struct DeviceBank {
     // tile kernel: per output-tile skewed, zero-padded half tables (see kernels.hip)
     void *tile_tab = nullptr;    // [n_rt][2][I_h][RT]
     int32_t RT = 0, n_rt = 0, I_h = 0;
+    void *tile_tab_m = nullptr;  // f32 engine: tables in the k_tile_mfma geometry
+    int32_t *tile_i0_m = nullptr;
     int32_t *tile_i0 = nullptr;  // [n_rt][2] device: first input offset (rel. to period start) of each half
     bool ready = false;
 };

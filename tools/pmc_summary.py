@@ -12,7 +12,7 @@ def main(paths):
         print("==", db)
         try:
             for r in c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
-                print("  %-60s calls %5d  avg %12.1f ns  %5.1f%%" % (r[0][:60], r[1], r[3], r[4]))
+                print("  %-60s calls %5d  avg %12.1f us  %5.1f%%" % (r[0][:60], r[1], r[3], r[4]))
         except sqlite3.Error as e:
             print("  (no top_kernels: %s)" % e)
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
