@@ -568,7 +568,8 @@ __global__ void __launch_bounds__(1024) k_tile_mfma_p(TileArgs a)
                 v[u] = (IO4){0, 0, 0, 0};
                 if (q < n4) {
                     const int64_t l = loc_base + ((int64_t)q << 2);
-                    if (vec && l >= 0 && l + 3 < a.in_frames) {
+                    if (a.dbg & 1) {
+                    } else if (vec && l >= 0 && l + 3 < a.in_frames) {
                         v[u] = *reinterpret_cast<const IO4 *>(xin + l);
                     } else {
                         if (l >= 0 && l < a.in_frames) v[u].x = xin[l * a.ifs];
@@ -623,13 +624,17 @@ __global__ void __launch_bounds__(1024) k_tile_mfma_p(TileArgs a)
             for (int32_t grp = 0; grp < n_groups; ++grp) {
                 poff += 64;
                 asm volatile("" : "+s"(poff)); // keep the software pipeline from being re-rolled
-                an = tL[poff];
+                an = (a.dbg & 4) ? ac : tL[poff];
                 __builtin_amdgcn_sched_barrier(0);
                 const Real *px = xL + fo;
-                const float4 b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
-                const float4 b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
-                const float4 b2 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 32 * R, 16));
-                const float4 b3 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 48 * R, 16));
+                float4 b0, b1, b2, b3;
+                if (a.dbg & 2) { b0 = b1 = b2 = b3 = ac; }
+                else {
+                b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
+                b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
+                b2 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 32 * R, 16));
+                b3 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 48 * R, 16));
+                }
 #define HIPSOXR_MFMA4(ACC, AV, C)                                                         \
     ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b0.C, ACC[0], 0, 0, 0);             \
     ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b1.C, ACC[1], 0, 0, 0);             \
@@ -652,13 +657,17 @@ __global__ void __launch_bounds__(1024) k_tile_mfma_p(TileArgs a)
             for (int32_t grp = 0; grp < n_groups; ++grp) {
                 poff += 64;
                 asm volatile("" : "+s"(poff));
-                an = tR[poff];
+                an = (a.dbg & 4) ? ac : tR[poff];
                 __builtin_amdgcn_sched_barrier(0);
                 const Real *px = xR + fo;
-                const float4 b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
-                const float4 b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
-                const float4 b2 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 32 * R, 16));
-                const float4 b3 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 48 * R, 16));
+                float4 b0, b1, b2, b3;
+                if (a.dbg & 2) { b0 = b1 = b2 = b3 = ac; }
+                else {
+                b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
+                b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
+                b2 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 32 * R, 16));
+                b3 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 48 * R, 16));
+                }
                 HIPSOXR_MFMA4(accR, ac.x, w)
                 HIPSOXR_MFMA4(accR, ac.y, z)
                 HIPSOXR_MFMA4(accR, ac.z, y)
@@ -670,6 +679,7 @@ __global__ void __launch_bounds__(1024) k_tile_mfma_p(TileArgs a)
             }
         }
         const int32_t r0 = rt * 16 + 4 * kq;
+        if ((a.dbg & 8) && accL[0][0] != 12345.f) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int64_t b = bw + 16 * g + j;
@@ -1042,12 +1052,15 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         }
         nw = best;
     }
+    if (const char *dn = getenv("HIPSOXR_DEBUG_NRT")) { a.n_rt = atoi(dn); nw = a.n_rt; }
+    if (const char *dw = getenv("HIPSOXR_DEBUG_NW")) nw = atoi(dw);
     a.n_waves = nw;
     {
         static const char *df = getenv("HIPSOXR_DEBUG_FLAGS");
         a.dbg = df ? atoi(df) : 0;
     }
     dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
+    // (HIPSOXR_DEBUG_* are timing experiments only; results are wrong when they are set)
     void (*kern)(TileArgs) = g.aligned ? k_tile<IO, Real, 16, true> : k_tile<IO, Real, 16, false>;
     if constexpr (sizeof(Real) == 4) {
         if (g.variant == 1) kern = k_tile_mfma<IO>;
