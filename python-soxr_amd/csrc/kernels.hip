@@ -186,6 +186,7 @@ struct TileArgs {
     int64_t Lc, Mc;      // replicated period
     int32_t n_rt, I_h, n_waves;
     int32_t rowR, plane; // k_tile_mfma_p: plane row stride and plane stride (words)
+    unsigned long long *trace; // HIPSOXR_DEBUG_TRACE: per-wave s_memtime stamps [block][wave][16]
     int32_t dbg; // timing ablations only (HIPSOXR_DEBUG_FLAGS): 1 no staging loads, 2 no LDS reads, 4 no coefficient loads, 8 no stores
     int32_t pad, i_min, x_count; // LDS row padding; first staged input; samples staged per tile
     uint32_t n_clips, n_channels;
@@ -539,166 +540,226 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
 //   * all offsets inside the loop are wave-uniform scalars: one v_add per 16 MFMAs.
 // Groups of 16 inputs are aligned to 16 (never straddle a slab row).  Same canonical arithmetic.
 // ---------------------------------------------------------------------------------------------
+// One half-chain of a work unit (16 phases x 32 periods), software-pipelined inside the wave:
+// the B operands (two ds_read_b128) of group g+1 and the A operand (one global_load_dwordx4) of
+// group g+2 are in flight while the 8 MFMAs of group g issue, so that a single wave per SIMD keeps
+// the matrix pipe busy.  The loop is unrolled by two groups with ping-pong registers (no copies).
+// RIGHT = false: ascending groups, chunk c uses component c; true: descending, component 3-c.
+template <bool RIGHT>
+__device__ __forceinline__ void mfma_half_chain(f32x4 (&acc)[2], const float4 *t, const float *xb,
+                                                int32_t e0, int32_t n_groups, int32_t Mc, int32_t R,
+                                                int32_t padR)
+{
+    int32_t rem = e0 % Mc, fo = (e0 / Mc) * R + (rem >> 2); // wave-uniform plane offset of the next B read
+    auto ldb = [&](float4 &b0, float4 &b1) {
+        const float *px = xb + fo;
+        b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
+        b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
+        if (!RIGHT) { fo += 4; rem += 16; if (rem == Mc) { rem = 0; fo += padR; } }
+        else { fo -= 4; rem -= 16; if (rem < 0) { rem += Mc; fo -= padR; } }
+    };
+#define HIPSOXR_MFMA8(AV, B0, B1)                                                              \
+    if (!RIGHT) {                                                                               \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.x, B0.x, acc[0], 0, 0, 0);             \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.x, B1.x, acc[1], 0, 0, 0);             \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.y, B0.y, acc[0], 0, 0, 0);             \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.y, B1.y, acc[1], 0, 0, 0);             \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.z, B0.z, acc[0], 0, 0, 0);             \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.z, B1.z, acc[1], 0, 0, 0);             \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.w, B0.w, acc[0], 0, 0, 0);             \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.w, B1.w, acc[1], 0, 0, 0);             \
+    } else {                                                                                    \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.x, B0.w, acc[0], 0, 0, 0);             \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.x, B1.w, acc[1], 0, 0, 0);             \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.y, B0.z, acc[0], 0, 0, 0);             \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.y, B1.z, acc[1], 0, 0, 0);             \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.z, B0.y, acc[0], 0, 0, 0);             \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.z, B1.y, acc[1], 0, 0, 0);             \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.w, B0.x, acc[0], 0, 0, 0);             \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.w, B1.x, acc[1], 0, 0, 0);             \
+    }
+    // A operands: ring of 4 registers, each reloaded for group g+4 right after group g's MFMAs
+    // (3 groups = 24 MFMAs = 768 pipe cycles ahead of use: an L2 round trip).  B operands: one
+    // group ahead (LDS latency).  sched_barrier(0) pins "loads first, then this group's MFMAs".
+    float4 a0 = t[0], a1 = t[64], a2 = t[128], a3 = t[192];
+    float4 bE0, bE1, bO0, bO1;
+    ldb(bE0, bE1);                  // B of group 0
+    int32_t poff = 192;             // table offset (float4) of the newest A in flight
+    int32_t grp = 0;
+#define HIPSOXR_STEP(AR, BC0, BC1, BN0, BN1)                                                   \
+    ldb(BN0, BN1);                  /* B of the next group */                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    HIPSOXR_MFMA8(AR, BC0, BC1)                                                                 \
+    poff += 64;                                                                                 \
+    asm volatile("" : "+s"(poff)); /* opaque: the pipeline must not be re-rolled */             \
+    AR = t[poff];                   /* A of group +4 */
+    for (; grp + 3 < n_groups; grp += 4) {
+        HIPSOXR_STEP(a0, bE0, bE1, bO0, bO1)
+        HIPSOXR_STEP(a1, bO0, bO1, bE0, bE1)
+        HIPSOXR_STEP(a2, bE0, bE1, bO0, bO1)
+        HIPSOXR_STEP(a3, bO0, bO1, bE0, bE1)
+    }
+    // 0..3 remaining groups (their A operands are already in a0..a2, B of the first in bE)
+    if (grp < n_groups) {
+        ldb(bO0, bO1);
+        __builtin_amdgcn_sched_barrier(0);
+        HIPSOXR_MFMA8(a0, bE0, bE1)
+        if (grp + 1 < n_groups) {
+            ldb(bE0, bE1);
+            __builtin_amdgcn_sched_barrier(0);
+            HIPSOXR_MFMA8(a1, bO0, bO1)
+            if (grp + 2 < n_groups) {
+                __builtin_amdgcn_sched_barrier(0);
+                HIPSOXR_MFMA8(a2, bE0, bE1)
+            }
+        }
+    }
+#undef HIPSOXR_STEP
+#undef HIPSOXR_MFMA8
+}
+
+// Stage one slab of k_tile_mfma_p: sample n -> plane (n & 3), index (n / Mc) * R + (n % Mc) / 4.
+// The CU's matrix pipes are saturated by other waves while this runs, and every ordinary VALU
+// instruction queues behind 32-cycle MFMA issues, so the code is VALU-lean: interior slabs (the
+// common case) take a path with no bounds tests, no division (the (row, column) of a thread's next
+// quad advances incrementally) and 32-bit offsets from a wave-uniform base; loads are issued in
+// batches of UNR before any is consumed.
 template <typename IO>
-__global__ void __launch_bounds__(1024) k_tile_mfma_p(TileArgs a)
+__device__ __forceinline__ void stage_planes(const TileArgs &a, float *xs, uint32_t clip, uint32_t ch,
+                                             int64_t bw)
+{
+    typedef IO IO4 __attribute__((ext_vector_type(4)));
+    constexpr int UNR = 4;
+    const int32_t Mc = (int32_t)a.Mc, R = a.rowR, PLANE = a.plane;
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
+    const int32_t n4 = a.x_count >> 2, stride = (int32_t)blockDim.x, Mq = Mc >> 2;
+    const bool fast = a.ifs == 1 && ((loc_base & 3) == 0) && loc_base >= 0 &&
+                      loc_base + a.x_count <= a.in_frames &&
+                      ((reinterpret_cast<uintptr_t>(xin) & (4 * sizeof(IO) - 1)) == 0);
+    if (fast) {
+        const IO4 *src = reinterpret_cast<const IO4 *>(xin + loc_base); // wave-uniform base
+        const int32_t drow = stride / Mq, dcol = stride - drow * Mq;     // uniform step of (row, col)
+        int32_t q = threadIdx.x, row = q / Mq, colq = q - row * Mq;
+        while (q < n4) {
+            IO4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (q + u * stride < n4) v[u] = src[q + u * stride];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (q + u * stride < n4) {
+                    const int32_t m = row * R + colq;
+                    xs[m] = (float)v[u].x;
+                    xs[m + PLANE] = (float)v[u].y;
+                    xs[m + 2 * PLANE] = (float)v[u].z;
+                    xs[m + 3 * PLANE] = (float)v[u].w;
+                }
+                row += drow; colq += dcol;
+                if (colq >= Mq) { colq -= Mq; ++row; }
+            }
+            q += stride * UNR;
+        }
+    } else {
+        for (int32_t q0 = threadIdx.x; q0 < n4; q0 += stride) {
+            const int64_t l = loc_base + ((int64_t)q0 << 2);
+            IO4 v = (IO4){0, 0, 0, 0};
+            if (l >= 0 && l < a.in_frames) v.x = xin[l * a.ifs];
+            if (l + 1 >= 0 && l + 1 < a.in_frames) v.y = xin[(l + 1) * a.ifs];
+            if (l + 2 >= 0 && l + 2 < a.in_frames) v.z = xin[(l + 2) * a.ifs];
+            if (l + 3 >= 0 && l + 3 < a.in_frames) v.w = xin[(l + 3) * a.ifs];
+            const int32_t row = q0 / Mq, m = row * R + (q0 - row * Mq);
+            xs[m] = (float)v.x;
+            xs[m + PLANE] = (float)v.y;
+            xs[m + 2 * PLANE] = (float)v.z;
+            xs[m + 3 * PLANE] = (float)v.w;
+        }
+    }
+}
+
+template <typename IO>
+__global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
 {
     typedef float Real;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Real *xs = reinterpret_cast<Real *>(smem_raw);
+    const int32_t Mc = (int32_t)a.Mc, R = a.rowR, PLANE = a.plane, padR = R - Mc / 4;
+    Real *xs = reinterpret_cast<Real *>(smem_raw) + R; // one row of slack below (pipelined reads run one group past the end)
 
     const uint32_t col = blockIdx.y;
     const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
     const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64;
-    const int32_t Mc = (int32_t)a.Mc, R = a.rowR, PLANE = a.plane, padR = R - Mc / 4;
+    const int64_t k_end = a.out_k0 + a.out_frames;
+    unsigned long long *tr = a.trace ? a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 : nullptr;
+    int tri = 0;
+#define HIPSOXR_STAMP() do { if (tr && (threadIdx.x & 63) == 0 && tri < 16) tr[tri] = __builtin_amdgcn_s_memtime(); ++tri; } while (0)
+    HIPSOXR_STAMP();
 
-    // ---- stage: sample n of the slab -> plane (n & 3), index (n / Mc) * R + (n % Mc) / 4 ----
-    {
-        typedef IO IO4 __attribute__((ext_vector_type(4)));
-        constexpr int UNR = 4;
-        const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-        const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
-        const bool vec = a.ifs == 1 && ((loc_base & 3) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(xin) & (4 * sizeof(IO) - 1)) == 0);
-        const int32_t n4 = a.x_count >> 2, stride = (int32_t)blockDim.x, Mq = Mc >> 2;
-        for (int32_t q0 = threadIdx.x; q0 < n4; q0 += stride * UNR) {
-            IO4 v[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int32_t q = q0 + u * stride;
-                v[u] = (IO4){0, 0, 0, 0};
-                if (q < n4) {
-                    const int64_t l = loc_base + ((int64_t)q << 2);
-                    if (a.dbg & 1) {
-                    } else if (vec && l >= 0 && l + 3 < a.in_frames) {
-                        v[u] = *reinterpret_cast<const IO4 *>(xin + l);
-                    } else {
-                        if (l >= 0 && l < a.in_frames) v[u].x = xin[l * a.ifs];
-                        if (l + 1 >= 0 && l + 1 < a.in_frames) v[u].y = xin[(l + 1) * a.ifs];
-                        if (l + 2 >= 0 && l + 2 < a.in_frames) v[u].z = xin[(l + 2) * a.ifs];
-                        if (l + 3 >= 0 && l + 3 < a.in_frames) v[u].w = xin[(l + 3) * a.ifs];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int32_t q = q0 + u * stride;
-                if (q < n4) {
-                    const int32_t row = q / Mq, m = row * R + (q - row * Mq);
-                    xs[m] = (Real)v[u].x;
-                    xs[m + PLANE] = (Real)v[u].y;
-                    xs[m + 2 * PLANE] = (Real)v[u].z;
-                    xs[m + 3 * PLANE] = (Real)v[u].w;
-                }
-            }
-        }
-    }
+    stage_planes<IO>(a, xs, clip, ch, bw);
+    HIPSOXR_STAMP();
     __syncthreads();
+    HIPSOXR_STAMP();
 
     const int lane = threadIdx.x & 63;
     const int kq = lane >> 4, j = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_waves = a.n_waves;
     const int32_t n_groups = a.I_h >> 4;
-    const size_t half_stride = (size_t)(n_groups + 1) * 64; // float4 per half table (+1 group of slack)
+    const size_t half_stride = (size_t)(n_groups + 4) * 64; // float4 per half table (+4 groups of prefetch slack)
     const Real *xL = xs + kq * PLANE + j * R;        // left : lane k reads plane k
     const Real *xR = xs + (3 - kq) * PLANE + j * R;  // right: lane k reads plane 3-k
-
-    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
     IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= k_end;
 
-    for (int rt_ = wave; rt_ < a.n_rt; rt_ += n_waves) {
-        const int rt = __builtin_amdgcn_readfirstlane(rt_);
+    // Work unit = (tile, half of the 64 periods).  A workgroup runs 4 waves — exactly one per SIMD,
+    // because 10-wave workgroups land 3/3/2/2 on the SIMDs and leave 17 % of the matrix pipe idle
+    // (tools/ubench/mfma_loop.hip) — and its 2*n_rt equal units are dealt round-robin.
+    // Small jobs additionally split a slab's units over gridDim.z workgroups (each stages the slab).
+    for (int u_ = wave + n_waves * (int)blockIdx.z; u_ < 2 * a.n_rt; u_ += n_waves * (int)gridDim.z) {
+        const int unit = __builtin_amdgcn_readfirstlane(u_);
+        const int rt = unit >> 1, ph = unit & 1; // periods 32*ph .. 32*ph + 31
         const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]); // multiples of 16
         const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
         const float4 *tL = (const float4 *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane;
         const float4 *tR = (const float4 *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane;
-        f32x4 accL[4], accR[4];
+        f32x4 accL[2], accR[2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { accL[g] = (f32x4){0, 0, 0, 0}; accR[g] = (f32x4){0, 0, 0, 0}; }
+        for (int g = 0; g < 2; ++g) { accL[g] = (f32x4){0, 0, 0, 0}; accR[g] = (f32x4){0, 0, 0, 0}; }
 
-        // ---- left half-chain: groups ascend; chunk c of a group = component c of every operand
-        {
-            int32_t rem = eL0 % Mc, fo = (eL0 / Mc) * R + (rem >> 2); // uniform plane offset
-            int32_t poff = 0;
-            float4 ac = tL[0], an;
-            for (int32_t grp = 0; grp < n_groups; ++grp) {
-                poff += 64;
-                asm volatile("" : "+s"(poff)); // keep the software pipeline from being re-rolled
-                an = (a.dbg & 4) ? ac : tL[poff];
-                __builtin_amdgcn_sched_barrier(0);
-                const Real *px = xL + fo;
-                float4 b0, b1, b2, b3;
-                if (a.dbg & 2) { b0 = b1 = b2 = b3 = ac; }
-                else {
-                b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
-                b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
-                b2 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 32 * R, 16));
-                b3 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 48 * R, 16));
-                }
-#define HIPSOXR_MFMA4(ACC, AV, C)                                                         \
-    ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b0.C, ACC[0], 0, 0, 0);             \
-    ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b1.C, ACC[1], 0, 0, 0);             \
-    ACC[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b2.C, ACC[2], 0, 0, 0);             \
-    ACC[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, b3.C, ACC[3], 0, 0, 0);
-                HIPSOXR_MFMA4(accL, ac.x, x)
-                HIPSOXR_MFMA4(accL, ac.y, y)
-                HIPSOXR_MFMA4(accL, ac.z, z)
-                HIPSOXR_MFMA4(accL, ac.w, w)
-                ac = an;
-                fo += 4; rem += 16;
-                if (rem == Mc) { rem = 0; fo += padR; }
-            }
-        }
-        // ---- right half-chain: groups descend; chunk c (highest inputs first) = component 3-c
-        {
-            int32_t rem = eR0 % Mc, fo = (eR0 / Mc) * R + (rem >> 2);
-            int32_t poff = 0;
-            float4 ac = tR[0], an;
-            for (int32_t grp = 0; grp < n_groups; ++grp) {
-                poff += 64;
-                asm volatile("" : "+s"(poff));
-                an = (a.dbg & 4) ? ac : tR[poff];
-                __builtin_amdgcn_sched_barrier(0);
-                const Real *px = xR + fo;
-                float4 b0, b1, b2, b3;
-                if (a.dbg & 2) { b0 = b1 = b2 = b3 = ac; }
-                else {
-                b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
-                b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
-                b2 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 32 * R, 16));
-                b3 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 48 * R, 16));
-                }
-                HIPSOXR_MFMA4(accR, ac.x, w)
-                HIPSOXR_MFMA4(accR, ac.y, z)
-                HIPSOXR_MFMA4(accR, ac.z, y)
-                HIPSOXR_MFMA4(accR, ac.w, x)
-#undef HIPSOXR_MFMA4
-                ac = an;
-                fo -= 4; rem -= 16;
-                if (rem < 0) { rem += Mc; fo -= padR; }
-            }
-        }
+        mfma_half_chain<false>(accL, tL, xL + ph * 32 * R, eL0, n_groups, Mc, R, padR);
+        mfma_half_chain<true>(accR, tR, xR + ph * 32 * R, eR0, n_groups, Mc, R, padR);
+        HIPSOXR_STAMP();
+
         const int32_t r0 = rt * 16 + 4 * kq;
-        if ((a.dbg & 8) && accL[0][0] != 12345.f) continue;
+        if (interior && rt * 16 + 16 <= a.Lc && a.ofs == 1) {
+            // whole unit in range, unit stride: 32-bit offsets from the slab's first output
+            IO *const yw = ybase + (bw * a.Lc - a.out_k0);           // wave-uniform
+            const int32_t o0 = (32 * ph + j) * (int32_t)a.Lc + r0;   // this lane, group 0
+            const int64_t kw = bw * a.Lc;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int64_t b = bw + 16 * g + j;
-            const int64_t k0 = b * a.Lc + r0;
-            IO *const yt = ybase + (k0 - a.out_k0) * a.ofs;
-            if (interior && r0 + 4 <= a.Lc) {
+            for (int g = 0; g < 2; ++g) {
+                const int32_t o = o0 + 16 * g * (int32_t)a.Lc;
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    store_out<Real>(yt + v * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, k0 + v);
-            } else {
+                for (int vv = 0; vv < 4; ++vv)
+                    store_out<Real>(yw + o + vv, accL[g][vv] + accR[g][vv], a.oc, ch, kw + o + vv);
+            }
+        } else {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int64_t idx = k0 + v - a.out_k0;
-                    if (r0 + v < a.Lc && idx >= 0 && idx < a.out_frames)
-                        store_out<Real>(yt + v * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, k0 + v);
+            for (int g = 0; g < 2; ++g) {
+                const int64_t b = bw + 32 * ph + 16 * g + j;
+                const int64_t k0 = b * a.Lc + r0;
+                IO *const yt = ybase + (k0 - a.out_k0) * a.ofs;
+#pragma unroll
+                for (int vv = 0; vv < 4; ++vv) {
+                    const int64_t idx = k0 + vv - a.out_k0;
+                    if (r0 + vv < a.Lc && idx >= 0 && idx < a.out_frames)
+                        store_out<Real>(yt + vv * a.ofs, accL[g][vv] + accR[g][vv], a.oc, ch, k0 + vv);
                 }
             }
         }
     }
+    tri = 15;
+    HIPSOXR_STAMP();
+#undef HIPSOXR_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -734,7 +795,7 @@ struct TileGeom {
 static inline int32_t floor16(int32_t v) { return v >= 0 ? (v / 16) * 16 : -(((-v) + 15) / 16) * 16; }
 
 // Geometry + coefficient table of k_tile_mfma_p (f32 engine, Mc % 16 == 0).
-// Table: [n_rt][2][n_groups + 1][64 lanes][4 chunks]; lane (row j = l & 15, k = l >> 4), chunk c:
+// Table: [n_rt][2][n_groups + 4][64 lanes][4 chunks]; lane (row j = l & 15, k = l >> 4), chunk c:
 //   left : C'[row][i0L + 16*grp + 4*c + k]        right: C'[row][i1R - (16*grp + 4*c + k)]
 static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
 {
@@ -772,9 +833,9 @@ static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
     g.rowR = Mc / 4;
     while ((g.rowR % 8) != 4) ++g.rowR; // R/4 odd -> conflict-free ds_read_b128 across the 16 periods
     g.pad = g.rowR - Mc / 4;
-    const int32_t rows_total = (g.x_count + Mc - 1) / Mc + 1;
+    const int32_t rows_total = (g.x_count + Mc - 1) / Mc + 3; // + slack rows: pipelined reads overrun by one group
     g.plane = (rows_total * g.rowR + 63) / 64 * 64;
-    g.lds_bytes = (size_t)g.plane * 4 * sizeof(float);
+    g.lds_bytes = ((size_t)g.plane * 4 + g.rowR) * sizeof(float);
     g.e0.resize((size_t)g.n_rt * 2);
     for (int rt = 0; rt < g.n_rt; ++rt) {
         g.e0[rt * 2 + 0] = i0L[rt] - i_min;
@@ -784,7 +845,7 @@ static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
     g.ok = true;
     if (tab) {
         const int ng = I_h / 16;
-        tab->assign((size_t)g.n_rt * 2 * (ng + 1) * 256, 0.f);
+        tab->assign((size_t)g.n_rt * 2 * (ng + 4) * 256, 0.f);
         for (int rt = 0; rt < g.n_rt; ++rt)
             for (int rr = 0; rr < 16; ++rr) {
                 int64_t r = (int64_t)rt * 16 + rr;
@@ -795,9 +856,9 @@ static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
                     const int grp = ii / 16, cc = (ii % 16) / 4, k = ii % 4, lane = k * 16 + rr;
                     const size_t at = ((size_t)grp * 64 + lane) * 4 + cc;
                     int32_t jl = i0L[rt] + ii - nr;
-                    if (jl >= 0 && jl < H) (*tab)[(size_t)(rt * 2 + 0) * (ng + 1) * 256 + at] = (float)cp[jl];
+                    if (jl >= 0 && jl < H) (*tab)[(size_t)(rt * 2 + 0) * (ng + 4) * 256 + at] = (float)cp[jl];
                     int32_t jr = i1R[rt] - ii - nr;
-                    if (jr >= H && jr < T) (*tab)[(size_t)(rt * 2 + 1) * (ng + 1) * 256 + at] = (float)cp[jr];
+                    if (jr >= H && jr < T) (*tab)[(size_t)(rt * 2 + 1) * (ng + 4) * 256 + at] = (float)cp[jr];
                 }
             }
     }
@@ -1052,6 +1113,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         }
         nw = best;
     }
+    if (g.variant == 2) nw = 4; // k_tile_mfma_p: one wave per SIMD, 2*n_rt units dealt round-robin
     if (const char *dn = getenv("HIPSOXR_DEBUG_NRT")) { a.n_rt = atoi(dn); nw = a.n_rt; }
     if (const char *dw = getenv("HIPSOXR_DEBUG_NW")) nw = atoi(dw);
     a.n_waves = nw;
@@ -1059,19 +1121,44 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         static const char *df = getenv("HIPSOXR_DEBUG_FLAGS");
         a.dbg = df ? atoi(df) : 0;
     }
-    dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
-    // (HIPSOXR_DEBUG_* are timing experiments only; results are wrong when they are set)
+    // (HIPSOXR_DEBUG_* are timing experiments only; results may be wrong when they are set)
     void (*kern)(TileArgs) = g.aligned ? k_tile<IO, Real, 16, true> : k_tile<IO, Real, 16, false>;
     if constexpr (sizeof(Real) == 4) {
         if (g.variant == 1) kern = k_tile_mfma<IO>;
         if (g.variant == 2) kern = k_tile_mfma_p<IO>;
     }
     a.rowR = g.rowR; a.plane = g.plane;
-    if (g.lds_bytes > 64 * 1024)
+    dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
+    if (g.variant == 2) {
+        // few slabs (e.g. one 60 s mono clip = 282): spread each slab's 2*n_rt units over up to
+        // ceil(2*n_rt/4) workgroups so that every CU gets an equal share (3 resident per CU)
+        const int64_t wgs = n_blocks * (int64_t)cols;
+        int split = (int)std::min<int64_t>((2 * g.n_rt + 3) / 4, (2 * 3 * 256) / std::max<int64_t>(wgs, 1));
+        if (const char *e = getenv("HIPSOXR_DEBUG_SPLIT")) split = atoi(e);
+        grid.z = (unsigned)std::max(1, split);
+    }
+    size_t lds_bytes = g.lds_bytes;
+    if (const char *e = getenv("HIPSOXR_DEBUG_LDS")) lds_bytes = std::max<size_t>(lds_bytes, (size_t)atoi(e)); // occupancy experiments
+    if (lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)g.lds_bytes));
-    hipLaunchKernelGGL(kern, grid, block, g.lds_bytes, st, a);
+                                    (int)lds_bytes));
+    a.trace = nullptr;
+    const char *trace_path = getenv("HIPSOXR_DEBUG_TRACE");
+    size_t trace_n = 0;
+    if (trace_path && g.variant == 2) {
+        trace_n = (size_t)grid.x * cols * grid.z * 4 * 16;
+        HIP_TRY(hipMalloc((void **)&a.trace, trace_n * 8));
+        HIP_TRY(hipMemset(a.trace, 0, trace_n * 8));
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, a);
     HIP_TRY(hipGetLastError());
+    if (a.trace) { // debugging aid only: synchronous dump of the per-wave time stamps
+        std::vector<unsigned long long> h(trace_n);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h.data(), a.trace, trace_n * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
+        (void)hipFree(a.trace);
+    }
     return nullptr;
 }
 

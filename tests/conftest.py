@@ -29,6 +29,24 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+def _init_torch_first():
+    """On a GPU box, bring up torch's HIP context BEFORE libhipsoxr touches the device.  Observed on
+    MI355X/ROCm 7.2: when torch's lazy CUDA init runs after another user of the same HIP runtime
+    has already created streams and launched kernels, the first `.cuda()` occasionally stalls for
+    minutes.  bench.py and smoke() initialise torch first as a matter of course; tests do it here."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda").cpu()
+    except Exception:
+        pass
+
+
+def pytest_sessionstart(session):
+    _init_torch_first()
+
+
 def pytest_report_header(config):
     # the reference prints versions and engine ids in the header (tests/conftest.py:5-16)
     try:

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,7 +62,7 @@ template <int MODE> int run(const char *name, int waves_per_simd, double flop_pe
     float *out, *in;
     CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     CHECK(hipMalloc(&in, 1024));
-    std::vector<float> h(256, 1e-3f);
+    std::vector<float> h(256); for (int i = 0; i < 256; ++i) h[i] = getenv("UB_RANDOM") ? (float)((i * 2654435761u) >> 8) / 16777216.f - 0.5f : 1e-3f;
     CHECK(hipMemcpy(in, h.data(), 1024, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
