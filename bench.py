@@ -33,8 +33,11 @@ for p in (ROOT, os.path.join(ROOT, "python-soxr_amd")):
         sys.path.insert(0, p)
 
 IN_RATE, OUT_RATE, QUALITY = 48000, 44100, "VHQ"
-KERNEL_NAMES = {0: "auto (k_tile_mfma<float> for this workload)", 1: "k_gather<float,float>",
-                2: "k_tile_mfma<float>", 3: "k_tile<float,float,16,true>", 4: "k_tile_mfma<float>"}
+KERNEL_NAMES = {0: "k_tile_mfma_p<float> (auto)", 1: "k_gather<float,float>", 2: "k_tile_mfma_p<float>",
+                3: "k_tile<float,float,16,true>", 4: "k_tile_mfma_p<float>"}
+# HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 +
+# WRITE_SIZE, see profiles/r01b_traffic.json); bench.py cannot collect counters itself.
+TRAFFIC_BYTES = {"configs1": 74978304, "batch_shard": 536548557}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
@@ -167,7 +170,8 @@ def main():
                    "taps_per_phase": plan.taps, "phases": plan.L, "frames_in": n_in, "frames_out": n_out,
                    "parallelism": f"independent clips per rank x{world}; RCCL bank broadcast at plan time"},
         "roofline": {"bound": "hbm", "achieved": algo_bytes / kern / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": algo_bytes / kern / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": algo_bytes / kern / 1e9 / HBM_PEAK_GBS,
+                     "traffic": TRAFFIC_BYTES["configs1"] if (args.kernel in (0, 2, 4) and args.seconds == 60) else None,
                      "kernel": KERNEL_NAMES.get(args.kernel, "auto"), "launch_us": kern * 1e6,
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "valu_tflops": flops / kern / 1e12,
@@ -191,7 +195,8 @@ def main():
             "value": world * b_in * bsteps / bwall / 1e6, "unit": "Msamples/s", "steps": bsteps,
             "ms_per_step": bwall / bsteps * 1e3,
             "roofline": {"bound": "hbm", "achieved": bbytes / bkern / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": bbytes / bkern / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": bbytes / bkern / 1e9 / HBM_PEAK_GBS,
+                         "traffic": TRAFFIC_BYTES["batch_shard"] if (args.kernel in (0, 2, 4) and clips == 128) else None,
                          "launch_us": bkern * 1e6, "valu_tflops": bflops / bkern / 1e12,
                          "valu_frac": bflops / bkern / 1e12 / VALU_PEAK_TFLOPS}}
         del xb, yb

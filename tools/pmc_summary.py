@@ -15,6 +15,15 @@ def main(paths):
                 print("  %-60s calls %5d  avg %12.1f us  %5.1f%%" % (r[0][:60], r[1], r[3], r[4]))
         except sqlite3.Error as e:
             print("  (no top_kernels: %s)" % e)
+        try:  # per (kernel, grid) launch durations: bench.py times two workloads with the same kernel
+            q = ("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), avg(end-start), min(end-start), "
+                 "max(end-start) from kernels group by name, grid_x, grid_y, grid_z")
+            for r in c.execute(q):
+                if "hipsoxr" in r[0]:
+                    print("  per-grid: %-44s grid (%d,%d,%d) block %d  n=%d  avg %.2f us  min %.2f  max %.2f" % (
+                        r[0][:44], r[1], r[2], r[3], r[4], r[5], r[6] / 1e3, r[7] / 1e3, r[8] / 1e3))
+        except sqlite3.Error:
+            pass
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         try:
             for r in c.execute("select kernel_name, counter_name, value, grid_size, workgroup_size from counters_collection"):
