@@ -76,11 +76,14 @@ typedef enum { HIPSOXR_F32 = 0, HIPSOXR_F64 = 1, HIPSOXR_I32 = 2, HIPSOXR_I16 = 
 
 /* Kernel selector for hipsoxr_run_device. */
 typedef enum {
-    HIPSOXR_KERNEL_AUTO = 0,
+    HIPSOXR_KERNEL_AUTO = 0,   /* fastest admissible engine, including the FFT engine for large float32 jobs */
     HIPSOXR_KERNEL_GATHER = 1, /* one lane per output sample, operands gathered through L1/L2 */
     HIPSOXR_KERNEL_TILE = 2,   /* period-tiled, best variant for the engine (MFMA f32, else VALU) */
     HIPSOXR_KERNEL_TILE_VALU = 3, /* period-tiled: input slab in LDS, coefficients on the scalar path */
-    HIPSOXR_KERNEL_TILE_MFMA = 4  /* period-tiled on the f32-input matrix pipe (f32 engine only) */
+    HIPSOXR_KERNEL_TILE_MFMA = 4, /* period-tiled on the f32-input matrix pipe (f32 engine only) */
+    HIPSOXR_KERNEL_FFT = 5,    /* frequency-domain overlap-save engine (whole-signal float32 jobs; 1e-6-class,
+                                  not bit-identical to the canonical order) */
+    HIPSOXR_KERNEL_EXACT = 6   /* AUTO restricted to the canonical-order kernels (bit-exact invariances) */
 } hipsoxr_kernel_t;
 
 typedef struct hipsoxr_plan hipsoxr_plan_t;     /* immutable: ratio + polyphase bank (host + device) */

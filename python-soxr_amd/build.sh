@@ -7,5 +7,5 @@ OUT="$HERE/soxr_amd/libhipsoxr.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -ffp-contract=off -Wall -Wno-unused-function"
 "$HIPCC" $FLAGS ${HIPSOXR_EXTRA_FLAGS} -I"$HERE/../include" \
-    "$SRC/plan.cpp" "$SRC/engine.cpp" "$SRC/kernels.hip" -o "$OUT"
+    "$SRC/plan.cpp" "$SRC/engine.cpp" "$SRC/kernels.hip" "$SRC/fft.hip" -o "$OUT"
 echo "built $OUT"

@@ -21,4 +21,9 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream);
 
 int device_count();
 
+// frequency-domain engine (fft.hip): whole-signal float32 jobs
+bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &job);
+const char *launch_fft(Plan *p, const hipsoxr_job_t &job, void *stream, bool *handled);
+void fft_release(const Plan *p);
+
 } // namespace hipsoxr

@@ -21,7 +21,7 @@ struct hipsoxr_plan {
 };
 
 namespace hipsoxr {
-Plan::~Plan() { device_bank_release(this); }
+Plan::~Plan() { device_bank_release(this); fft_release(this); }
 } // namespace hipsoxr
 
 struct hipsoxr_stream {
@@ -104,6 +104,7 @@ hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *h, const double *src, size
     if (!h || !src) return "null argument";
     if (n != h->p.bank.size()) return "bank size mismatch";
     device_bank_release(&h->p);
+    fft_release(&h->p);
     std::memcpy(h->p.bank.data(), src, n * sizeof(double));
     return nullptr;
 }
@@ -225,7 +226,7 @@ static const char *stream_emit(hipsoxr_stream *s, void *out, size_t olen, size_t
     }
     hipsoxr_job_t j;
     std::memset(&j, 0, sizeof j);
-    j.in = s->d_in; j.out = s->d_out; j.elem = s->elem; j.kernel = HIPSOXR_KERNEL_AUTO;
+    j.in = s->d_in; j.out = s->d_out; j.elem = s->elem; j.kernel = HIPSOXR_KERNEL_EXACT; // bit-exact chunk invariance
     j.n_clips = 1; j.n_channels = s->ch;
     if (!s->split) {
         j.in_frame_stride = s->ch; j.in_chan_stride = 1;

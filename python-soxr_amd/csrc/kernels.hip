@@ -1173,6 +1173,7 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
         if (TileGeom *gp = geom_find(p, prec, 1)) gm = *gp;
     }
     int kernel = j.kernel;
+    if (kernel == HIPSOXR_KERNEL_EXACT || kernel == HIPSOXR_KERNEL_FFT) kernel = HIPSOXR_KERNEL_AUTO;
     if (kernel == HIPSOXR_KERNEL_TILE_VALU && !gv.ok) return "tile kernel unavailable for this plan";
     if (kernel == HIPSOXR_KERNEL_TILE_MFMA && !gm.ok) return "tile kernel unavailable for this plan";
     if (kernel == HIPSOXR_KERNEL_TILE) {
@@ -1195,6 +1196,22 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream)
     if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return nullptr;
     const int prec = engine_prec(j.elem);
     if (const char *e = device_bank_ensure(p, prec)) return e;
+    // Frequency-domain engine: explicit request, or AUTO for large whole-signal float32 jobs.
+    // It is NOT bit-identical to the canonical order (1.4e-7 relative RMS), so it is never chosen
+    // for HIPSOXR_KERNEL_EXACT — which is what the stream / one-shot host entry points pass.
+    if (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO) {
+        static const bool no_fft = getenv("HIPSOXR_NO_FFT") != nullptr;
+        const bool eligible = fft_job_eligible(*p, j);
+        const bool big = (int64_t)j.out_frames * j.n_clips * j.n_channels >= (1 << 18);
+        if (j.kernel == HIPSOXR_KERNEL_FFT && !eligible)
+            return "FFT engine needs a whole-signal float32 job (in_abs0 == 0, out_k0 == 0)";
+        if (eligible && (j.kernel == HIPSOXR_KERNEL_FFT || (big && !no_fft))) {
+            bool handled = false;
+            if (const char *e = launch_fft(p, j, stream, &handled)) return e;
+            if (handled) return nullptr;
+            if (j.kernel == HIPSOXR_KERNEL_FFT) return "FFT engine unavailable for this plan";
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (j.elem) {
     case HIPSOXR_F32: return launch_typed<float, float>(p, j, st);
