@@ -33,11 +33,13 @@ for p in (ROOT, os.path.join(ROOT, "python-soxr_amd")):
         sys.path.insert(0, p)
 
 IN_RATE, OUT_RATE, QUALITY = 48000, 44100, "VHQ"
-KERNEL_NAMES = {0: "k_tile_mfma_p<float> (auto)", 1: "k_gather<float,float>", 2: "k_tile_mfma_p<float>",
-                3: "k_tile<float,float,16,true>", 4: "k_tile_mfma_p<float>"}
+KERNEL_NAMES = {0: "k_fft_block (AUTO: frequency-domain engine for large float32 device jobs)",
+                1: "k_gather<float,float>", 2: "k_tile_mfma_p<float>", 3: "k_tile<float,float,16,true>",
+                4: "k_tile_mfma_p<float>", 5: "k_fft_block", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
 # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 +
 # WRITE_SIZE, see profiles/r01b_traffic.json); bench.py cannot collect counters itself.
-TRAFFIC_BYTES = {"configs1": 74978304, "batch_shard": 536548557}
+TRAFFIC_BYTES = {("configs1", 0): 24267674, ("configs1", 5): 24267674,
+                 ("batch_shard", 0): 489458074, ("batch_shard", 5): 489458074}  # profiles/r01c_traffic.json
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
@@ -171,11 +173,10 @@ def main():
                    "parallelism": f"independent clips per rank x{world}; RCCL bank broadcast at plan time"},
         "roofline": {"bound": "hbm", "achieved": algo_bytes / kern / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo_bytes / kern / 1e9 / HBM_PEAK_GBS,
-                     "traffic": TRAFFIC_BYTES["configs1"] if (args.kernel in (0, 2, 4) and args.seconds == 60) else None,
+                     "traffic": TRAFFIC_BYTES.get(("configs1", args.kernel)) if args.seconds == 60 else None,
                      "kernel": KERNEL_NAMES.get(args.kernel, "auto"), "launch_us": kern * 1e6,
                      "algorithmic_bytes_per_launch": algo_bytes,
-                     "valu_tflops": flops / kern / 1e12,
-                     "valu_frac": flops / kern / 1e12 / VALU_PEAK_TFLOPS},
+                     "direct_form_equiv_tflops": flops / kern / 1e12},
     }
 
     # ---- configs[3] shard: 1024 x 10 s clips over 8 GPUs -> 128 clips per GPU ----------------
@@ -196,10 +197,17 @@ def main():
             "ms_per_step": bwall / bsteps * 1e3,
             "roofline": {"bound": "hbm", "achieved": bbytes / bkern / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bbytes / bkern / 1e9 / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES["batch_shard"] if (args.kernel in (0, 2, 4) and clips == 128) else None,
-                         "launch_us": bkern * 1e6, "valu_tflops": bflops / bkern / 1e12,
-                         "valu_frac": bflops / bkern / 1e12 / VALU_PEAK_TFLOPS}}
+                         "traffic": TRAFFIC_BYTES.get(("batch_shard", args.kernel)) if clips == 128 else None,
+                         "launch_us": bkern * 1e6, "direct_form_equiv_tflops": bflops / bkern / 1e12}}
         del xb, yb
+
+    # the canonical-order (bit-exact) engine on the same workloads, for reference
+    if args.kernel == 0 and world == 1:
+        ew, ek, _ = time_workload(plan, x, max(10, args.steps // 4), 5, world, device, kernel=6)
+        result["exact_engine"] = {"kernel": KERNEL_NAMES[6], "launch_us": ek * 1e6,
+                                  "value": n_in / ek / 1e6, "unit": "Msamples/s",
+                                  "hbm_frac": algo_bytes / ek / 1e9 / HBM_PEAK_GBS,
+                                  "mfma_tflops": flops / ek / 1e12, "mfma_frac": flops / ek / 1e12 / VALU_PEAK_TFLOPS}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args.seconds)

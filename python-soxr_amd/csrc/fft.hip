@@ -192,8 +192,11 @@ __device__ __forceinline__ void fft_pass(cf *buf, int N, int Ns, const cf *W)
 }
 
 // Compile-time specialised pass (N, Ns, R constants): no divisions, fully unrolled.
-template <int N, int Ns, int R, int SIGN, int NT>
-__device__ __forceinline__ void fft_pass_ct(cf *buf, const cf *W)
+// `load(n)` supplies element n of the pass input (LDS, or global memory for the first pass) and
+// `store(n, v)` consumes element n of the pass output (LDS, or the output signal for the last
+// pass), so the first/last passes stream straight from/to HBM without an extra LDS round trip.
+template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, typename Load, typename Store>
+__device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store)
 {
     constexpr int nb = N / R, wstep = N / (Ns * R), NB = (nb + NT - 1) / NT;
     cf u[NB][R];
@@ -203,9 +206,9 @@ __device__ __forceinline__ void fft_pass_ct(cf *buf, const cf *W)
         if (NB * NT == nb || j < nb) {
             const int k = j % Ns;
             cf w1 = make_float2(1.f, 0.f);
-            if (Ns > 1) w1 = W[k * wstep]; // issued before the LDS reads: the two latencies overlap
+            if (Ns > 1) w1 = W[k * wstep]; // issued before the data reads: the latencies overlap
 #pragma unroll
-            for (int t = 0; t < R; ++t) u[i][t] = buf[j + t * nb];
+            for (int t = 0; t < R; ++t) u[i][t] = load(j + t * nb);
             if (Ns > 1) {
                 cf w = w1;
 #pragma unroll
@@ -217,26 +220,33 @@ __device__ __forceinline__ void fft_pass_ct(cf *buf, const cf *W)
             dft_r<R, SIGN>(u[i]);
         }
     }
-    __syncthreads();
+    if (SYNC_BEFORE_STORE) __syncthreads(); // in-place: every input of the pass is in registers
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int j = threadIdx.x + i * NT;
         if (NB * NT == nb || j < nb) {
-            const int k = j % Ns;
-            cf *o = buf + (j - k) * R + k;
+            const int k = j % Ns, o = (j - k) * R + k;
 #pragma unroll
-            for (int t = 0; t < R; ++t) o[t * Ns] = u[i][t];
+            for (int t = 0; t < R; ++t) store(o + t * Ns, u[i][t]);
         }
     }
-    __syncthreads();
 }
-template <int N, int SIGN, int NT, int R0, int R1, int R2, int R3>
-__device__ __forceinline__ void fft_ct(cf *buf, const cf *W)
+// Four-pass transform: first pass input from `first_load`, last pass output to `last_store`,
+// everything in between in place in `buf`.
+template <int N, int SIGN, int NT, int R0, int R1, int R2, int R3, typename Load, typename Store>
+__device__ __forceinline__ void fft_ct(cf *buf, const cf *W, Load first_load, Store last_store, bool first_in_lds)
 {
-    fft_pass_ct<N, 1, R0, SIGN, NT>(buf, W);
-    fft_pass_ct<N, R0, R1, SIGN, NT>(buf, W);
-    fft_pass_ct<N, R0 * R1, R2, SIGN, NT>(buf, W);
-    if constexpr (R3 > 1) fft_pass_ct<N, R0 * R1 * R2, R3, SIGN, NT>(buf, W);
+    auto lds_load = [&](int n) -> cf { return buf[n]; };
+    auto lds_store = [&](int n, cf v) { buf[n] = v; };
+    // pass 0 (Ns = 1): when its input is not in LDS nothing has to be protected before storing
+    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, lds_store);
+    else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, lds_store);
+    __syncthreads();
+    fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, lds_load, lds_store);
+    __syncthreads();
+    fft_pass_ct<N, R0 * R1, R2, SIGN, NT, true>(W, lds_load, lds_store);
+    __syncthreads();
+    fft_pass_ct<N, R0 * R1 * R2, R3, SIGN, NT, false>(W, lds_load, last_store);
 }
 
 struct FftArgs {
@@ -276,18 +286,31 @@ __device__ __forceinline__ void run_passes(cf *buf, int N, int n_pass, const int
     }
 }
 
-struct SpecRuntime { static constexpr bool ct = false; static constexpr int NT = 256; };
+struct SpecRuntime { static constexpr bool ct = false; static constexpr int NT = 256, A = 0, B = 4096; };
 // 48k -> 44.1k family (L = 147, M = 160, k = 32): N_in/2 = 2560 = 5*8*8*8, N_out/2 = 2352 = 3*7*7*16
 struct Spec2560x2352 {
     static constexpr bool ct = true;
     static constexpr int A = 2560, B = 2352;
     static constexpr int NT = 256;
-    template <int NT> static __device__ __forceinline__ void fwd(cf *b, const cf *W) { fft_ct<2560, -1, NT, 5, 8, 8, 8>(b, W); }
-    template <int NT> static __device__ __forceinline__ void inv(cf *b, const cf *W) { fft_ct<2352, +1, NT, 3, 7, 7, 16>(b, W); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    { fft_ct<2560, -1, NT, 5, 8, 8, 8>(b, W, ld, st, in_lds); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    { fft_ct<2352, +1, NT, 3, 7, 7, 16>(b, W, ld, st, in_lds); }
+};
+
+// same family, half-size blocks (k = 16) for small jobs: N_in/2 = 1280 = 5*8*8*4, N_out/2 = 1176 = 3*7*7*8
+struct Spec1280x1176 {
+    static constexpr bool ct = true;
+    static constexpr int A = 1280, B = 1176;
+    static constexpr int NT = 256;
+    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    { fft_ct<1280, -1, NT, 5, 8, 8, 4>(b, W, ld, st, in_lds); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    { fft_ct<1176, +1, NT, 3, 7, 7, 8>(b, W, ld, st, in_lds); }
 };
 
 template <typename Spec>
-__global__ void __launch_bounds__(256, 5) k_fft_block(FftArgs a)
+__global__ void __launch_bounds__(256, Spec::ct ? 5 : 2) k_fft_block(FftArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int32_t A = a.A, B = a.B;
@@ -300,27 +323,29 @@ __global__ void __launch_bounds__(256, 5) k_fft_block(FftArgs a)
     const int64_t in0 = p0 * a.M, out0 = p0 * a.L;          // absolute indices of local sample 0
     const float *xin = (const float *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
 
-    // ---- load: z[n] = x[2n] + i x[2n+1], zero outside the signal
-    {
-        const bool fast = a.ifs == 1 && in0 >= 0 && in0 + 2 * (int64_t)A <= a.in_frames &&
-                          (((reinterpret_cast<uintptr_t>(xin) >> 2) + (uint64_t)in0) & 1) == 0;
-        if (fast) {
+    // ---- load: z[n] = x[2n] + i x[2n+1], zero outside the signal; forward complex FFT of length A.
+    //      Interior blocks of the specialised kernel stream the first pass straight from HBM.
+    const bool fast = a.ifs == 1 && in0 >= 0 && in0 + 2 * (int64_t)A <= a.in_frames &&
+                      (((reinterpret_cast<uintptr_t>(xin) >> 2) + (uint64_t)in0) & 1) == 0;
+    auto lds_load = [&](int n) -> cf { return cur[n]; };
+    auto lds_store = [&](int n, cf v) { cur[n] = v; };
+    if (Spec::ct && fast) {
+        if constexpr (Spec::ct) {
             const float2 *src = reinterpret_cast<const float2 *>(xin + in0);
-            for (int n = threadIdx.x; n < A; n += blockDim.x) cur[n] = src[n];
-        } else {
-            for (int n = threadIdx.x; n < A; n += blockDim.x) {
-                const int64_t l = in0 + 2 * (int64_t)n;
-                float re = (l >= 0 && l < a.in_frames) ? xin[l * a.ifs] : 0.f;
-                float im = (l + 1 >= 0 && l + 1 < a.in_frames) ? xin[(l + 1) * a.ifs] : 0.f;
-                cur[n] = make_float2(re, im);
-            }
+            Spec::fwd(cur, a.WA, [&](int n) -> cf { return src[n]; }, lds_store, false);
         }
+    } else {
+        for (int n = threadIdx.x; n < A; n += blockDim.x) {
+            const int64_t l = in0 + 2 * (int64_t)n;
+            float re = (l >= 0 && l < a.in_frames) ? xin[l * a.ifs] : 0.f;
+            float im = (l + 1 >= 0 && l + 1 < a.in_frames) ? xin[(l + 1) * a.ifs] : 0.f;
+            cur[n] = make_float2(re, im);
+        }
+        __syncthreads();
+        if constexpr (Spec::ct) Spec::fwd(cur, a.WA, lds_load, lds_store, true);
+        else run_passes<-1>(cur, A, a.nA, a.radA, a.WA);
     }
     __syncthreads();
-
-    // ---- forward complex FFT of length A
-    if constexpr (Spec::ct) Spec::template fwd<Spec::NT>(cur, a.WA);
-    else run_passes<-1>(cur, A, a.nA, a.radA, a.WA);
 
     // ---- untangle the real FFT, apply the filter, tangle for the inverse real FFT — in registers:
     //      X[q] = (Z[q] + conj Z[A-q])/2 - i/2 P[q] (Z[q] - conj Z[A-q]),   P[q] = exp(-2 pi i q / N_in)
@@ -336,7 +361,7 @@ __global__ void __launch_bounds__(256, 5) k_fft_block(FftArgs a)
             const cf x = make_float2(0.5f * (s.x + d.y), 0.5f * (s.y - d.x));
             return cmul(x, a.Hs[q]);
         };
-        constexpr int NP = 10; // pairs per thread: B/2+1 <= 256*NP
+        constexpr int NP = (Spec::B / 2 + 1 + Spec::NT - 1) / Spec::NT; // pairs per thread: B/2 + 1 <= 256 * NP (spec: 1177; generic: B <= 4096)
         cf wq[NP], wr[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -364,21 +389,22 @@ __global__ void __launch_bounds__(256, 5) k_fft_block(FftArgs a)
     }
     __syncthreads();
 
-    // ---- inverse complex FFT of length B (unnormalised; the scale lives in Hs)
-    if constexpr (Spec::ct) Spec::template inv<Spec::NT>(cur, a.WB);
-    else run_passes<+1>(cur, B, a.nB, a.radB, a.WB);
-
-    // ---- store the kept outputs: local index i = 2n (+1) in [v0, v0 + hop_out)
-    {
-        float *yo = (float *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
-        const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out;
-        for (int n = threadIdx.x; n < B; n += blockDim.x) {
-            const cf w = cur[n];
-            const int32_t i0 = 2 * n;
-            const int64_t k0 = out0 + i0;
-            if (i0 >= v0 && i0 < v1 && k0 >= 0 && k0 < a.out_frames) yo[k0 * a.ofs] = w.x;
-            if (i0 + 1 >= v0 && i0 + 1 < v1 && k0 + 1 >= 0 && k0 + 1 < a.out_frames) yo[(k0 + 1) * a.ofs] = w.y;
-        }
+    // ---- inverse complex FFT of length B (unnormalised; the scale lives in Hs) and store of the
+    //      kept outputs: element n of the result holds local outputs 2n (re) and 2n+1 (im); the
+    //      specialised kernel writes them from the last pass's registers.
+    float *yo = (float *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+    const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out;
+    auto out_store = [&](int n, cf w) {
+        const int32_t i0 = 2 * n;
+        const int64_t k0 = out0 + i0;
+        if (i0 >= v0 && i0 < v1 && k0 >= 0 && k0 < a.out_frames) yo[k0 * a.ofs] = w.x;
+        if (i0 + 1 >= v0 && i0 + 1 < v1 && k0 + 1 >= 0 && k0 + 1 < a.out_frames) yo[(k0 + 1) * a.ofs] = w.y;
+    };
+    if constexpr (Spec::ct) {
+        Spec::inv(cur, a.WB, lds_load, out_store, true);
+    } else {
+        run_passes<+1>(cur, B, a.nB, a.radB, a.WB);
+        for (int n = threadIdx.x; n < B; n += blockDim.x) out_store(n, cur[n]);
     }
 }
 
@@ -413,19 +439,19 @@ static bool factor_radices(int n, std::vector<int> &rad)
 }
 
 static std::mutex g_fft_mu;
-static std::vector<std::pair<const Plan *, FftGeom>> g_fft;
+static std::vector<std::pair<std::pair<const Plan *, bool>, FftGeom>> g_fft; // key: (plan, small-block variant)
 
 void fft_release(const Plan *p)
 {
     std::lock_guard<std::mutex> lk(g_fft_mu);
     for (size_t i = 0; i < g_fft.size();)
-        if (g_fft[i].first == p) {
+        if (g_fft[i].first.first == p) {
             if (g_fft[i].second.dev) (void)hipFree(g_fft[i].second.dev);
             g_fft.erase(g_fft.begin() + i);
         } else ++i;
 }
 
-static const char *fft_build(const Plan &p, FftGeom *out)
+static const char *fft_build(const Plan &p, FftGeom *out, bool small)
 {
     FftGeom g;
     const int64_t L = p.L, M = p.M;
@@ -440,10 +466,10 @@ static const char *fft_build(const Plan &p, FftGeom *out)
         const int64_t Nin = M * k, Nout = L * k;
         if (Nin % 2 || Nout % 2) continue;
         if (Nin < 6 * (int64_t)T) continue;
-        if (Nin / 2 > 4096 || Nout / 2 > 4096 || Nout / 4 + 1 > 2560) break;
+        if (Nin / 2 > 4096 || Nout / 2 > 4096) break;
         std::vector<int> ra, rb;
         if (!factor_radices((int)(Nin / 2), ra) || !factor_radices((int)(Nout / 2), rb)) continue;
-        if (g.k && std::max(Nin, Nout) / 2 > 2600) break;
+        if (g.k && (small || std::max(Nin, Nout) / 2 > 2600)) break;
         g.k = k; g.N_in = (int32_t)Nin; g.N_out = (int32_t)Nout; g.A = g.N_in / 2; g.B = g.N_out / 2;
         g.radA = ra; g.radB = rb;
     }
@@ -506,15 +532,24 @@ bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &j)
 const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *handled)
 {
     *handled = false;
-    FftGeom g;
-    {
+    auto get = [&](bool small, FftGeom *g) -> const char * {
         std::lock_guard<std::mutex> lk(g_fft_mu);
-        bool found = false;
         for (auto &e : g_fft)
-            if (e.first == p) { g = e.second; found = true; }
-        if (!found) {
-            if (const char *err = fft_build(*p, &g)) return err;
-            g_fft.push_back({p, g});
+            if (e.first.first == p && e.first.second == small) { *g = e.second; return nullptr; }
+        if (const char *err = fft_build(*p, g, small)) return err;
+        g_fft.push_back({{p, small}, *g});
+        return nullptr;
+    };
+    FftGeom g;
+    if (const char *err = get(false, &g)) return err;
+    if (g.ok) {
+        // few blocks (e.g. one 60 s clip = 600): half-size blocks give twice as many workgroups of
+        // half the latency, at the price of more overlap
+        const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out) * (int64_t)j.n_clips * j.n_channels;
+        if (wgs < 8 * 256 && !getenv("HIPSOXR_FFT_LARGE_ONLY")) {
+            FftGeom gs;
+            if (const char *err = get(true, &gs)) return err;
+            if (gs.ok && gs.k < g.k) g = gs;
         }
     }
     if (!g.ok) return nullptr;
@@ -534,8 +569,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";
     if (n_blocks > 2147483647LL) return "job too long for one launch";
     void (*kern)(FftArgs) = k_fft_block<SpecRuntime>;
-    if (g.A == 2560 && g.B == 2352) // compile-time radix schedule for the 147/160 family
-        kern = k_fft_block<Spec2560x2352>;
+    if (g.A == 2560 && g.B == 2352) kern = k_fft_block<Spec2560x2352>; // compile-time radix schedules
+    if (g.A == 1280 && g.B == 1176) kern = k_fft_block<Spec1280x1176>; // for the 147/160 family
     if (g.lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)g.lds_bytes));
