@@ -99,20 +99,22 @@ typedef struct {
     unsigned long recipe;
     int64_t L, M;          /* out/in = L/M in lowest terms: L phases, phase step M              */
     int32_t taps;          /* taps per phase (even, multiple of 8)                               */
-    int32_t interpolated;  /* 0: exact rational bank                                             */
+    int32_t interpolated;  /* 0: exact rational bank [L][taps]; P > 0: interpolated-phase plan
+                              (ratios whose exact bank would exceed 2^22 entries): the bank is the
+                              cubic coefficient table [P][taps][4]                               */
     double precision_bits; /* 0 (QQ), 16, 20, 28                                                 */
     double passband_end;   /* fraction of the lower rate's Nyquist                                */
     double stopband_begin;
     double att_db;         /* design stop-band attenuation                                        */
     double kaiser_beta;
-    uint64_t bank_elems;   /* L * taps                                                            */
+    uint64_t bank_elems;   /* L * taps, or P * taps * 4                                           */
 } hipsoxr_plan_info_t;
 
 HIPSOXR_API hipsoxr_error_t hipsoxr_plan_create(double in_rate, double out_rate,
                                                 unsigned long recipe, hipsoxr_plan_t **out);
 HIPSOXR_API void hipsoxr_plan_delete(hipsoxr_plan_t *);
 HIPSOXR_API hipsoxr_error_t hipsoxr_plan_info(const hipsoxr_plan_t *, hipsoxr_plan_info_t *info);
-/* Copy the float64 bank, phase-major [L][taps], into dst (n = L*taps doubles). */
+/* Copy the float64 bank (phase-major [L][taps], or [P][taps][4]) into dst (n = bank_elems doubles). */
 HIPSOXR_API hipsoxr_error_t hipsoxr_plan_get_bank(const hipsoxr_plan_t *, double *dst, size_t n);
 /* Replace the bank (e.g. with the one RCCL-broadcast from rank 0); device tables are rebuilt. */
 HIPSOXR_API hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *, const double *src, size_t n);

@@ -55,6 +55,14 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, i64, i64, i32, C.c_void_p, i64, i64,
                                          C.c_void_p, i64, i64]
             getattr(L, name).restype = None
+        L.oracle_plan_phases.argtypes = [dbl, dbl, C.c_ulong]
+        L.oracle_plan_phases.restype = i32
+        L.oracle_design_interp.argtypes = [dbl, dbl, C.c_ulong, C.c_void_p]
+        L.oracle_interp_exact_coefs.argtypes = [dbl, dbl, C.c_ulong, dbl, C.c_void_p]
+        for name in ("oracle_interp_ref", "oracle_interp_port_f64", "oracle_interp_port_f32"):
+            getattr(L, name).argtypes = [C.c_void_p, i32, i64, i64, i32, C.c_void_p, i64, i64,
+                                         C.c_void_p, i64, i64]
+            getattr(L, name).restype = None
         L.oracle_dither.argtypes = [u32, u32, i64]
         L.oracle_dither.restype = dbl
         L.oracle_quantize_i16.argtypes = [C.c_void_p, i64, C.c_int, u32, u32, i64, C.c_void_p]
@@ -79,7 +87,8 @@ def quality(recipe):
 
 
 class Plan:
-    """Geometry + float64 bank [L][T] for (in_rate, out_rate, recipe)."""
+    """Geometry + float64 bank for (in_rate, out_rate, recipe): [L][T] for an exact plan
+    (phases == 0), else the interpolated-phase table [P][T][4] (phases == P)."""
 
     def __init__(self, in_rate, out_rate, recipe="HQ"):
         self.in_rate, self.out_rate, self.recipe = float(in_rate), float(out_rate), quality_enum(recipe)
@@ -89,9 +98,24 @@ class Plan:
         if rc:
             raise ValueError(f"oracle_plan failed ({rc})")
         self.L, self.M, self.T, self.att_db, self.beta = L.value, M.value, T.value, att.value, beta.value
-        self.bank = np.empty((self.L, self.T), np.float64)
-        if lib().oracle_design_bank(self.in_rate, self.out_rate, self.recipe, self.bank.ctypes.data):
-            raise ValueError("oracle_design_bank failed")
+        self.phases = int(lib().oracle_plan_phases(self.in_rate, self.out_rate, self.recipe))
+        if self.phases < 0:
+            raise ValueError("oracle_plan_phases failed")
+        if self.phases:
+            self.bank = np.empty((self.phases, self.T, 4), np.float64)
+            if lib().oracle_design_interp(self.in_rate, self.out_rate, self.recipe, self.bank.ctypes.data):
+                raise ValueError("oracle_design_interp failed")
+        else:
+            self.bank = np.empty((self.L, self.T), np.float64)
+            if lib().oracle_design_bank(self.in_rate, self.out_rate, self.recipe, self.bank.ctypes.data):
+                raise ValueError("oracle_design_bank failed")
+
+    def exact_coefs(self, f):
+        """Un-interpolated coefficients c_j(f) of an interpolated-phase plan (accuracy checks)."""
+        c = np.empty(self.T, np.float64)
+        if lib().oracle_interp_exact_coefs(self.in_rate, self.out_rate, self.recipe, float(f), c.ctypes.data):
+            raise ValueError("oracle_interp_exact_coefs failed")
+        return c
 
     def out_len(self, n_in):
         return int(lib().oracle_out_len(int(n_in), self.L, self.M))
@@ -116,18 +140,22 @@ def resample_channel(pl, x, mode, k0=0, n_out=None, in_abs0=0, bank=None):
     if mode == "ref":
         x = np.ascontiguousarray(x, np.float64)
         y = np.empty(n_out, np.float64)
-        fn = lib().oracle_resample_ref
+        fn = lib().oracle_interp_ref if pl.phases else lib().oracle_resample_ref
     elif mode == "port_f64":
         x = np.ascontiguousarray(x, np.float64)
         y = np.empty(n_out, np.float64)
-        fn = lib().oracle_resample_port_f64
+        fn = lib().oracle_interp_port_f64 if pl.phases else lib().oracle_resample_port_f64
     elif mode == "port_f32":
         x = np.ascontiguousarray(x, np.float32)
         y = np.empty(n_out, np.float32)
-        fn = lib().oracle_resample_port_f32
+        fn = lib().oracle_interp_port_f32 if pl.phases else lib().oracle_resample_port_f32
     else:
         raise ValueError(mode)
-    fn(bank.ctypes.data, pl.L, pl.M, pl.T, x.ctypes.data, in_abs0, len(x), y.ctypes.data, k0, n_out)
+    if pl.phases:
+        fn(bank.ctypes.data, pl.phases, pl.L, pl.M, pl.T, x.ctypes.data, in_abs0, len(x), y.ctypes.data,
+           k0, n_out)
+    else:
+        fn(bank.ctypes.data, pl.L, pl.M, pl.T, x.ctypes.data, in_abs0, len(x), y.ctypes.data, k0, n_out)
     return y
 
 

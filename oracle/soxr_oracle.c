@@ -168,6 +168,7 @@ API int oracle_design_bank(double in_rate, double out_rate, unsigned long recipe
     double att, beta, bits, pb, sb;
     if (oracle_plan(in_rate, out_rate, recipe, &L, &M, &T, &att, &beta)) return -1;
     oracle_quality(recipe, &bits, &pb, &sb);
+    if (L * (int64_t)T > ((int64_t)1 << 22)) return -2; /* interpolated-phase plan: oracle_design_interp */
     half = L * (int64_t)T / 2;
     if (bits == 0.) {
         /* 4-point Lagrange cubic kernel k(t), |t| < 2 input samples, stretched by s >= 1;
@@ -294,6 +295,237 @@ API void oracle_resample_port_f32(const double *bank, int64_t L, int64_t M, int3
             int64_t a = n0 + j - in_abs0;
             float xv = (a >= 0 && a < n_in) ? x[a] : 0.f;
             accR = fmaf(c[j], xv, accR);
+        }
+        y[i] = accL + accR;
+    }
+    free(cf);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* interpolated-phase plans: ratios whose exact bank would be too large (L*T > 2^22 entries),    */
+/* e.g. random integer or float rates (/root/reference/tests/test_random.py:21-26).               */
+/* ------------------------------------------------------------------------------------------ */
+/* Same prototype, now as a function of continuous time tau (input samples):
+ *     h(tau) = 2fc sinc(2 fc tau) * I0(beta sqrt(1-(tau/W)^2)) / I0(beta),  |tau| < W = T/2,
+ *     fc = L * (fc of the exact design) cycles per input sample,
+ * normalised to unit DC gain (sum over a 64x over-sampled grid).  Tap j of an output at fractional
+ * position f = ((k*M) mod L)/L uses c_j(f) = h(f + T/2-1-j).  The fraction axis is cut into P
+ * intervals (16 / 32 / 128 for <=16 / 20 / 28 bits, 256 for QQ); on interval i each tap is the cubic
+ * through h at the 4 Chebyshev nodes of the interval, stored as monomial coefficients
+ *     coef[i][j][0..3]:   c_j = a0 + x (a1 + x (a2 + x a3)),   x = f*P - i  in [0,1).
+ * Interpolation error (measured, tests/test_oracle_pinning.py) is >30x below 2^-(bits+1).
+ * x is quantised to 24 (f32 engine) or 32 (f64 engine) bits with integer arithmetic, so that oracle
+ * and GPU derive bit-identical coefficients:
+ *     r = (k*M) mod L;  i = floor(r*P/L);  x = floor(((r*P) mod L) * 2^SH / L) * 2^-SH.        */
+#define EXACT_BANK_MAX_ELEMS ((int64_t)1 << 22)
+#define INTERP_GRID 64
+
+/* 0 for an exact-bank plan, else the number of phase intervals P. */
+API int32_t oracle_plan_phases(double in_rate, double out_rate, unsigned long recipe)
+{
+    int64_t L, M;
+    int32_t T;
+    double att, beta, bits, pb, sb;
+    if (oracle_plan(in_rate, out_rate, recipe, &L, &M, &T, &att, &beta)) return -1;
+    oracle_quality(recipe, &bits, &pb, &sb);
+    if (L * (int64_t)T <= EXACT_BANK_MAX_ELEMS) return 0;
+    return bits == 0. ? 256 : bits <= 16. ? 16 : bits <= 20. ? 32 : 128;
+}
+
+typedef struct {
+    double fc, W, beta, inv_i0, s; /* s: QQ stretch */
+    int qq;
+} proto_t;
+
+static double proto_eval(const proto_t *pr, double tau)
+{
+    if (pr->qq) {
+        double t = fabs(tau) / pr->s;
+        if (t < 1.) return (1. - t * t) * (2. - t) * .5;
+        if (t < 2.) return (1. - t) * (2. - t) * (3. - t) / 6.;
+        return 0.;
+    } else {
+        double u = tau / pr->W, w = 1. - u * u, sv;
+        if (w < 0.) w = 0.;
+        sv = tau == 0. ? 2. * pr->fc : sin(2. * M_PI * pr->fc * tau) / (M_PI * tau);
+        return sv * bessel_i0(pr->beta * sqrt(w)) * pr->inv_i0;
+    }
+}
+
+static int proto_setup(double in_rate, double out_rate, unsigned long recipe, proto_t *pr,
+                       int64_t *L, int64_t *M, int32_t *T, double *scale)
+{
+    double att, beta, bits, pb, sb;
+    if (oracle_plan(in_rate, out_rate, recipe, L, M, T, &att, &beta)) return -1;
+    oracle_quality(recipe, &bits, &pb, &sb);
+    memset(pr, 0, sizeof *pr);
+    pr->qq = bits == 0.;
+    pr->W = .5 * (double)*T;
+    if (pr->qq) {
+        pr->s = *M > *L ? (double)*M / (double)*L : 1.;
+        *scale = 1.;
+    } else {
+        double fn = .5 * (in_rate < out_rate ? in_rate : out_rate), sum = 0.;
+        int64_t half = (int64_t)INTERP_GRID * *T / 2, m;
+        pr->fc = .5 * (pb + sb) * fn / in_rate;
+        pr->beta = beta;
+        pr->inv_i0 = 1. / bessel_i0(beta);
+        for (m = -half; m < half; ++m) sum += proto_eval(pr, (double)m / (double)INTERP_GRID);
+        *scale = (double)INTERP_GRID / sum;
+    }
+    return 0;
+}
+
+/* Exact (un-interpolated) coefficients of fraction f in [0,1): c[j] = h(f + T/2-1-j), j < T. */
+API int oracle_interp_exact_coefs(double in_rate, double out_rate, unsigned long recipe, double f,
+                                  double *c)
+{
+    proto_t pr;
+    int64_t L, M;
+    int32_t T, j;
+    double scale, sum = 0.;
+    if (proto_setup(in_rate, out_rate, recipe, &pr, &L, &M, &T, &scale)) return -1;
+    for (j = 0; j < T; ++j) {
+        c[j] = proto_eval(&pr, f + (double)(T / 2 - 1 - j)) * scale;
+        sum += c[j];
+    }
+    if (pr.qq) for (j = 0; j < T; ++j) c[j] /= sum; /* QQ: every fraction has unit DC gain */
+    return 0;
+}
+
+/* coef[P][T][4] (float64). */
+API int oracle_design_interp(double in_rate, double out_rate, unsigned long recipe, double *coef)
+{
+    proto_t pr;
+    int64_t L, M;
+    int32_t T, P, i, j, c;
+    double scale, xn[4], *v;
+    P = oracle_plan_phases(in_rate, out_rate, recipe);
+    if (P <= 0) return -1;
+    if (proto_setup(in_rate, out_rate, recipe, &pr, &L, &M, &T, &scale)) return -1;
+    for (c = 0; c < 4; ++c) xn[c] = .5 - .5 * cos((double)(2 * c + 1) * M_PI / 8.);
+    v = (double *)malloc((size_t)T * 4 * sizeof(double));
+    for (i = 0; i < P; ++i) {
+        for (c = 0; c < 4; ++c) {
+            double f = ((double)i + xn[c]) / (double)P, sum = 0.;
+            for (j = 0; j < T; ++j) {
+                v[c * T + j] = proto_eval(&pr, f + (double)(T / 2 - 1 - j)) * scale;
+                sum += v[c * T + j];
+            }
+            if (pr.qq) for (j = 0; j < T; ++j) v[c * T + j] /= sum;
+        }
+        for (j = 0; j < T; ++j) {
+            /* Newton divided differences on the nodes, then expansion to monomials */
+            double v0 = v[j], v1 = v[T + j], v2 = v[2 * T + j], v3 = v[3 * T + j];
+            double d01 = (v1 - v0) / (xn[1] - xn[0]), d12 = (v2 - v1) / (xn[2] - xn[1]),
+                   d23 = (v3 - v2) / (xn[3] - xn[2]);
+            double d012 = (d12 - d01) / (xn[2] - xn[0]), d123 = (d23 - d12) / (xn[3] - xn[1]);
+            double d3 = (d123 - d012) / (xn[3] - xn[0]);
+            double *a = coef + ((size_t)i * T + j) * 4;
+            a[3] = d3;
+            a[2] = d012 - d3 * (xn[0] + xn[1] + xn[2]);
+            a[1] = d01 - d012 * (xn[0] + xn[1]) + d3 * (xn[0] * xn[1] + xn[0] * xn[2] + xn[1] * xn[2]);
+            a[0] = v0 - d01 * xn[0] + d012 * (xn[0] * xn[1]) - d3 * (xn[0] * xn[1] * xn[2]);
+        }
+    }
+    free(v);
+    return 0;
+}
+
+/* position of output k: first tap's absolute input index, interval, quantised residual */
+static inline void locate_interp(int64_t k, int64_t L, int64_t M, int32_t T, int32_t P, int sh,
+                                 int64_t *n0, int32_t *iv, uint64_t *xq)
+{
+    __int128 kM = (__int128)k * M;
+    uint64_t r = (uint64_t)(kM % L), t = r * (uint64_t)P, rem;
+    *n0 = (int64_t)(kM / L) - (T / 2 - 1);
+    *iv = (int32_t)(t / (uint64_t)L);
+    rem = t % (uint64_t)L;
+    *xq = (rem << sh) / (uint64_t)L;
+}
+
+API void oracle_interp_ref(const double *coef, int32_t P, int64_t L, int64_t M, int32_t T,
+                           const double *x, int64_t in_abs0, int64_t n_in, double *y, int64_t k0,
+                           int64_t n_out)
+{
+    int64_t i;
+    for (i = 0; i < n_out; ++i) {
+        int64_t n0, j;
+        int32_t iv;
+        uint64_t xq;
+        double acc = 0., xx;
+        const double *a;
+        locate_interp(k0 + i, L, M, T, P, 32, &n0, &iv, &xq);
+        xx = (double)xq * (1. / 4294967296.);
+        a = coef + (size_t)iv * T * 4;
+        for (j = 0; j < T; ++j) {
+            int64_t q = n0 + j - in_abs0;
+            if (q >= 0 && q < n_in)
+                acc += (a[4 * j] + xx * (a[4 * j + 1] + xx * (a[4 * j + 2] + xx * a[4 * j + 3]))) * x[q];
+        }
+        y[i] = acc;
+    }
+}
+
+/* canonical order, f64 engine: coefficient by fma-Horner, then the two half-chains */
+API void oracle_interp_port_f64(const double *coef, int32_t P, int64_t L, int64_t M, int32_t T,
+                                const double *x, int64_t in_abs0, int64_t n_in, double *y, int64_t k0,
+                                int64_t n_out)
+{
+    int64_t i;
+    for (i = 0; i < n_out; ++i) {
+        int64_t n0, j;
+        int32_t iv;
+        uint64_t xq;
+        double accL = 0., accR = 0., xx;
+        const double *a;
+        locate_interp(k0 + i, L, M, T, P, 32, &n0, &iv, &xq);
+        xx = (double)xq * (1. / 4294967296.);
+        a = coef + (size_t)iv * T * 4;
+        for (j = 0; j < T / 2; ++j) {
+            int64_t q = n0 + j - in_abs0;
+            double xv = (q >= 0 && q < n_in) ? x[q] : 0.;
+            double c = fma(fma(fma(a[4 * j + 3], xx, a[4 * j + 2]), xx, a[4 * j + 1]), xx, a[4 * j]);
+            accL = fma(c, xv, accL);
+        }
+        for (j = T - 1; j >= T / 2; --j) {
+            int64_t q = n0 + j - in_abs0;
+            double xv = (q >= 0 && q < n_in) ? x[q] : 0.;
+            double c = fma(fma(fma(a[4 * j + 3], xx, a[4 * j + 2]), xx, a[4 * j + 1]), xx, a[4 * j]);
+            accR = fma(c, xv, accR);
+        }
+        y[i] = accL + accR;
+    }
+}
+
+/* f32 engine: polynomial coefficients rounded to float32, Horner and chains in float32 */
+API void oracle_interp_port_f32(const double *coef, int32_t P, int64_t L, int64_t M, int32_t T,
+                                const float *x, int64_t in_abs0, int64_t n_in, float *y, int64_t k0,
+                                int64_t n_out)
+{
+    int64_t i, n = (int64_t)P * T * 4;
+    float *cf = (float *)malloc((size_t)n * sizeof(float));
+    for (i = 0; i < n; ++i) cf[i] = (float)coef[i];
+    for (i = 0; i < n_out; ++i) {
+        int64_t n0, j;
+        int32_t iv;
+        uint64_t xq;
+        float accL = 0.f, accR = 0.f, xx;
+        const float *a;
+        locate_interp(k0 + i, L, M, T, P, 24, &n0, &iv, &xq);
+        xx = (float)xq * (1.f / 16777216.f);
+        a = cf + (size_t)iv * T * 4;
+        for (j = 0; j < T / 2; ++j) {
+            int64_t q = n0 + j - in_abs0;
+            float xv = (q >= 0 && q < n_in) ? x[q] : 0.f;
+            float c = fmaf(fmaf(fmaf(a[4 * j + 3], xx, a[4 * j + 2]), xx, a[4 * j + 1]), xx, a[4 * j]);
+            accL = fmaf(c, xv, accL);
+        }
+        for (j = T - 1; j >= T / 2; --j) {
+            int64_t q = n0 + j - in_abs0;
+            float xv = (q >= 0 && q < n_in) ? x[q] : 0.f;
+            float c = fmaf(fmaf(fmaf(a[4 * j + 3], xx, a[4 * j + 2]), xx, a[4 * j + 1]), xx, a[4 * j]);
+            accR = fmaf(c, xv, accR);
         }
         y[i] = accL + accR;
     }

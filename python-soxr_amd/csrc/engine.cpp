@@ -84,7 +84,7 @@ hipsoxr_error_t hipsoxr_plan_info(const hipsoxr_plan_t *h, hipsoxr_plan_info_t *
     if (!h || !info) return "null argument";
     const Plan &p = h->p;
     info->in_rate = p.in_rate; info->out_rate = p.out_rate; info->recipe = p.recipe;
-    info->L = p.L; info->M = p.M; info->taps = p.T; info->interpolated = 0;
+    info->L = p.L; info->M = p.M; info->taps = p.T; info->interpolated = p.phases;
     info->precision_bits = p.q.bits; info->passband_end = p.q.passband_end;
     info->stopband_begin = p.q.stopband_begin; info->att_db = p.att_db; info->kaiser_beta = p.beta;
     info->bank_elems = (uint64_t)p.bank.size();

@@ -525,7 +525,7 @@ bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &j)
 {
     // what the method neglects is the aliasing of the filter's stop band: only recipes whose stop band
     // is far below the 1e-6 bar qualify (HQ 128 dB, VHQ 177 dB; MQ/LQ at 104 dB do not)
-    return p.att_db >= 120. && j.elem == HIPSOXR_F32 && j.in_abs0 == 0 && j.out_k0 == 0 &&
+    return p.phases == 0 && p.att_db >= 120. && j.elem == HIPSOXR_F32 && j.in_abs0 == 0 && j.out_k0 == 0 &&
            (uint64_t)j.out_frames <= plan_out_len(p, (uint64_t)j.in_frames);
 }
 

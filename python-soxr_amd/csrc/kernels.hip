@@ -168,6 +168,79 @@ __global__ void __launch_bounds__(256) k_gather(GatherArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_interp — interpolated-phase plans (ratios without a small rational form; plan.cpp)
+// ---------------------------------------------------------------------------------------------
+// One lane per output sample, as k_gather, but the coefficient of tap j is evaluated from the cubic
+// of the output's phase interval:  c = fma(fma(fma(a3, x, a2), x, a1), x, a0), one 16/32-byte load
+// per tap.  Interval and residual come from exact integer arithmetic on (k*M) mod L, so the result
+// is again a pure function of the absolute output index (chunk / launch invariant) and equals
+// oracle_interp_port_* bit for bit.
+template <typename Real> struct Vec4;
+template <> struct Vec4<float> { typedef float4 type; };
+template <> struct Vec4<double> { typedef double4 type; };
+
+struct InterpArgs {
+    GatherArgs g;   // bank/Lpad unused
+    const void *tab; // [P][T] of Vec4<Real>
+    int32_t P;
+};
+
+template <typename IO, typename Real>
+__global__ void __launch_bounds__(256) k_interp(InterpArgs ia)
+{
+    typedef typename Vec4<Real>::type V4;
+    const GatherArgs &a = ia.g;
+    int64_t idx;
+    uint32_t ch, clip;
+    if (a.ch_fast) {
+        int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        idx = e / a.n_channels;
+        ch = (uint32_t)(e - idx * a.n_channels);
+        clip = blockIdx.y;
+    } else {
+        idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        ch = blockIdx.y % a.n_channels;
+        clip = blockIdx.y / a.n_channels;
+    }
+    if (idx >= a.out_frames) return;
+    const int64_t t = a.p0 + idx * a.M;
+    const int64_t q = t / a.L;
+    const uint64_t r = (uint64_t)(t - q * a.L);
+    const uint64_t tp = r * (uint64_t)ia.P, iv = tp / (uint64_t)a.L, rem = tp - iv * (uint64_t)a.L;
+    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
+    const uint64_t xq = (rem << SH) / (uint64_t)a.L;
+    const Real xx = (Real)xq * (Real)(1. / (double)(1ULL << SH));
+    const int32_t T = a.T, H = T / 2;
+    const int64_t n0 = a.d0 + q - (H - 1);
+    const int64_t loc0 = n0 - a.in_abs0;
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    const V4 *c = (const V4 *)ia.tab + (int64_t)iv * T;
+    Real accL = 0, accR = 0;
+    auto coef = [&](int j) -> Real {
+        const V4 v = c[j];
+        return fma_r(fma_r(fma_r(v.w, xx, v.z), xx, v.y), xx, v.x);
+    };
+    if (loc0 >= 0 && loc0 + T <= a.in_frames) {
+        const IO *xp = xin + loc0 * a.ifs;
+        for (int j = 0; j < H; ++j) accL = fma_r(coef(j), (Real)xp[(int64_t)j * a.ifs], accL);
+        for (int j = T - 1; j >= H; --j) accR = fma_r(coef(j), (Real)xp[(int64_t)j * a.ifs], accR);
+    } else {
+        for (int j = 0; j < H; ++j) {
+            int64_t l = loc0 + j;
+            Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+            accL = fma_r(coef(j), xv, accL);
+        }
+        for (int j = T - 1; j >= H; --j) {
+            int64_t l = loc0 + j;
+            Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+            accR = fma_r(coef(j), xv, accR);
+        }
+    }
+    IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + idx * a.ofs + (int64_t)ch * a.ochs;
+    store_out<Real>(yo, accL + accR, a.oc, ch, a.out_k0 + idx);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_tile
 // ---------------------------------------------------------------------------------------------
 // Geometry (host-built, see build_tile_tables): the plan's period may be replicated c times so
@@ -958,6 +1031,13 @@ static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out, TileG
 {
     const int64_t L = p->L;
     const int32_t T = p->T;
+    if (p->phases) { // interpolated-phase plan: the cubic table in the engine precision, nothing else
+        std::vector<Real> tb(p->bank.size());
+        for (size_t i = 0; i < tb.size(); ++i) tb[i] = (Real)p->bank[i];
+        HIP_TRY(hipMalloc(&d.interp_tab, tb.size() * sizeof(Real)));
+        HIP_TRY(hipMemcpy(d.interp_tab, tb.data(), tb.size() * sizeof(Real), hipMemcpyHostToDevice));
+        return nullptr;
+    }
     d.Lpad = (L + 15) / 16 * 16;
     std::vector<Real> tm((size_t)T * d.Lpad, (Real)0);
     for (int64_t ph = 0; ph < L; ++ph)
@@ -1024,6 +1104,7 @@ void device_bank_release(Plan *p)
     for (int i = 0; i < 2; ++i) {
         DeviceBank &d = p->dev[i];
         if (d.tap_major) (void)hipFree(d.tap_major);
+        if (d.interp_tab) (void)hipFree(d.interp_tab);
         if (d.tile_tab) (void)hipFree(d.tile_tab);
         if (d.tile_i0) (void)hipFree(d.tile_i0);
         if (d.tile_tab_m) (void)hipFree(d.tile_tab_m);
@@ -1074,7 +1155,13 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             }
             grid = dim3((unsigned)((nf + 255) / 256), (unsigned)cols, 1);
         }
-        hipLaunchKernelGGL((k_gather<IO, Real>), grid, block, 0, st, a);
+        if (p->phases) {
+            InterpArgs ia;
+            ia.g = a; ia.tab = d.interp_tab; ia.P = p->phases;
+            hipLaunchKernelGGL((k_interp<IO, Real>), grid, block, 0, st, ia);
+        } else {
+            hipLaunchKernelGGL((k_gather<IO, Real>), grid, block, 0, st, a);
+        }
         HIP_TRY(hipGetLastError());
     }
     return nullptr;
@@ -1174,6 +1261,11 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
     }
     int kernel = j.kernel;
     if (kernel == HIPSOXR_KERNEL_EXACT || kernel == HIPSOXR_KERNEL_FFT) kernel = HIPSOXR_KERNEL_AUTO;
+    if (p->phases) { // interpolated-phase plan: one kernel (k_interp, dispatched by launch_gather)
+        if (kernel != HIPSOXR_KERNEL_AUTO && kernel != HIPSOXR_KERNEL_GATHER)
+            return "tile kernel unavailable for this plan";
+        return launch_gather<IO, Real>(p, j, st);
+    }
     if (kernel == HIPSOXR_KERNEL_TILE_VALU && !gv.ok) return "tile kernel unavailable for this plan";
     if (kernel == HIPSOXR_KERNEL_TILE_MFMA && !gm.ok) return "tile kernel unavailable for this plan";
     if (kernel == HIPSOXR_KERNEL_TILE) {

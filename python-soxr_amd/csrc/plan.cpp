@@ -76,8 +76,90 @@ static double bessel_i0(double x)
     return sum;
 }
 
-// Upper bound on bank entries for the exact-rational bank (32 Mi doubles = 256 MiB).
-static const int64_t kMaxBankElems = (int64_t)1 << 25;
+// Largest exact-rational bank (entries).  Ratios that would need more phases x taps than this —
+// random integer or float rates, reference tests/test_random.py:21-26 — get an interpolated-phase
+// plan instead.
+static const int64_t kMaxBankElems = (int64_t)1 << 22;
+
+// ---- interpolated-phase plans -----------------------------------------------------------------
+// The same prototype as a function of continuous time tau (in input samples),
+//     h(tau) = 2 fc sinc(2 fc tau) . I0(beta sqrt(1 - (tau/W)^2)) / I0(beta),   W = T/2,
+// normalised to unit DC gain on a 64x over-sampled grid.  An output at fractional input position
+// f = ((k M) mod L) / L weights tap j with h(f + T/2-1-j).  The f axis is divided into P intervals;
+// on each, every tap is the cubic through h at the interval's four Chebyshev nodes, kept in
+// monomial form [P][T][4] so that a kernel evaluates it with three FMAs (Horner) per tap.
+namespace {
+struct Proto {
+    bool cubic = false; // QQ: Lagrange 4-point kernel instead of the windowed sinc
+    double fc = 0, W = 0, beta = 0, inv_i0 = 0, stretch = 1;
+    double operator()(double tau) const
+    {
+        if (cubic) {
+            double t = std::fabs(tau) / stretch;
+            if (t < 1.) return (1. - t * t) * (2. - t) * .5;
+            if (t < 2.) return (1. - t) * (2. - t) * (3. - t) / 6.;
+            return 0.;
+        }
+        double u = tau / W, w = 1. - u * u;
+        if (w < 0.) w = 0.;
+        double s = tau == 0. ? 2. * fc : std::sin(2. * M_PI * fc * tau) / (M_PI * tau);
+        return s * bessel_i0(beta * std::sqrt(w)) * inv_i0;
+    }
+};
+const int kGrid = 64;
+} // namespace
+
+static void design_interp(Plan *p)
+{
+    const int32_t T = p->T, P = p->phases;
+    Proto h;
+    h.cubic = p->q.bits == 0.;
+    h.W = .5 * (double)T;
+    double scale = 1.;
+    if (h.cubic) {
+        h.stretch = p->M > p->L ? (double)p->M / (double)p->L : 1.;
+    } else {
+        const double fn = .5 * (p->in_rate < p->out_rate ? p->in_rate : p->out_rate);
+        h.fc = .5 * (p->q.passband_end + p->q.stopband_begin) * fn / p->in_rate;
+        h.beta = p->beta;
+        h.inv_i0 = 1. / bessel_i0(p->beta);
+        const int64_t half = (int64_t)kGrid * T / 2;
+        double sum = 0.;
+        for (int64_t m = -half; m < half; ++m) sum += h((double)m / (double)kGrid);
+        scale = (double)kGrid / sum;
+    }
+    double node[4];
+    for (int c = 0; c < 4; ++c) node[c] = .5 - .5 * std::cos((double)(2 * c + 1) * M_PI / 8.);
+    const double s01 = node[0] + node[1], s012 = node[0] + node[1] + node[2], p01 = node[0] * node[1],
+                 e2 = node[0] * node[1] + node[0] * node[2] + node[1] * node[2],
+                 p012 = node[0] * node[1] * node[2];
+    p->bank.assign((size_t)P * T * 4, 0.);
+    std::vector<double> v((size_t)4 * T);
+    for (int32_t i = 0; i < P; ++i) {
+        for (int c = 0; c < 4; ++c) {
+            const double f = ((double)i + node[c]) / (double)P;
+            double sum = 0.;
+            for (int32_t j = 0; j < T; ++j) {
+                v[(size_t)c * T + j] = h(f + (double)(T / 2 - 1 - j)) * scale;
+                sum += v[(size_t)c * T + j];
+            }
+            if (h.cubic)
+                for (int32_t j = 0; j < T; ++j) v[(size_t)c * T + j] /= sum;
+        }
+        for (int32_t j = 0; j < T; ++j) {
+            const double v0 = v[j], v1 = v[(size_t)T + j], v2 = v[(size_t)2 * T + j], v3 = v[(size_t)3 * T + j];
+            const double d01 = (v1 - v0) / (node[1] - node[0]), d12 = (v2 - v1) / (node[2] - node[1]),
+                         d23 = (v3 - v2) / (node[3] - node[2]);
+            const double d012 = (d12 - d01) / (node[2] - node[0]), d123 = (d23 - d12) / (node[3] - node[1]);
+            const double d3 = (d123 - d012) / (node[3] - node[0]);
+            double *a = &p->bank[((size_t)i * T + j) * 4];
+            a[3] = d3;
+            a[2] = d012 - d3 * s012;
+            a[1] = d01 - d012 * s01 + d3 * e2;
+            a[0] = v0 - d01 * node[0] + d012 * p01 - d3 * p012;
+        }
+    }
+}
 
 const char *plan_design(double in_rate, double out_rate, unsigned long recipe, Plan *p)
 {
@@ -93,7 +175,7 @@ const char *plan_design(double in_rate, double out_rate, unsigned long recipe, P
         int t = (int)std::ceil(4. * s);
         p->T = (t + 7) / 8 * 8;
         p->att_db = 0.; p->beta = 0.;
-        if (L * (int64_t)p->T > kMaxBankElems) return "rate ratio needs too many phases";
+        if (L * (int64_t)p->T > kMaxBankElems) { p->phases = 256; design_interp(p); return nullptr; }
         p->bank.assign((size_t)(L * p->T), 0.);
         const int32_t T = p->T;
         for (int64_t ph = 0; ph < L; ++ph) {
@@ -120,7 +202,11 @@ const char *plan_design(double in_rate, double out_rate, unsigned long recipe, P
     p->T = (int32_t)((t + 7) / 8 * 8);
     p->att_db = A;
     p->beta = .1102 * (A - 8.7);
-    if (L * (int64_t)p->T > kMaxBankElems) return "rate ratio needs too many phases";
+    if (L * (int64_t)p->T > kMaxBankElems) {
+        p->phases = p->q.bits <= 16. ? 16 : p->q.bits <= 20. ? 32 : 128;
+        design_interp(p);
+        return nullptr;
+    }
 
     const int32_t T = p->T;
     const int64_t half = L * (int64_t)T / 2;

@@ -20,6 +20,7 @@ struct QualitySpec {
 // Device-resident tables for one engine precision (float or double).
 struct DeviceBank {
     void *tap_major = nullptr;   // [T][Lpad]   (gather kernel: lanes read neighbouring phases)
+    void *interp_tab = nullptr;  // interpolated-phase plans: [P][T] of Real4 (a0..a3)
     int64_t Lpad = 0;
     // tile kernel: per output-tile skewed, zero-padded half tables (see kernels.hip)
     void *tile_tab = nullptr;    // [n_rt][2][I_h][RT]
@@ -37,7 +38,10 @@ struct Plan {
     int64_t L = 1, M = 1; // out/in = L/M
     int32_t T = 8;        // taps per phase
     double att_db = 0, beta = 0;
-    std::vector<double> bank; // [L][T], float64
+    // phases == 0: exact rational bank [L][T].  phases == P > 0: interpolated-phase plan, bank holds
+    // the cubic coefficient table [P][T][4] (see plan.cpp, "interpolated-phase plans").
+    int32_t phases = 0;
+    std::vector<double> bank; // float64
     // device side (lazily built on first use, per precision: 0 = f32, 1 = f64)
     DeviceBank dev[2];
     std::mutex mu;

@@ -28,6 +28,7 @@ class Plan:
         _n.check(_n.lib.hipsoxr_plan_info(self._h, _C.byref(info)))
         self.in_rate, self.out_rate = info.in_rate, info.out_rate
         self.L, self.M, self.taps = int(info.L), int(info.M), int(info.taps)
+        self.phases = int(info.interpolated)  # 0: exact bank; P: interpolated-phase plan
         self.precision_bits, self.passband_end = info.precision_bits, info.passband_end
         self.stopband_begin, self.att_db, self.kaiser_beta = info.stopband_begin, info.att_db, info.kaiser_beta
 
@@ -45,8 +46,10 @@ class Plan:
         return int(_n.lib.hipsoxr_plan_out_len(self._h, int(n_in)))
 
     def bank(self):
-        """float64 bank, phase-major [L][taps]."""
-        b = np.empty((self.L, self.taps), np.float64)
+        """float64 bank: phase-major [L][taps], or the cubic table [P][taps][4] of an
+        interpolated-phase plan."""
+        shape = (self.phases, self.taps, 4) if self.phases else (self.L, self.taps)
+        b = np.empty(shape, np.float64)
         _n.check(_n.lib.hipsoxr_plan_get_bank(self._h, b.ctypes.data, b.size))
         return b
 

@@ -81,6 +81,48 @@ def test_invalid_plans():
         dev.Plan(0, 44100)
     with pytest.raises(ValueError):
         dev.Plan(48000, 44100, "best")
-    # a ratio with no usable small rational form is refused (interpolated mode is not built yet)
-    with pytest.raises(RuntimeError):
-        dev.Plan(44100.123456789, 47999.987654321, "HQ")
+
+
+# ratios without a small rational form (reference tests/test_random.py:21-26: random integer and
+# float rates) -> interpolated-phase plans
+INTERP_RATES = [(48000, 44101), (44100.123456789, 47999.987654321), (95999, 8001), (8000.5, 96000.25),
+                (12345.678, 54321.9), (77777, 33333.3)]
+
+
+@pytest.mark.parametrize("in_rate,out_rate", INTERP_RATES)
+@pytest.mark.parametrize("quality", QUALS)
+def test_interp_plan_identical_to_oracle(oracle, in_rate, out_rate, quality):
+    from soxr_amd import device as dev
+    p = dev.Plan(in_rate, out_rate, quality)
+    o = oracle.plan(in_rate, out_rate, quality)
+    assert (p.L, p.M, p.taps, p.phases) == (o.L, o.M, o.T, o.phases)
+    assert abs(p.L / p.M - out_rate / in_rate) <= 1e-15 * out_rate / in_rate
+    assert np.array_equal(p.bank(), o.bank)
+    if p.phases:
+        assert p.L * p.taps > 1 << 22
+        n = 123457
+        assert p.out_len(n) == o.out_len(n)
+        assert abs(p.out_len(n) - n * out_rate / in_rate) <= 0.5 + 1e-6
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(48000, 44101), (95999, 8001), (12345.678, 54321.9)])
+@pytest.mark.parametrize("quality,bits", [("VHQ", 28), ("HQ", 20), ("MQ", 16)])
+def test_interp_table_accuracy(oracle, in_rate, out_rate, quality, bits):
+    """The cubic table reproduces the continuous prototype to far below the recipe's precision, and
+    every fractional position has unit DC gain."""
+    from soxr_amd import device as dev
+    p = dev.Plan(in_rate, out_rate, quality)
+    assert p.phases > 0
+    tab = p.bank()
+    o = oracle.plan(in_rate, out_rate, quality)
+    rng = np.random.default_rng(5)
+    worst = dc = 0.0
+    for f in np.concatenate([rng.random(24), [0.0, 1 - 2.0 ** -30]]):
+        iv = int(f * p.phases)
+        x = f * p.phases - iv
+        a = tab[iv]
+        c = a[:, 0] + x * (a[:, 1] + x * (a[:, 2] + x * a[:, 3]))
+        worst = max(worst, np.abs(c - o.exact_coefs(f)).max())
+        dc = max(dc, abs(c.sum() - 1))
+    assert worst <= 2.0 ** -(bits + 4)
+    assert dc <= 2.0 ** -(bits + 1)
