@@ -575,7 +575,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)g.lds_bytes));
     const unsigned nt = 256u;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks, (unsigned)cols, 1), dim3(nt), g.lds_bytes,
+    static const size_t dbg_lds = getenv("HIPSOXR_DEBUG_FFT_LDS") ? (size_t)atoi(getenv("HIPSOXR_DEBUG_FFT_LDS")) : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks, (unsigned)cols, 1), dim3(nt), std::max(g.lds_bytes, dbg_lds),
                        (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     *handled = true;
