@@ -63,6 +63,10 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, i32, i64, i64, i32, C.c_void_p, i64, i64,
                                          C.c_void_p, i64, i64]
             getattr(L, name).restype = None
+        L.oracle_design_vr.argtypes = [dbl, dbl, C.c_ulong, P(i32), P(i32), C.c_void_p]
+        for name in ("oracle_vr_ref", "oracle_vr_port_f64", "oracle_vr_port_f32"):
+            getattr(L, name).argtypes = [C.c_void_p, i32, i32, C.c_void_p, i64, i64, C.c_void_p, i64] + [u64] * 6
+            getattr(L, name).restype = None
         L.oracle_dither.argtypes = [u32, u32, i64]
         L.oracle_dither.restype = dbl
         L.oracle_quantize_i16.argtypes = [C.c_void_p, i64, C.c_int, u32, u32, i64, C.c_void_p]
@@ -156,6 +160,34 @@ def resample_channel(pl, x, mode, k0=0, n_out=None, in_abs0=0, bank=None):
            k0, n_out)
     else:
         fn(bank.ctypes.data, pl.L, pl.M, pl.T, x.ctypes.data, in_abs0, len(x), y.ctypes.data, k0, n_out)
+    return y
+
+
+class VrPlan:
+    """The table of a variable-rate stream created with (in_rate, out_rate) = the largest io ratio."""
+
+    def __init__(self, in_rate, out_rate, recipe="HQ"):
+        T, P = C.c_int32(), C.c_int32()
+        r = quality_enum(recipe)
+        if lib().oracle_design_vr(float(in_rate), float(out_rate), r, T, P, None):
+            raise ValueError("oracle_design_vr failed")
+        self.T, self.phases = T.value, P.value
+        self.bank = np.empty((self.phases, self.T, 4), np.float64)
+        lib().oracle_design_vr(float(in_rate), float(out_rate), r, T, P, self.bank.ctypes.data)
+
+
+def vr_run(vp, x, mode, n_out, T0, S0, D, in_abs0=0):
+    """Outputs i < n_out at Q64.64 positions T0 + i*S0 + D*i(i-1)/2 (Python integers; D may be
+    negative).  mode: "ref" | "port_f64" | "port_f32"."""
+    real = np.float32 if mode == "port_f32" else np.float64
+    x = np.ascontiguousarray(x, real)
+    y = np.empty(n_out, real)
+    words = []
+    for v in (T0, S0, D):
+        v &= (1 << 128) - 1
+        words += [v >> 64, v & ((1 << 64) - 1)]
+    getattr(lib(), "oracle_vr_" + mode)(vp.bank.ctypes.data, vp.phases, vp.T, x.ctypes.data, in_abs0, len(x),
+                                        y.ctypes.data, n_out, *words)
     return y
 
 

@@ -394,14 +394,13 @@ API int oracle_interp_exact_coefs(double in_rate, double out_rate, unsigned long
 }
 
 /* coef[P][T][4] (float64). */
-API int oracle_design_interp(double in_rate, double out_rate, unsigned long recipe, double *coef)
+static int design_interp_table(double in_rate, double out_rate, unsigned long recipe, int32_t P,
+                               double *coef)
 {
     proto_t pr;
     int64_t L, M;
-    int32_t T, P, i, j, c;
+    int32_t T, i, j, c;
     double scale, xn[4], *v;
-    P = oracle_plan_phases(in_rate, out_rate, recipe);
-    if (P <= 0) return -1;
     if (proto_setup(in_rate, out_rate, recipe, &pr, &L, &M, &T, &scale)) return -1;
     for (c = 0; c < 4; ++c) xn[c] = .5 - .5 * cos((double)(2 * c + 1) * M_PI / 8.);
     v = (double *)malloc((size_t)T * 4 * sizeof(double));
@@ -430,6 +429,13 @@ API int oracle_design_interp(double in_rate, double out_rate, unsigned long reci
     }
     free(v);
     return 0;
+}
+
+API int oracle_design_interp(double in_rate, double out_rate, unsigned long recipe, double *coef)
+{
+    int32_t P = oracle_plan_phases(in_rate, out_rate, recipe);
+    if (P <= 0) return -1;
+    return design_interp_table(in_rate, out_rate, recipe, P, coef);
 }
 
 /* position of output k: first tap's absolute input index, interval, quantised residual */
@@ -530,6 +536,133 @@ API void oracle_interp_port_f32(const double *coef, int32_t P, int64_t L, int64_
         y[i] = accL + accR;
     }
     free(cf);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* variable rate (SOXR_VR streams, /root/reference/src/soxr_ext.cpp:74, :200-204; usage pattern    */
+/* /root/reference/tests/vr.py:60-114).  Untested in the reference: only the API shape is pinned. */
+/* ------------------------------------------------------------------------------------------ */
+/* Same interpolated-phase table, designed for the largest io ratio.  Time is Q64.64 fixed point;
+ * one call covers outputs i = 0..n_out-1 whose input positions are the quadratic
+ *     t(i) = T0 + i*S0 + D*i(i-1)/2          (128-bit two's-complement integers, hi:lo words)
+ * (D = 0: constant ratio; D != 0: the step slews linearly).  P is a power of two: interval =
+ * top log2(P) bits of the fraction, residual = the next 24 (f32) / 32 (f64) bits.  The schedule
+ * of (T0, S0, D) across ratio changes is restated by the tests in Python integers. */
+typedef unsigned __int128 u128;
+
+static inline void locate_vr(int64_t i, uint64_t t_hi, uint64_t t_lo, uint64_t s_hi, uint64_t s_lo,
+                             uint64_t d_hi, uint64_t d_lo, int32_t T, int lgP, int sh, int64_t *n0,
+                             int32_t *iv, uint64_t *xq)
+{
+    u128 T0 = ((u128)t_hi << 64) | t_lo, S0 = ((u128)s_hi << 64) | s_lo, D = ((u128)d_hi << 64) | d_lo;
+    u128 n = (u128)(uint64_t)i, m = n * (n - 1) / 2; /* n = 0 -> 0 */
+    u128 t = T0 + n * S0 + D * m;                    /* modular: two's-complement D */
+    uint64_t frac = (uint64_t)t;
+    *n0 = (int64_t)(uint64_t)(t >> 64) - (T / 2 - 1);
+    *iv = lgP ? (int32_t)(frac >> (64 - lgP)) : 0;
+    *xq = (frac << lgP) >> (64 - sh);
+}
+
+#define VR_ARGS uint64_t t_hi, uint64_t t_lo, uint64_t s_hi, uint64_t s_lo, uint64_t d_hi, uint64_t d_lo
+#define VR_PASS t_hi, t_lo, s_hi, s_lo, d_hi, d_lo
+
+static int ilog2(int32_t P) { int l = 0; while ((1 << l) < P) ++l; return l; }
+
+API void oracle_vr_ref(const double *coef, int32_t P, int32_t T, const double *x, int64_t in_abs0,
+                       int64_t n_in, double *y, int64_t n_out, VR_ARGS)
+{
+    int64_t i;
+    int lgP = ilog2(P);
+    for (i = 0; i < n_out; ++i) {
+        int64_t n0, j;
+        int32_t iv;
+        uint64_t xq;
+        double acc = 0., xx;
+        const double *a;
+        locate_vr(i, VR_PASS, T, lgP, 32, &n0, &iv, &xq);
+        xx = (double)xq * (1. / 4294967296.);
+        a = coef + (size_t)iv * T * 4;
+        for (j = 0; j < T; ++j) {
+            int64_t q = n0 + j - in_abs0;
+            if (q >= 0 && q < n_in)
+                acc += (a[4 * j] + xx * (a[4 * j + 1] + xx * (a[4 * j + 2] + xx * a[4 * j + 3]))) * x[q];
+        }
+        y[i] = acc;
+    }
+}
+
+API void oracle_vr_port_f64(const double *coef, int32_t P, int32_t T, const double *x, int64_t in_abs0,
+                            int64_t n_in, double *y, int64_t n_out, VR_ARGS)
+{
+    int64_t i;
+    int lgP = ilog2(P);
+    for (i = 0; i < n_out; ++i) {
+        int64_t n0, j;
+        int32_t iv;
+        uint64_t xq;
+        double accL = 0., accR = 0., xx;
+        const double *a;
+        locate_vr(i, VR_PASS, T, lgP, 32, &n0, &iv, &xq);
+        xx = (double)xq * (1. / 4294967296.);
+        a = coef + (size_t)iv * T * 4;
+        for (j = 0; j < T / 2; ++j) {
+            int64_t q = n0 + j - in_abs0;
+            double xv = (q >= 0 && q < n_in) ? x[q] : 0.;
+            accL = fma(fma(fma(fma(a[4 * j + 3], xx, a[4 * j + 2]), xx, a[4 * j + 1]), xx, a[4 * j]), xv, accL);
+        }
+        for (j = T - 1; j >= T / 2; --j) {
+            int64_t q = n0 + j - in_abs0;
+            double xv = (q >= 0 && q < n_in) ? x[q] : 0.;
+            accR = fma(fma(fma(fma(a[4 * j + 3], xx, a[4 * j + 2]), xx, a[4 * j + 1]), xx, a[4 * j]), xv, accR);
+        }
+        y[i] = accL + accR;
+    }
+}
+
+API void oracle_vr_port_f32(const double *coef, int32_t P, int32_t T, const float *x, int64_t in_abs0,
+                            int64_t n_in, float *y, int64_t n_out, VR_ARGS)
+{
+    int64_t i, n = (int64_t)P * T * 4;
+    int lgP = ilog2(P);
+    float *cf = (float *)malloc((size_t)n * sizeof(float));
+    for (i = 0; i < n; ++i) cf[i] = (float)coef[i];
+    for (i = 0; i < n_out; ++i) {
+        int64_t n0, j;
+        int32_t iv;
+        uint64_t xq;
+        float accL = 0.f, accR = 0.f, xx;
+        const float *a;
+        locate_vr(i, VR_PASS, T, lgP, 24, &n0, &iv, &xq);
+        xx = (float)xq * (1.f / 16777216.f);
+        a = cf + (size_t)iv * T * 4;
+        for (j = 0; j < T / 2; ++j) {
+            int64_t q = n0 + j - in_abs0;
+            float xv = (q >= 0 && q < n_in) ? x[q] : 0.f;
+            accL = fmaf(fmaf(fmaf(fmaf(a[4 * j + 3], xx, a[4 * j + 2]), xx, a[4 * j + 1]), xx, a[4 * j]), xv, accL);
+        }
+        for (j = T - 1; j >= T / 2; --j) {
+            int64_t q = n0 + j - in_abs0;
+            float xv = (q >= 0 && q < n_in) ? x[q] : 0.f;
+            accR = fmaf(fmaf(fmaf(fmaf(a[4 * j + 3], xx, a[4 * j + 2]), xx, a[4 * j + 1]), xx, a[4 * j]), xv, accR);
+        }
+        y[i] = accL + accR;
+    }
+    free(cf);
+}
+
+/* The table a VR stream uses: always interpolated-phase, whatever the ratio.  coef == NULL: only
+ * report T and P. */
+API int oracle_design_vr(double in_rate, double out_rate, unsigned long recipe, int32_t *T_out,
+                         int32_t *P_out, double *coef)
+{
+    int64_t L, M;
+    int32_t T;
+    double att, beta, bits, pb, sb;
+    if (oracle_plan(in_rate, out_rate, recipe, &L, &M, &T, &att, &beta)) return -1;
+    oracle_quality(recipe, &bits, &pb, &sb);
+    *T_out = T;
+    *P_out = bits == 0. ? 256 : bits <= 16. ? 16 : bits <= 20. ? 32 : 128;
+    return coef ? design_interp_table(in_rate, out_rate, recipe, *P_out, coef) : 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -16,8 +16,15 @@ inline size_t elem_size(int elem)
     return elem == HIPSOXR_F32 ? 4 : elem == HIPSOXR_F64 ? 8 : elem == HIPSOXR_I32 ? 4 : 2;
 }
 
-// Enqueue one job (validated by the caller) on `stream`.
-const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream);
+// Variable-rate launches: input position of local output i is the Q64.64 fixed-point quadratic
+//   t(i) = T0 + i*S0 + D*i(i-1)/2     (128-bit two's-complement words, hi:lo)
+struct VrPos {
+    uint64_t t_hi, t_lo, s_hi, s_lo, d_hi, d_lo;
+};
+
+// Enqueue one job (validated by the caller) on `stream`.  vr != nullptr: positions come from *vr
+// instead of the plan's rational ratio (interpolated-phase plans only).
+const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream, const VrPos *vr = nullptr);
 
 int device_count();
 

@@ -9,8 +9,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "device.h"
 
@@ -24,7 +26,37 @@ namespace hipsoxr {
 Plan::~Plan() { device_bank_release(this); fft_release(this); }
 } // namespace hipsoxr
 
+// Variable-rate state (SOXR_VR streams; reference: src/soxr_ext.cpp:74, :200-204).  Time is kept in
+// Q64.64 fixed point.  The current segment starts at output k_s with input position t_s and step
+// s0; during the first n_slew outputs the step grows by `delta` per output, afterwards it is s1:
+//     t(k_s + n) = t_s + n*s0 + delta*n(n-1)/2                      n <= n_slew
+//                = t(k_s + n_slew) + (n - n_slew)*s1                n >  n_slew
+// All integer arithmetic: positions are exact, monotonic, and independent of how calls are cut.
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+struct VrState {
+    bool on = false;
+    double max_io = 0.;  // in_rate/out_rate at creation: the largest io ratio the filter allows
+    uint64_t k_s = 0, n_slew = 0;
+    i128 t_s = 0, s0 = 0, delta = 0, s1 = 0;
+
+    i128 pos(uint64_t k) const
+    {
+        const u128 n = k - k_s;
+        if (n <= n_slew) return t_s + (i128)n * s0 + delta * (i128)(n * (n - 1) / 2);
+        const u128 N = n_slew;
+        return t_s + (i128)N * s0 + delta * (i128)(N * (N - 1) / 2) + (i128)(n - N) * s1;
+    }
+    i128 step(uint64_t k) const
+    {
+        const u128 n = k - k_s;
+        return n < n_slew ? s0 + (i128)n * delta : s1;
+    }
+};
+static inline i128 q64(double x) { return (i128)(u128)std::ldexp(x, 64); } // truncating, exact scaling
+
 struct hipsoxr_stream {
+    VrState vr;
     hipsoxr_plan *plan = nullptr;
     bool own_plan = false;
     unsigned ch = 1;
@@ -142,12 +174,44 @@ static uint64_t k_avail(const Plan &p, uint64_t N)
     return (uint64_t)v + 1;
 }
 
+// Absolute index of the first input sample the next output (k_done) needs.
+static int64_t first_needed(const hipsoxr_stream *s)
+{
+    const Plan &p = s->plan->p;
+    if (s->vr.on) return (int64_t)(s->vr.pos(s->k_done) >> 64) - (p.T / 2 - 1);
+    int64_t n0, ph;
+    locate(p, (int64_t)s->k_done, &n0, &ph);
+    return n0;
+}
+
+// Variable rate: number of outputs [0, K) computable from N input frames without zero-extension
+// (output k reads up to floor(t(k)) + T/2), or — at end of input — the total K with
+// t(k) + step(k)/2 <= N (the constant-rate rule floor(N*L/M + 1/2), restated for a moving step).
+static uint64_t vr_k_limit(const hipsoxr_stream *s, bool ended)
+{
+    const VrState &v = s->vr;
+    const int64_t H = s->plan->p.T / 2;
+    const i128 N = (i128)s->n_in_total << 64;
+    auto ok = [&](uint64_t k) -> bool {
+        if (ended) return v.pos(k) + v.step(k) / 2 <= N;
+        return (int64_t)(v.pos(k) >> 64) + H <= (int64_t)s->n_in_total - 1;
+    };
+    uint64_t lo = s->k_done; // invariant: every k < lo is ok (already emitted, or checked)
+    if (!ok(lo)) return lo;
+    uint64_t span = 1;
+    while (ok(lo + span)) { lo += span; span <<= 1; } // t is strictly increasing: exponential + binary search
+    uint64_t hi = lo + span;                           // ok(lo), !ok(hi)
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (ok(mid)) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
 // Move the still-needed tail of the staged input to the front of the alternate buffer.
 static const char *stream_compact(hipsoxr_stream *s, size_t want_cap)
 {
-    const Plan &p = s->plan->p;
-    int64_t n0, ph;
-    locate(p, (int64_t)s->k_done, &n0, &ph);
+    const int64_t n0 = first_needed(s);
     int64_t keep_from = std::max<int64_t>(n0, s->in_base);
     keep_from = std::min<int64_t>(keep_from, s->in_base + (int64_t)s->in_fill);
     const size_t drop = (size_t)(keep_from - s->in_base), keep = s->in_fill - drop;
@@ -180,9 +244,7 @@ static const char *stream_append(hipsoxr_stream *s, const void *in, size_t ilen)
 {
     if (s->in_fill + ilen > s->in_cap) {
         // retire consumed input first; grow (power of two) only if that is not enough
-        const Plan &p = s->plan->p;
-        int64_t n0, ph;
-        locate(p, (int64_t)s->k_done, &n0, &ph);
+        const int64_t n0 = first_needed(s);
         int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base),
                                               s->in_base + (int64_t)s->in_fill);
         size_t keep = s->in_fill - (size_t)(keep_from - s->in_base);
@@ -205,12 +267,46 @@ static const char *stream_append(hipsoxr_stream *s, const void *in, size_t ilen)
 }
 
 // Emit up to olen frames (host destination).  `out_off` = frame offset into the caller's buffers.
+static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, size_t *odone);
+
+// Variable-rate streams evaluate one position law per launch, so a call that crosses the end of a
+// slew is served by two launches; everything else is a single one.
 static const char *stream_emit(hipsoxr_stream *s, void *out, size_t olen, size_t *odone)
 {
+    if (!s->vr.on) return stream_emit_once(s, out, olen, odone);
+    size_t total = 0;
+    std::vector<void *> chans(s->split ? s->ch : 0);
+    for (int pass = 0; pass < 4 && total < olen; ++pass) {
+        void *o = out;
+        if (s->split) {
+            for (unsigned c = 0; c < s->ch; ++c) chans[c] = (char *)((void *const *)out)[c] + total * esz(s);
+            o = chans.data();
+        } else {
+            o = (char *)out + total * s->ch * esz(s);
+        }
+        size_t got = 0;
+        if (const char *e = stream_emit_once(s, o, olen - total, &got)) return e;
+        total += got;
+        if (!got) break;
+    }
+    *odone = total;
+    return nullptr;
+}
+
+static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, size_t *odone)
+{
     const Plan &p = s->plan->p;
-    const uint64_t k_end = s->ended ? plan_out_len(p, s->n_in_total) : k_avail(p, s->n_in_total);
+    VrState &v = s->vr;
+    if (v.on && v.n_slew && s->k_done >= v.k_s + v.n_slew) { // slew finished: renormalise to a constant segment
+        const uint64_t k1 = v.k_s + v.n_slew;
+        v.t_s = v.pos(k1); v.k_s = k1; v.s0 = v.s1; v.delta = 0; v.n_slew = 0;
+    }
+    const uint64_t k_end = v.on ? vr_k_limit(s, s->ended)
+                                : s->ended ? plan_out_len(p, s->n_in_total) : k_avail(p, s->n_in_total);
     size_t n = 0;
     if (k_end > s->k_done) n = (size_t)std::min<uint64_t>(k_end - s->k_done, olen);
+    // one launch evaluates one quadratic: stop at the end of a slew (stream_emit comes back for the rest)
+    if (v.on && v.n_slew && s->k_done + n > v.k_s + v.n_slew) n = (size_t)(v.k_s + v.n_slew - s->k_done);
     *odone = n;
     if (n == 0) {
         HIP_TRY(hipStreamSynchronize(s->st)); // the caller's input buffer is borrowed only for the call
@@ -243,7 +339,12 @@ static const char *stream_emit(hipsoxr_stream *s, void *out, size_t olen, size_t
     if (s->in_fill == 0) { // nothing staged yet (e.g. flush of an empty stream): any valid pointer
         j.in = s->d_out;
     }
-    if (const char *e = launch_job(&s->plan->p, j, s->st)) return e;
+    if (v.on) {
+        const i128 T0 = v.pos(s->k_done), S0 = v.step(s->k_done), D = s->k_done < v.k_s + v.n_slew ? v.delta : 0;
+        VrPos vp = {(uint64_t)((u128)T0 >> 64), (uint64_t)(u128)T0, (uint64_t)((u128)S0 >> 64), (uint64_t)(u128)S0,
+                    (uint64_t)((u128)D >> 64), (uint64_t)(u128)D};
+        if (const char *e = launch_job(&s->plan->p, j, s->st, &vp)) return e;
+    } else if (const char *e = launch_job(&s->plan->p, j, s->st)) return e;
     if (!s->split) {
         HIP_TRY(hipMemcpyAsync(out, s->d_out, n * s->ch * esz(s), hipMemcpyDeviceToHost, s->st));
     } else {
@@ -262,12 +363,18 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
 {
     if (ch < 1) return "invalid channel count";
     if ((int)io < 0 || (int)io > 7) return "invalid io datatype";
-    if (flags & HIPSOXR_VR) return "variable-rate (SOXR_VR) resampling is not implemented";
+    if ((flags & HIPSOXR_VR) && !plan->p.phases) return "variable-rate streams need an interpolated-phase plan";
     if (device_count() <= 0) return kNoDevice;
     hipsoxr_stream *s = new (std::nothrow) hipsoxr_stream();
     if (!s) return "out of memory";
     s->plan = plan; s->own_plan = own; s->ch = ch;
     s->elem = (int)io & 3; s->split = ((int)io & 4) != 0; s->flags = flags;
+    if (flags & HIPSOXR_VR) {
+        const double io0 = plan->p.in_rate / plan->p.out_rate;
+        if (!(io0 > 9.5367431640625e-07) || !(io0 < 1048576.)) { delete s; return "io ratio out of range for variable rate"; }
+        s->vr.on = true; s->vr.max_io = io0;
+        s->vr.s0 = s->vr.s1 = q64(io0);
+    }
     const char *err = nullptr;
     do {
         if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
@@ -300,7 +407,11 @@ hipsoxr_error_t hipsoxr_stream_create(double in_rate, double out_rate, unsigned 
     if (!out) return "null argument";
     *out = nullptr;
     hipsoxr_plan_t *plan = nullptr;
-    if (const char *e = hipsoxr_plan_create(in_rate, out_rate, recipe, &plan)) return e;
+    if (flags & HIPSOXR_VR) { // positions are not tied to L/M: always the interpolated-phase table
+        plan = new (std::nothrow) hipsoxr_plan();
+        if (!plan) return "out of memory";
+        if (const char *e = plan_design(in_rate, out_rate, recipe, &plan->p, true)) { delete plan; return e; }
+    } else if (const char *e = hipsoxr_plan_create(in_rate, out_rate, recipe, &plan)) return e;
     if (const char *e = stream_new(plan, false, num_channels, io_type, flags, out)) {
         hipsoxr_plan_delete(plan);
         return e;
@@ -353,6 +464,9 @@ hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
 {
     if (!s) return "null argument";
     s->ended = false; s->n_in_total = 0; s->k_done = 0; s->in_base = 0; s->in_fill = 0;
+    if (s->vr.on) { // fresh signal at the ratio last requested
+        s->vr.k_s = 0; s->vr.t_s = 0; s->vr.s0 = s->vr.s1; s->vr.delta = 0; s->vr.n_slew = 0;
+    }
     HIP_TRY(hipMemsetAsync(s->d_clips, 0, sizeof(uint64_t), s->st));
     HIP_TRY(hipStreamSynchronize(s->st));
     return nullptr;
@@ -362,7 +476,13 @@ double hipsoxr_stream_delay(hipsoxr_stream_t *s)
 {
     if (!s) return 0.;
     const Plan &p = s->plan->p;
-    double d = (double)s->n_in_total * (double)p.L / (double)p.M - (double)s->k_done;
+    double d;
+    if (s->vr.on) { // input not yet passed by the output clock, in output samples at the current step
+        const double two64 = 18446744073709551616.;
+        d = ((double)s->n_in_total - (double)s->vr.pos(s->k_done) / two64) / ((double)s->vr.step(s->k_done) / two64);
+    } else {
+        d = (double)s->n_in_total * (double)p.L / (double)p.M - (double)s->k_done;
+    }
     return d > 0. ? d : 0.;
 }
 
@@ -377,9 +497,23 @@ size_t hipsoxr_stream_num_clips(hipsoxr_stream_t *s)
 
 const char *hipsoxr_stream_engine(hipsoxr_stream_t *s) { return s ? s->engine_name : ""; }
 
-hipsoxr_error_t hipsoxr_stream_set_io_ratio(hipsoxr_stream_t *, double, size_t)
+// reference: soxr_set_io_ratio, src/soxr_ext.cpp:200-204.  Takes effect at the next output frame
+// (index k_done); with slew_len > 0 the step moves linearly to the new value over that many OUTPUT
+// frames, otherwise at once.  The input position is continuous across the change.
+hipsoxr_error_t hipsoxr_stream_set_io_ratio(hipsoxr_stream_t *s, double io_ratio, size_t slew_len)
 {
-    return "variable-rate (SOXR_VR) resampling is not implemented";
+    if (!s) return "null argument";
+    if (!s->vr.on) return "set_io_ratio needs a stream created with the variable-rate flag (SOXR_VR)";
+    if (!(io_ratio > 9.5367431640625e-07) || !(io_ratio < 1048576.)) return "io ratio out of range";
+    if (io_ratio > s->vr.max_io * (1. + 1e-12))
+        return "io ratio exceeds the maximum given at creation (the filter would alias)";
+    if (slew_len > ((size_t)1 << 40)) return "slew length out of range";
+    VrState &v = s->vr;
+    const i128 t_now = v.pos(s->k_done), s_now = v.step(s->k_done), s_new = q64(io_ratio);
+    v.k_s = s->k_done; v.t_s = t_now; v.s1 = s_new;
+    if (slew_len > 0) { v.s0 = s_now; v.n_slew = slew_len; v.delta = (s_new - s_now) / (i128)slew_len; }
+    else { v.s0 = s_new; v.n_slew = 0; v.delta = 0; }
+    return nullptr;
 }
 
 hipsoxr_plan_t *hipsoxr_stream_plan(hipsoxr_stream_t *s) { return s ? s->plan : nullptr; }

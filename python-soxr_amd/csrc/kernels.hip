@@ -179,13 +179,19 @@ template <typename Real> struct Vec4;
 template <> struct Vec4<float> { typedef float4 type; };
 template <> struct Vec4<double> { typedef double4 type; };
 
+//
+// VR = true (variable-rate streams, engine.cpp): the position of local output i is the Q64.64
+// fixed-point quadratic  t(i) = T0 + i*S0 + D*i(i-1)/2  (constant step: D = 0; linear slew of the
+// step: D != 0), evaluated in 128-bit integers — again exact and launch-invariant.  P is a power
+// of two, so interval and residual are bit fields of the fraction.
 struct InterpArgs {
     GatherArgs g;   // bank/Lpad unused
     const void *tab; // [P][T] of Vec4<Real>
-    int32_t P;
+    int32_t P, lgP;
+    uint64_t t_hi, t_lo, s_hi, s_lo, d_hi, d_lo; // VR: T0, S0, D (two's complement), Q64.64
 };
 
-template <typename IO, typename Real>
+template <typename IO, typename Real, bool VR>
 __global__ void __launch_bounds__(256) k_interp(InterpArgs ia)
 {
     typedef typename Vec4<Real>::type V4;
@@ -203,15 +209,30 @@ __global__ void __launch_bounds__(256) k_interp(InterpArgs ia)
         clip = blockIdx.y / a.n_channels;
     }
     if (idx >= a.out_frames) return;
-    const int64_t t = a.p0 + idx * a.M;
-    const int64_t q = t / a.L;
-    const uint64_t r = (uint64_t)(t - q * a.L);
-    const uint64_t tp = r * (uint64_t)ia.P, iv = tp / (uint64_t)a.L, rem = tp - iv * (uint64_t)a.L;
     constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
-    const uint64_t xq = (rem << SH) / (uint64_t)a.L;
-    const Real xx = (Real)xq * (Real)(1. / (double)(1ULL << SH));
     const int32_t T = a.T, H = T / 2;
-    const int64_t n0 = a.d0 + q - (H - 1);
+    uint64_t iv, xq;
+    int64_t n0;
+    if (VR) {
+        typedef unsigned __int128 u128;
+        const u128 T0 = ((u128)ia.t_hi << 64) | ia.t_lo, S0 = ((u128)ia.s_hi << 64) | ia.s_lo,
+                   D = ((u128)ia.d_hi << 64) | ia.d_lo;
+        const uint64_t i = (uint64_t)idx, m = i * (i - 1) / 2; // i = 0: 0 * (2^64-1) / 2 ... handled below
+        const u128 tt = T0 + (u128)i * S0 + D * (u128)(i ? m : 0); // modular arithmetic == signed D
+        const uint64_t frac = (uint64_t)tt;
+        n0 = (int64_t)(uint64_t)(tt >> 64) - (H - 1);
+        iv = ia.lgP ? frac >> (64 - ia.lgP) : 0;
+        xq = (frac << ia.lgP) >> (64 - SH);
+    } else {
+        const int64_t t = a.p0 + idx * a.M;
+        const int64_t q = t / a.L;
+        const uint64_t r = (uint64_t)(t - q * a.L);
+        const uint64_t tp = r * (uint64_t)ia.P, rem = tp % (uint64_t)a.L;
+        iv = tp / (uint64_t)a.L;
+        xq = (rem << SH) / (uint64_t)a.L;
+        n0 = a.d0 + q - (H - 1);
+    }
+    const Real xx = (Real)xq * (Real)(1. / (double)(1ULL << SH));
     const int64_t loc0 = n0 - a.in_abs0;
     const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
     const V4 *c = (const V4 *)ia.tab + (int64_t)iv * T;
@@ -1121,7 +1142,7 @@ void device_bank_release(Plan *p)
 // launch
 // ---------------------------------------------------------------------------------------------
 template <typename IO, typename Real>
-static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
+static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr = nullptr)
 {
     const DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
     // split so that idx*M stays far below 2^63 and grid.x below 2^31
@@ -1157,8 +1178,24 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
         }
         if (p->phases) {
             InterpArgs ia;
+            std::memset(&ia, 0, sizeof ia);
             ia.g = a; ia.tab = d.interp_tab; ia.P = p->phases;
-            hipLaunchKernelGGL((k_interp<IO, Real>), grid, block, 0, st, ia);
+            while ((1 << ia.lgP) < ia.P) ++ia.lgP;
+            if (vr) {
+                if ((1 << ia.lgP) != ia.P) return "variable-rate needs a power-of-two phase count";
+                // position of the first output of this launch: advance (T0, S0) by `done` outputs
+                typedef unsigned __int128 u128;
+                const u128 T0 = ((u128)vr->t_hi << 64) | vr->t_lo, S0 = ((u128)vr->s_hi << 64) | vr->s_lo,
+                           D = ((u128)vr->d_hi << 64) | vr->d_lo;
+                const u128 n = (u128)(uint64_t)done, m = n * (n - 1) / 2;
+                const u128 T1 = T0 + n * S0 + D * (done ? m : 0), S1 = S0 + D * n;
+                ia.t_hi = (uint64_t)(T1 >> 64); ia.t_lo = (uint64_t)T1;
+                ia.s_hi = (uint64_t)(S1 >> 64); ia.s_lo = (uint64_t)S1;
+                ia.d_hi = vr->d_hi; ia.d_lo = vr->d_lo;
+                hipLaunchKernelGGL((k_interp<IO, Real, true>), grid, block, 0, st, ia);
+            } else {
+                hipLaunchKernelGGL((k_interp<IO, Real, false>), grid, block, 0, st, ia);
+            }
         } else {
             hipLaunchKernelGGL((k_gather<IO, Real>), grid, block, 0, st, a);
         }
@@ -1250,7 +1287,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
 }
 
 template <typename IO, typename Real>
-static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
+static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr)
 {
     const int prec = sizeof(Real) == 4 ? 0 : 1;
     TileGeom gv, gm; // VALU-tile and MFMA-tile geometries (the latter exists for the f32 engine only)
@@ -1264,8 +1301,9 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
     if (p->phases) { // interpolated-phase plan: one kernel (k_interp, dispatched by launch_gather)
         if (kernel != HIPSOXR_KERNEL_AUTO && kernel != HIPSOXR_KERNEL_GATHER)
             return "tile kernel unavailable for this plan";
-        return launch_gather<IO, Real>(p, j, st);
+        return launch_gather<IO, Real>(p, j, st, vr);
     }
+    if (vr) return "variable-rate needs an interpolated-phase plan";
     if (kernel == HIPSOXR_KERNEL_TILE_VALU && !gv.ok) return "tile kernel unavailable for this plan";
     if (kernel == HIPSOXR_KERNEL_TILE_MFMA && !gm.ok) return "tile kernel unavailable for this plan";
     if (kernel == HIPSOXR_KERNEL_TILE) {
@@ -1283,7 +1321,7 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
     return launch_gather<IO, Real>(p, j, st);
 }
 
-const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream)
+const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr)
 {
     if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return nullptr;
     const int prec = engine_prec(j.elem);
@@ -1291,7 +1329,7 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream)
     // Frequency-domain engine: explicit request, or AUTO for large whole-signal float32 jobs.
     // It is NOT bit-identical to the canonical order (1.4e-7 relative RMS), so it is never chosen
     // for HIPSOXR_KERNEL_EXACT — which is what the stream / one-shot host entry points pass.
-    if (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO) {
+    if (!vr && (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO)) {
         static const bool no_fft = getenv("HIPSOXR_NO_FFT") != nullptr;
         const bool eligible = fft_job_eligible(*p, j);
         const bool big = (int64_t)j.out_frames * j.n_clips * j.n_channels >= (1 << 18);
@@ -1306,10 +1344,10 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream)
     }
     hipStream_t st = (hipStream_t)stream;
     switch (j.elem) {
-    case HIPSOXR_F32: return launch_typed<float, float>(p, j, st);
-    case HIPSOXR_F64: return launch_typed<double, double>(p, j, st);
-    case HIPSOXR_I32: return launch_typed<int32_t, double>(p, j, st);
-    case HIPSOXR_I16: return launch_typed<int16_t, float>(p, j, st);
+    case HIPSOXR_F32: return launch_typed<float, float>(p, j, st, vr);
+    case HIPSOXR_F64: return launch_typed<double, double>(p, j, st, vr);
+    case HIPSOXR_I32: return launch_typed<int32_t, double>(p, j, st, vr);
+    case HIPSOXR_I16: return launch_typed<int16_t, float>(p, j, st, vr);
     }
     return "invalid element type";
 }

@@ -161,7 +161,7 @@ static void design_interp(Plan *p)
     }
 }
 
-const char *plan_design(double in_rate, double out_rate, unsigned long recipe, Plan *p)
+const char *plan_design(double in_rate, double out_rate, unsigned long recipe, Plan *p, bool force_interp)
 {
     if (const char *e = quality_spec(recipe, &p->q)) return e;
     if (const char *e = reduce_ratio(in_rate, out_rate, &p->L, &p->M)) return e;
@@ -175,7 +175,7 @@ const char *plan_design(double in_rate, double out_rate, unsigned long recipe, P
         int t = (int)std::ceil(4. * s);
         p->T = (t + 7) / 8 * 8;
         p->att_db = 0.; p->beta = 0.;
-        if (L * (int64_t)p->T > kMaxBankElems) { p->phases = 256; design_interp(p); return nullptr; }
+        if (force_interp || L * (int64_t)p->T > kMaxBankElems) { p->phases = 256; design_interp(p); return nullptr; }
         p->bank.assign((size_t)(L * p->T), 0.);
         const int32_t T = p->T;
         for (int64_t ph = 0; ph < L; ++ph) {
@@ -202,7 +202,7 @@ const char *plan_design(double in_rate, double out_rate, unsigned long recipe, P
     p->T = (int32_t)((t + 7) / 8 * 8);
     p->att_db = A;
     p->beta = .1102 * (A - 8.7);
-    if (L * (int64_t)p->T > kMaxBankElems) {
+    if (force_interp || L * (int64_t)p->T > kMaxBankElems) {
         p->phases = p->q.bits <= 16. ? 16 : p->q.bits <= 20. ? 32 : 128;
         design_interp(p);
         return nullptr;

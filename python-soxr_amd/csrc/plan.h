@@ -53,7 +53,9 @@ struct Plan {
 // Returns nullptr on success, else a static error string.
 const char *quality_spec(unsigned long recipe, QualitySpec *q);
 const char *reduce_ratio(double in_rate, double out_rate, int64_t *L, int64_t *M);
-const char *plan_design(double in_rate, double out_rate, unsigned long recipe, Plan *p);
+// force_interp: always build the interpolated-phase table (variable-rate streams need one whatever
+// the ratio: their positions are not tied to L/M).
+const char *plan_design(double in_rate, double out_rate, unsigned long recipe, Plan *p, bool force_interp = false);
 uint64_t plan_out_len(const Plan &p, uint64_t n_in);
 
 // Position of output k: first tap's absolute input index n0 and phase p.

@@ -82,7 +82,8 @@ class ResampleStream:
     num_channels : int              1 .. 65536
     dtype : float32 | float64 | int16 | int32 (type or str)
     quality : 'QQ' | 'LQ' | 'MQ' | 'HQ' | 'VHQ' (or the soxr.* constants)
-    vr : bool                       variable-rate mode — not implemented (RuntimeError)
+    vr : bool                       (experimental in the reference) variable-rate mode: in_rate/out_rate
+                                    must be the LARGEST io ratio that will be used; see set_io_ratio
     """
 
     def __init__(self, in_rate, out_rate, num_channels, dtype="float32", quality="HQ", vr=False):
@@ -164,9 +165,16 @@ class ResampleStream:
         return _n.lib.hipsoxr_stream_engine(self._h).decode()
 
     def set_io_ratio(self, in_rate, out_rate, slew_len=0):
-        """(Experimental in the reference.)  Variable-rate control — not implemented here."""
+        """(Experimental in the reference, src/soxr/__init__.py:162-179.)  New rate ratio for the
+        output that follows; needs vr=True.  slew_len > 0: the ratio moves linearly to the new value
+        over that many output frames; 0: at once.  in_rate/out_rate may not exceed the ratio given
+        to the constructor."""
+        if in_rate <= 0 or out_rate <= 0:
+            raise ValueError("Sample rate should be over 0")
         _n.check(_n.lib.hipsoxr_stream_set_io_ratio(self._h, float(in_rate) / float(out_rate),
                                                     int(slew_len)))
+        # output buffers are sized from the largest out/in ratio seen (src/soxr_ext.cpp:203)
+        self._ratio = max(self._ratio, float(out_rate) / float(in_rate))
 
 
 def _layout_split(x):

@@ -152,4 +152,4 @@ def test_stream_protocol(soxr):
     assert np.array_equal(full, again)
     assert np.array_equal(full, soxr.resample(x, 44100, 16000, quality="VHQ"))
     with pytest.raises(RuntimeError):
-        soxr.ResampleStream(44100, 16000, 1, vr=True)           # variable rate: not implemented
+        rs.set_io_ratio(44100, 22050)                           # needs vr=True (tests/test_gpu_vr.py)
