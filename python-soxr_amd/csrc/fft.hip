@@ -136,12 +136,49 @@ template <int R, int SIGN> __device__ __forceinline__ void dft_odd(cf *u)
 #pragma unroll
     for (int m = 0; m < R; ++m) u[m] = out[m];
 }
+template <int R, int SIGN> __device__ __forceinline__ void dft_r(cf *u);
+
+// Composite radix R1*R2 with coprime factors by the prime-factor (Good-Thomas) index maps: a
+// plain R1 x R2 two-dimensional DFT, no internal twiddles; the maps are compile-time constants, so
+// they cost register renaming only.
+constexpr int inv_mod(int a, int m)
+{
+    for (int x = 1; x < m; ++x)
+        if ((a * x) % m == 1) return x;
+    return 1;
+}
+template <int R1, int R2, int SIGN> __device__ __forceinline__ void dft_pfa(cf *u)
+{
+    constexpr int N = R1 * R2, e1 = R2 * inv_mod(R2 % R1, R1), e2 = R1 * inv_mod(R1 % R2, R2);
+    cf x[R2][R1]; // x[n2][n1] = u[(R2 n1 + R1 n2) mod N]
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2)
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) x[n2][n1] = u[(R2 * n1 + R1 * n2) % N];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) dft_r<R1, SIGN>(x[n2]);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+        cf c[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) c[n2] = x[n2][k1];
+        dft_r<R2, SIGN>(c);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) u[(e1 * k1 + e2 * k2) % N] = c[k2]; // CRT output map
+    }
+}
 template <int R, int SIGN> __device__ __forceinline__ void dft_r(cf *u)
 {
     if constexpr (R == 2) dft2<SIGN>(u[0], u[1]);
     else if constexpr (R == 4) dft4<SIGN>(u[0], u[1], u[2], u[3]);
     else if constexpr (R == 8) dft8<SIGN>(u);
     else if constexpr (R == 16) dft16<SIGN>(u);
+    else if constexpr (R == 6) dft_pfa<2, 3, SIGN>(u);
+    else if constexpr (R == 10) dft_pfa<2, 5, SIGN>(u);
+    else if constexpr (R == 12) dft_pfa<4, 3, SIGN>(u);
+    else if constexpr (R == 14) dft_pfa<2, 7, SIGN>(u);
+    else if constexpr (R == 20) dft_pfa<4, 5, SIGN>(u);
+    else if constexpr (R == 21) dft_pfa<3, 7, SIGN>(u);
     else dft_odd<R, SIGN>(u);
 }
 
@@ -249,10 +286,26 @@ __device__ __forceinline__ void fft_ct(cf *buf, const cf *W, Load first_load, St
     fft_pass_ct<N, R0 * R1 * R2, R3, SIGN, NT, false>(W, lds_load, last_store);
 }
 
+// Three-pass variant (larger radices: fewer LDS round trips and barriers).
+template <int N, int SIGN, int NT, int R0, int R1, int R2, typename Load, typename Store>
+__device__ __forceinline__ void fft_ct3(cf *buf, const cf *W, Load first_load, Store last_store, bool first_in_lds)
+{
+    static_assert(R0 * R1 * R2 == N, "radix schedule");
+    auto lds_load = [&](int n) -> cf { return buf[n]; };
+    auto lds_store = [&](int n, cf v) { buf[n] = v; };
+    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, lds_store);
+    else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, lds_store);
+    __syncthreads();
+    fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, lds_load, lds_store);
+    __syncthreads();
+    fft_pass_ct<N, R0 * R1, R2, SIGN, NT, false>(W, lds_load, last_store);
+}
+
 struct FftArgs {
     const void *in;
     void *out;
     const float2 *WA, *WB, *P, *Q, *Hs; // twiddles of both transforms, (un)tangling twiddles, filter
+    const float2 *WA2, *WB2;            // paired-block kernel: twiddles of the full-length transforms
     int32_t A, B;            // complex transform lengths: N_in/2, N_out/2
     int32_t nA, nB;          // number of passes
     int32_t radA[8], radB[8];
@@ -409,6 +462,84 @@ __global__ void __launch_bounds__(256, Spec::ct ? 5 : 2) k_fft_block(FftArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Paired-block kernel.  The whole chain  FFT -> multiply by H -> truncate -> inverse FFT  maps real
+// signals to real signals and is linear, so it can process TWO real blocks at once as the real and
+// imaginary part of one complex signal:  z = x_a + i x_b  ->  y_a + i y_b  (H is Hermitian, the
+// truncation symmetric; the Nyquist bin of the output grid sums both aliases so that the operator
+// stays exactly real).  That removes the real-FFT untangle/tangle stages altogether — the filter
+// multiply rides on the loads of the first inverse pass — and, with radix-16/20/21 butterflies,
+// leaves 3 + 3 LDS passes per pair of blocks instead of 4 + 1 + 4 per block.
+// One workgroup = blocks (2b, 2b+1) of one column; one LDS buffer of N_in complex values.
+// ---------------------------------------------------------------------------------------------
+// 48k -> 44.1k family, k = 32: N_in = 5120 = 16*16*20, N_out = 4704 = 16*14*21
+struct Pair5120x4704 {
+    static constexpr int NA = 5120, NB = 4704, NT = 384;
+    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    { fft_ct3<5120, -1, NT, 16, 16, 20>(b, W, ld, st, in_lds); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    { fft_ct3<4704, +1, NT, 16, 14, 21>(b, W, ld, st, in_lds); }
+};
+// same family, k = 16 (small jobs): N_in = 2560 = 16*16*10, N_out = 2352 = 16*7*21
+struct Pair2560x2352 {
+    static constexpr int NA = 2560, NB = 2352, NT = 192;
+    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    { fft_ct3<2560, -1, NT, 16, 16, 10>(b, W, ld, st, in_lds); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    { fft_ct3<2352, +1, NT, 16, 7, 21>(b, W, ld, st, in_lds); }
+};
+
+template <typename Spec>
+__global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *cur = reinterpret_cast<cf *>(smem_raw);
+    constexpr int NA = Spec::NA, NB = Spec::NB;
+    static_assert(NA >= NB, "paired kernel is instantiated for down-sampling families");
+
+    const uint32_t col = blockIdx.y;
+    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    const int64_t pa = 2 * (int64_t)blockIdx.x * a.hop_periods - a.lead_periods; // first period of block a
+    const int64_t pb = pa + a.hop_periods;                                       // ... of block b
+    const int64_t ina = pa * a.M, inb = pb * a.M, outa = pa * a.L, outb = pb * a.L;
+    const float *xin = (const float *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    auto lds_store = [&](int n, cf v) { cur[n] = v; };
+
+    // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
+    // (one instantiation of the transform for interior and edge blocks alike, so that both run the
+    // same instruction sequence and round identically)
+    const bool interior = a.ifs == 1 && ina >= 0 && inb + NA <= a.in_frames;
+    const float *xa = xin + ina, *xb = xin + inb;
+    Spec::fwd(cur, a.WA2, [&](int n) -> cf {
+        if (interior) return make_float2(xa[n], xb[n]);
+        const int64_t la = ina + n, lb = inb + n;
+        return make_float2((la >= 0 && la < a.in_frames) ? xin[la * a.ifs] : 0.f,
+                           (lb >= 0 && lb < a.in_frames) ? xin[lb * a.ifs] : 0.f);
+    }, lds_store, false);
+    __syncthreads();
+
+    // ---- inverse: bin n of the output grid <- bin n (n <= NB/2) or n + NA - NB (negative
+    //      frequencies) of the input grid, times H (Hermitian); result n = (y_a[n], y_b[n]) ---------
+    float *yo = (float *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+    const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out;
+    auto h_load = [&](int n) -> cf {
+        const bool neg = n > NB / 2;
+        cf h = a.Hs[neg ? NB - n : n];
+        if (neg) h.y = -h.y;
+        cf y = cmul(cur[neg ? n + (NA - NB) : n], h);
+        if (n == NB / 2) y = cadd(y, cmul(cur[n + (NA - NB)], cconj(h)));
+        return y;
+    };
+    auto out_store = [&](int n, cf w) {
+        if (n >= v0 && n < v1) {
+            const int64_t ka = outa + n, kb = outb + n;
+            if (ka >= 0 && ka < a.out_frames) yo[ka * a.ofs] = w.x;
+            if (kb >= 0 && kb < a.out_frames) yo[kb * a.ofs] = w.y;
+        }
+    };
+    Spec::inv(cur, a.WB2, h_load, out_store, true);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host: geometry, tables
 // ---------------------------------------------------------------------------------------------
 struct FftGeom {
@@ -418,7 +549,7 @@ struct FftGeom {
     std::vector<int> radA, radB;
     int32_t lead_periods = 0, hop_periods = 0, v0 = 0, hop_out = 0;
     size_t lds_bytes = 0;
-    float2 *dev = nullptr; // [WA: A][WB: B][P: A+1][Q: B][Hs: B+1]
+    float2 *dev = nullptr; // [WA: A][WB: B][P: A+1][Q: B][Hs: B+1][WA2: N_in][WB2: N_out]
 };
 
 static bool factor_radices(int n, std::vector<int> &rad)
@@ -486,8 +617,11 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small)
     if (g.lds_bytes > 150 * 1024) { *out = g; return nullptr; }
 
     const int A = g.A, B = g.B;
-    std::vector<float2> tab((size_t)A + B + (A + 1) + B + (B + 1));
+    std::vector<float2> tab((size_t)A + B + (A + 1) + B + (B + 1) + g.N_in + g.N_out);
     float2 *WA = tab.data(), *WB = WA + A, *P = WB + B, *Q = P + (A + 1), *Hs = Q + B;
+    float2 *WA2 = Hs + (B + 1), *WB2 = WA2 + g.N_in;
+    for (int m = 0; m < g.N_in; ++m) WA2[m] = make_float2((float)std::cos(6.283185307179586476925286766559 * m / g.N_in), (float)-std::sin(6.283185307179586476925286766559 * m / g.N_in));
+    for (int m = 0; m < g.N_out; ++m) WB2[m] = make_float2((float)std::cos(6.283185307179586476925286766559 * m / g.N_out), (float)std::sin(6.283185307179586476925286766559 * m / g.N_out));
     const double PI2 = 6.283185307179586476925286766559;
     for (int m = 0; m < A; ++m) WA[m] = make_float2((float)std::cos(PI2 * m / A), (float)-std::sin(PI2 * m / A));
     for (int m = 0; m < B; ++m) WB[m] = make_float2((float)std::cos(PI2 * m / B), (float)std::sin(PI2 * m / B));
@@ -556,6 +690,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     FftArgs a;
     a.in = j.in; a.out = j.out;
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
+    a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
     a.A = g.A; a.B = g.B; a.nA = (int32_t)g.radA.size(); a.nB = (int32_t)g.radB.size();
     for (int i = 0; i < 8; ++i) { a.radA[i] = i < a.nA ? g.radA[i] : 1; a.radB[i] = i < a.nB ? g.radB[i] : 1; }
     a.L = p->L; a.M = p->M;
@@ -568,6 +703,19 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
     if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";
     if (n_blocks > 2147483647LL) return "job too long for one launch";
+    // paired-block kernels (compile-time schedules of the 147/160 family)
+    static const bool no_pair = getenv("HIPSOXR_FFT_NO_PAIR") != nullptr;
+    if (!no_pair && ((g.N_in == 5120 && g.N_out == 4704) || (g.N_in == 2560 && g.N_out == 2352))) {
+        const bool big = g.N_in == 5120;
+        void (*pk)(FftArgs) = big ? k_fft_pair<Pair5120x4704> : k_fft_pair<Pair2560x2352>;
+        const unsigned nt = big ? Pair5120x4704::NT : Pair2560x2352::NT;
+        const size_t lds = (size_t)g.N_in * sizeof(float2);
+        hipLaunchKernelGGL(pk, dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols, 1), dim3(nt), lds,
+                           (hipStream_t)stream, a);
+        HIP_TRY(hipGetLastError());
+        *handled = true;
+        return nullptr;
+    }
     void (*kern)(FftArgs) = k_fft_block<SpecRuntime>;
     if (g.A == 2560 && g.B == 2352) kern = k_fft_block<Spec2560x2352>; // compile-time radix schedules
     if (g.A == 1280 && g.B == 1176) kern = k_fft_block<Spec1280x1176>; // for the 147/160 family
