@@ -287,16 +287,23 @@ __device__ __forceinline__ void fft_ct(cf *buf, const cf *W, Load first_load, St
 }
 
 // Three-pass variant (larger radices: fewer LDS round trips and barriers).
-template <int N, int SIGN, int NT, int R0, int R1, int R2, typename Load, typename Store>
+// LDS bank conflicts: pass loads are contiguous across lanes (conflict-free); pass stores run in
+// groups of Ns consecutive elements, so only the FIRST pass (Ns = 1: lane stride = R0 elements) can
+// conflict.  An odd-ish R0 (5, 21: stride 40 / 168 bytes) is conflict-free as it is; for R0 = 16
+// (stride 128 bytes = every lane on the same two banks, a 16-way conflict) the buffer between pass
+// 1 and pass 2 is kept in a swizzled layout  n -> n ^ ((n >> 4) & 15)  (SWZ).
+template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, typename Load, typename Store>
 __device__ __forceinline__ void fft_ct3(cf *buf, const cf *W, Load first_load, Store last_store, bool first_in_lds)
 {
     static_assert(R0 * R1 * R2 == N, "radix schedule");
     auto lds_load = [&](int n) -> cf { return buf[n]; };
     auto lds_store = [&](int n, cf v) { buf[n] = v; };
-    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, lds_store);
-    else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, lds_store);
+    auto swz_load = [&](int n) -> cf { return buf[SWZ ? n ^ ((n >> 4) & 15) : n]; };
+    auto swz_store = [&](int n, cf v) { buf[SWZ ? n ^ ((n >> 4) & 15) : n] = v; };
+    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, swz_store);
+    else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, swz_store);
     __syncthreads();
-    fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, lds_load, lds_store);
+    fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, swz_load, lds_store);
     __syncthreads();
     fft_pass_ct<N, R0 * R1, R2, SIGN, NT, false>(W, lds_load, last_store);
 }
@@ -471,21 +478,21 @@ __global__ void __launch_bounds__(256, Spec::ct ? 5 : 2) k_fft_block(FftArgs a)
 // leaves 3 + 3 LDS passes per pair of blocks instead of 4 + 1 + 4 per block.
 // One workgroup = blocks (2b, 2b+1) of one column; one LDS buffer of N_in complex values.
 // ---------------------------------------------------------------------------------------------
-// 48k -> 44.1k family, k = 32: N_in = 5120 = 16*16*20, N_out = 4704 = 16*14*21
+// 48k -> 44.1k family, k = 32: N_in = 5120 = 16*16*20, N_out = 4704 = 21*16*14
 struct Pair5120x4704 {
     static constexpr int NA = 5120, NB = 4704, NT = 384;
     template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
-    { fft_ct3<5120, -1, NT, 16, 16, 20>(b, W, ld, st, in_lds); }
+    { fft_ct3<5120, -1, NT, 16, 16, 20, true>(b, W, ld, st, in_lds); }
     template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
-    { fft_ct3<4704, +1, NT, 16, 14, 21>(b, W, ld, st, in_lds); }
+    { fft_ct3<4704, +1, NT, 21, 16, 14, false>(b, W, ld, st, in_lds); }
 };
-// same family, k = 16 (small jobs): N_in = 2560 = 16*16*10, N_out = 2352 = 16*7*21
+// same family, k = 16 (small jobs): N_in = 2560 = 16*16*10, N_out = 2352 = 21*16*7
 struct Pair2560x2352 {
-    static constexpr int NA = 2560, NB = 2352, NT = 192;
+    static constexpr int NA = 2560, NB = 2352, NT = 256;
     template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
-    { fft_ct3<2560, -1, NT, 16, 16, 10>(b, W, ld, st, in_lds); }
+    { fft_ct3<2560, -1, NT, 16, 16, 10, true>(b, W, ld, st, in_lds); }
     template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
-    { fft_ct3<2352, +1, NT, 16, 7, 21>(b, W, ld, st, in_lds); }
+    { fft_ct3<2352, +1, NT, 21, 16, 7, false>(b, W, ld, st, in_lds); }
 };
 
 template <typename Spec>
@@ -680,7 +687,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         // few blocks (e.g. one 60 s clip = 600): half-size blocks give twice as many workgroups of
         // half the latency, at the price of more overlap
         const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out) * (int64_t)j.n_clips * j.n_channels;
-        if (wgs < 8 * 256 && !getenv("HIPSOXR_FFT_LARGE_ONLY")) {
+        if ((wgs < 8 * 256 && !getenv("HIPSOXR_FFT_LARGE_ONLY")) || getenv("HIPSOXR_FFT_SMALL_ONLY")) {
             FftGeom gs;
             if (const char *err = get(true, &gs)) return err;
             if (gs.ok && gs.k < g.k) g = gs;
