@@ -156,10 +156,17 @@ def hbm_ceiling(device, n_bytes=1 << 29):
     """What this box's HBM delivers to plain streaming kernels (torch's copy and reduction), so
     that roofline fractions can also be read against the achievable rather than the spec peak."""
     import torch
+    from soxr_amd import _native as nat
     a = torch.empty(n_bytes // 4, dtype=torch.float32, device=device).normal_()
     b = torch.empty_like(a)
+    st = torch.cuda.current_stream(device).cuda_stream
     res = {}
-    for name, fn, moved in (("copy", lambda: b.copy_(a), 2 * n_bytes), ("read", lambda: a.sum(), n_bytes)):
+
+    def own(mode):
+        nat.check(nat.lib.hipsoxr_bench_stream(b.data_ptr(), a.data_ptr(), n_bytes, mode, st))
+
+    for name, fn, moved in (("copy", lambda: own(0), 2 * n_bytes), ("read", lambda: own(1), n_bytes),
+                            ("torch_copy", lambda: b.copy_(a), 2 * n_bytes)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize(device)
@@ -170,7 +177,7 @@ def hbm_ceiling(device, n_bytes=1 << 29):
         e1.record()
         torch.cuda.synchronize(device)
         res[name + "_GBs"] = moved * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    res["note"] = "torch copy_/sum over 512 MiB float32, HIP events"
+    res["note"] = "float4 grid-stride copy / read kernels (hipsoxr_bench_stream) and torch copy_, 512 MiB, HIP events"
     return res
 
 

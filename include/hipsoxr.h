@@ -169,6 +169,13 @@ HIPSOXR_API hipsoxr_error_t hipsoxr_stream_set_io_ratio(hipsoxr_stream_t *, doub
                                                         size_t slew_len);
 HIPSOXR_API hipsoxr_plan_t *hipsoxr_stream_plan(hipsoxr_stream_t *);
 
+/* ---- measurement helper (no counterpart in the reference) -------------------------------- */
+/* Plain streaming kernels over device buffers, for the "achievable HBM rate" that bench.py
+ * reports beside the roofline: mode 0 copies `bytes` from src to dst, mode 1 only reads src
+ * (dst must still point to at least 4 writable bytes).  Asynchronous on `hip_stream`. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_bench_stream(void *dst, const void *src, size_t bytes, int mode,
+                                                 void *hip_stream);
+
 /* ---- one-shot (create + process all + flush + delete), host pointers ---------------------- */
 HIPSOXR_API hipsoxr_error_t hipsoxr_oneshot(double in_rate, double out_rate, unsigned num_channels,
                                             const void *in, size_t ilen, void *out, size_t olen,

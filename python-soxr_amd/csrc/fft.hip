@@ -488,7 +488,7 @@ struct Pair5120x4704 {
 };
 // same family, k = 16 (small jobs): N_in = 2560 = 16*16*10, N_out = 2352 = 21*16*7
 struct Pair2560x2352 {
-    static constexpr int NA = 2560, NB = 2352, NT = 256;
+    static constexpr int NA = 2560, NB = 2352, NT = 384;
     template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
     { fft_ct3<2560, -1, NT, 16, 16, 10, true>(b, W, ld, st, in_lds); }
     template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)

@@ -1321,6 +1321,33 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st,
     return launch_gather<IO, Real>(p, j, st);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Measurement helpers (bench.py "hbm_ceiling"): what plain streaming kernels reach on this device,
+// so roofline fractions can be read against the achievable rate as well as the 8 TB/s spec.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_stream_copy(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_stream_read(float *__restrict__ sink, const float4 *__restrict__ src, size_t n)
+{
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4 v = src[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x; // never true for the test data; keeps the loads
+}
+const char *stream_kernel(void *dst, const void *src, size_t bytes, int mode, void *stream)
+{
+    const size_t n = bytes / sizeof(float4);
+    const unsigned blocks = 256 * 16; // 16 workgroups per CU, grid-stride
+    if (mode == 0) hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)dst, (const float4 *)src, n);
+    else hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float *)dst, (const float4 *)src, n);
+    HIP_TRY(hipGetLastError());
+    return nullptr;
+}
+
 const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr)
 {
     if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return nullptr;

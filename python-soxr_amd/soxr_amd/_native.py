@@ -95,6 +95,7 @@ SIGNATURES = {
     "hipsoxr_stream_engine": (C.c_char_p, [C.c_void_p]),
     "hipsoxr_stream_set_io_ratio": (_err, [C.c_void_p, C.c_double, C.c_size_t]),
     "hipsoxr_stream_plan": (C.c_void_p, [C.c_void_p]),
+    "hipsoxr_bench_stream": (_err, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "hipsoxr_oneshot": (_err, [C.c_double, C.c_double, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p,
                                C.c_size_t, _P(C.c_size_t), C.c_int, C.c_ulong, C.c_ulong]),
 }
