@@ -517,6 +517,9 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     const bool interior = a.ifs == 1 && ina >= 0 && inb + NA <= a.in_frames;
     const float *xa = xin + ina, *xb = xin + inb;
     Spec::fwd(cur, a.WA2, [&](int n) -> cf {
+#if defined(FFT_ABL) && (FFT_ABL & 2) // timing ablation (tools/fft_ablate.sh): no input loads
+        if (interior) return make_float2((float)n * 1e-3f, (float)(n ^ 5) * 1e-3f);
+#endif
         if (interior) return make_float2(xa[n], xb[n]);
         const int64_t la = ina + n, lb = inb + n;
         return make_float2((la >= 0 && la < a.in_frames) ? xin[la * a.ifs] : 0.f,
@@ -537,6 +540,9 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
         return y;
     };
     auto out_store = [&](int n, cf w) {
+#if defined(FFT_ABL) && (FFT_ABL & 1) // timing ablation: no output stores
+        if (w.x != 1234.5f) return;
+#endif
         if (n >= v0 && n < v1) {
             const int64_t ka = outa + n, kb = outb + n;
             if (ka >= 0 && ka < a.out_frames) yo[ka * a.ofs] = w.x;
