@@ -247,12 +247,15 @@ __device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store)
 #pragma unroll
             for (int t = 0; t < R; ++t) u[i][t] = load(j + t * nb);
             if (Ns > 1) {
-                cf w = w1;
+                // powers of the butterfly's twiddle by squaring (w^2t = (w^t)^2, w^(2t+1) = w^2t w):
+                // same number of complex products as a running product, but a dependency depth of
+                // log2 R instead of R, and rounding error that grows with log2 R
+                cf pw[R];
+                pw[1] = w1;
 #pragma unroll
-                for (int t = 1; t < R; ++t) {
-                    u[i][t] = cmul(u[i][t], w);
-                    if (t + 1 < R) w = cmul(w, w1);
-                }
+                for (int t = 2; t < R; ++t) pw[t] = (t & 1) ? cmul(pw[t - 1], w1) : cmul(pw[t / 2], pw[t / 2]);
+#pragma unroll
+                for (int t = 1; t < R; ++t) u[i][t] = cmul(u[i][t], pw[t]);
             }
             dft_r<R, SIGN>(u[i]);
         }
