@@ -33,13 +33,13 @@ for p in (ROOT, os.path.join(ROOT, "python-soxr_amd")):
         sys.path.insert(0, p)
 
 IN_RATE, OUT_RATE, QUALITY = 48000, 44100, "VHQ"
-KERNEL_NAMES = {0: "k_fft_block (AUTO: frequency-domain engine for large float32 device jobs)",
+KERNEL_NAMES = {0: "k_fft_pair (AUTO: frequency-domain engine, paired-block kernel, for large float32 device jobs)",
                 1: "k_gather<float,float>", 2: "k_tile_mfma_p<float>", 3: "k_tile<float,float,16,true>",
-                4: "k_tile_mfma_p<float>", 5: "k_fft_block", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
+                4: "k_tile_mfma_p<float>", 5: "k_fft_pair", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
 # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 +
-# WRITE_SIZE, see profiles/r01b_traffic.json); bench.py cannot collect counters itself.
-TRAFFIC_BYTES = {("configs1", 0): 24267674, ("configs1", 5): 24267674,
-                 ("batch_shard", 0): 489458074, ("batch_shard", 5): 489458074}  # profiles/r01c_traffic.json
+# WRITE_SIZE, see profiles/r01d_traffic.json); bench.py cannot collect counters itself.
+TRAFFIC_BYTES = {("configs1", 0): 25038848, ("configs1", 5): 25038848,
+                 ("batch_shard", 0): 518786252, ("batch_shard", 5): 518786252}  # profiles/r01d_traffic.json
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
@@ -177,6 +177,7 @@ def hbm_ceiling(device, n_bytes=1 << 29):
         e1.record()
         torch.cuda.synchronize(device)
         res[name + "_GBs"] = moved * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    res["best_copy_GBs"] = max(res["copy_GBs"], res["torch_copy_GBs"])
     res["note"] = "float4 grid-stride copy / read kernels (hipsoxr_bench_stream) and torch copy_, 512 MiB, HIP events"
     return res
 
@@ -276,10 +277,10 @@ def main():
         result["hbm_ceiling"] = ceil
         # the north star words its target against the HBM *read* roofline: input bytes only
         result["roofline"]["read_frac"] = 4.0 * n_in / kern / 1e9 / HBM_PEAK_GBS
-        result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / ceil["copy_GBs"]
+        result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / ceil["best_copy_GBs"]
         if "batch_shard" in result:
             result["batch_shard"]["roofline"]["frac_of_measured_copy"] = \
-                result["batch_shard"]["roofline"]["achieved"] / ceil["copy_GBs"]
+                result["batch_shard"]["roofline"]["achieved"] / ceil["best_copy_GBs"]
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(args.seconds)
     elif rank == 0:
