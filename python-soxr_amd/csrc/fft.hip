@@ -325,6 +325,7 @@ struct FftArgs {
     uint32_t n_clips, n_channels;
     int64_t ics, ifs, ichs, ocs, ofs, ochs;
     int64_t in_frames, out_frames;
+    int32_t chpair; // paired kernel: 1 = pair neighbouring channels of interleaved data instead of blocks
 };
 
 // butterflies per thread are bounded by N/(R*256) rounded up; lengths up to 4096
@@ -481,22 +482,27 @@ __global__ void __launch_bounds__(256, Spec::ct ? 5 : 2) k_fft_block(FftArgs a)
 // leaves 3 + 3 LDS passes per pair of blocks instead of 4 + 1 + 4 per block.
 // One workgroup = blocks (2b, 2b+1) of one column; one LDS buffer of N_in complex values.
 // ---------------------------------------------------------------------------------------------
-// 48k -> 44.1k family, k = 32: N_in = 5120 = 16*16*20, N_out = 4704 = 21*16*14
-struct Pair5120x4704 {
-    static constexpr int NA = 5120, NB = 4704, NT = 384;
+// Schedules: N_in = A0*A1*A2 (forward), N_out = B0*B1*B2 (inverse); *SWZ = swizzled layout after a
+// power-of-two first radix (see fft_ct3).  NT >= the largest butterfly count of any pass.
+template <int NA_, int NB_, int NT_, int A0, int A1, int A2, bool ASWZ, int B0, int B1, int B2, bool BSWZ>
+struct PairSpec {
+    static constexpr int NA = NA_, NB = NB_, NT = NT_;
     template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
-    { fft_ct3<5120, -1, NT, 16, 16, 20, true>(b, W, ld, st, in_lds); }
+    { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ>(b, W, ld, st, in_lds); }
     template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
-    { fft_ct3<4704, +1, NT, 21, 16, 14, false>(b, W, ld, st, in_lds); }
+    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ>(b, W, ld, st, in_lds); }
 };
-// same family, k = 16 (small jobs): N_in = 2560 = 16*16*10, N_out = 2352 = 21*16*7
-struct Pair2560x2352 {
-    static constexpr int NA = 2560, NB = 2352, NT = 384;
-    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
-    { fft_ct3<2560, -1, NT, 16, 16, 10, true>(b, W, ld, st, in_lds); }
-    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
-    { fft_ct3<2352, +1, NT, 21, 16, 7, false>(b, W, ld, st, in_lds); }
-};
+// 48k <-> 44.1k (L/M = 147/160 and 160/147): k = 32, and k = 16 for small jobs
+typedef PairSpec<5120, 4704, 384, 16, 16, 20, true, 21, 16, 14, false> Pair5120x4704;
+typedef PairSpec<2560, 2352, 384, 16, 16, 10, true, 21, 16, 7, false> Pair2560x2352;
+typedef PairSpec<4704, 5120, 384, 21, 16, 14, false, 16, 16, 20, true> Pair4704x5120;
+typedef PairSpec<2352, 2560, 384, 21, 16, 7, false, 16, 16, 10, true> Pair2352x2560;
+// 44.1k <-> 16k (160/441 and 441/160): k = 16
+typedef PairSpec<7056, 2560, 448, 21, 16, 21, false, 16, 16, 10, true> Pair7056x2560;
+typedef PairSpec<2560, 7056, 448, 16, 16, 10, true, 21, 16, 21, false> Pair2560x7056;
+// 2:1 and 1:2: k = 2048
+typedef PairSpec<4096, 2048, 256, 16, 16, 16, true, 16, 16, 8, true> Pair4096x2048;
+typedef PairSpec<2048, 4096, 256, 16, 16, 8, true, 16, 16, 16, true> Pair2048x4096;
 
 template <typename Spec>
 __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
@@ -504,12 +510,17 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *cur = reinterpret_cast<cf *>(smem_raw);
     constexpr int NA = Spec::NA, NB = Spec::NB;
-    static_assert(NA >= NB, "paired kernel is instantiated for down-sampling families");
 
+    // What is paired: two consecutive blocks of one column (planar / mono data), or — for
+    // interleaved data with an even channel count (a.chpair) — the same block of two neighbouring
+    // channels, whose samples are one aligned float2 in memory: loads and stores then move 8
+    // contiguous bytes per lane instead of two 4-byte words with a channel stride between lanes.
+    const bool cp = a.chpair != 0;
     const uint32_t col = blockIdx.y;
-    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
-    const int64_t pa = 2 * (int64_t)blockIdx.x * a.hop_periods - a.lead_periods; // first period of block a
-    const int64_t pb = pa + a.hop_periods;                                       // ... of block b
+    const uint32_t cpr = cp ? a.n_channels / 2 : a.n_channels;
+    const uint32_t ch = cp ? 2 * (col % cpr) : col % cpr, clip = col / cpr;
+    const int64_t pa = (cp ? 1 : 2) * (int64_t)blockIdx.x * a.hop_periods - a.lead_periods; // first period of block a
+    const int64_t pb = cp ? pa : pa + a.hop_periods;                                         // ... of block b
     const int64_t ina = pa * a.M, inb = pb * a.M, outa = pa * a.L, outb = pb * a.L;
     const float *xin = (const float *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
     auto lds_store = [&](int n, cf v) { cur[n] = v; };
@@ -517,16 +528,22 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
     // (one instantiation of the transform for interior and edge blocks alike, so that both run the
     // same instruction sequence and round identically)
-    const bool interior = a.ifs == 1 && ina >= 0 && inb + NA <= a.in_frames;
-    const float *xa = xin + ina, *xb = xin + inb;
+    const bool interior = ina >= 0 && inb + NA <= a.in_frames && a.ifs < (1 << 16);
+    const int32_t ifs32 = (int32_t)a.ifs;
+    const bool unit = a.ifs == 1 && !cp;
+    const float *xa = xin + ina * a.ifs, *xb = xin + inb * a.ifs;
     Spec::fwd(cur, a.WA2, [&](int n) -> cf {
 #if defined(FFT_ABL) && (FFT_ABL & 2) // timing ablation (tools/fft_ablate.sh): no input loads
         if (interior) return make_float2((float)n * 1e-3f, (float)(n ^ 5) * 1e-3f);
 #endif
-        if (interior) return make_float2(xa[n], xb[n]);
+        if (interior) {
+            if (unit) return make_float2(xa[n], xb[n]);           // planar / mono: the common fast path
+            if (cp) return *reinterpret_cast<const float2 *>(xa + n * ifs32);
+            return make_float2(xa[n * ifs32], xb[n * ifs32]);
+        }
         const int64_t la = ina + n, lb = inb + n;
         return make_float2((la >= 0 && la < a.in_frames) ? xin[la * a.ifs] : 0.f,
-                           (lb >= 0 && lb < a.in_frames) ? xin[lb * a.ifs] : 0.f);
+                           (lb >= 0 && lb < a.in_frames) ? xin[lb * a.ifs + (cp ? 1 : 0)] : 0.f);
     }, lds_store, false);
     __syncthreads();
 
@@ -536,11 +553,18 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out;
     auto h_load = [&](int n) -> cf {
         const bool neg = n > NB / 2;
-        cf h = a.Hs[neg ? NB - n : n];
+        const int q = neg ? NB - n : n; // |frequency| in bins
+        cf h = a.Hs[q];
         if (neg) h.y = -h.y;
-        cf y = cmul(cur[neg ? n + (NA - NB) : n], h);
-        if (n == NB / 2) y = cadd(y, cmul(cur[n + (NA - NB)], cconj(h)));
-        return y;
+        if constexpr (NA >= NB) { // down-sampling: the spectrum is truncated
+            cf y = cmul(cur[neg ? n + (NA - NB) : n], h);
+            if (n == NB / 2) y = cadd(y, cmul(cur[n + (NA - NB)], cconj(h)));
+            return y;
+        } else {                  // up-sampling: the spectrum is zero-extended
+            const bool in_band = q < NA / 2; // the input Nyquist bin itself carries only stop-band energy
+            const cf y = cmul(cur[in_band ? (neg ? NA - q : q) : 0], h);
+            return in_band ? y : make_float2(0.f, 0.f);
+        }
     };
     auto out_store = [&](int n, cf w) {
 #if defined(FFT_ABL) && (FFT_ABL & 1) // timing ablation: no output stores
@@ -548,10 +572,17 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
 #endif
         if (n >= v0 && n < v1) {
             const int64_t ka = outa + n, kb = outb + n;
-            // streaming (non-temporal) stores: the output is not read again by this launch, and
-            // keeping it out of L2's way is worth ~7 % on the batch workload (151 -> 140 us)
-            if (ka >= 0 && ka < a.out_frames) __builtin_nontemporal_store(w.x, &yo[ka * a.ofs]);
-            if (kb >= 0 && kb < a.out_frames) __builtin_nontemporal_store(w.y, &yo[kb * a.ofs]);
+            if (a.ofs == 1) {
+                // streaming (non-temporal) stores: the output is not read again by this launch, and
+                // keeping it out of L2's way is worth ~7 % on the batch workload (151 -> 140 us)
+                if (ka >= 0 && ka < a.out_frames) __builtin_nontemporal_store(w.x, &yo[ka]);
+                if (kb >= 0 && kb < a.out_frames) __builtin_nontemporal_store(w.y, &yo[kb]);
+            } else if (cp) { // one aligned float2 per frame
+                if (ka >= 0 && ka < a.out_frames) *reinterpret_cast<float2 *>(&yo[ka * a.ofs]) = w;
+            } else {
+                if (ka >= 0 && ka < a.out_frames) yo[ka * a.ofs] = w.x;
+                if (kb >= 0 && kb < a.out_frames) yo[kb * a.ofs] = w.y;
+            }
         }
     };
     Spec::inv(cur, a.WB2, h_load, out_store, true);
@@ -588,7 +619,7 @@ static bool factor_radices(int n, std::vector<int> &rad)
 }
 
 static std::mutex g_fft_mu;
-static std::vector<std::pair<std::pair<const Plan *, bool>, FftGeom>> g_fft; // key: (plan, small-block variant)
+static std::vector<std::pair<std::pair<const Plan *, int>, FftGeom>> g_fft; // key: (plan, geometry variant)
 
 void fft_release(const Plan *p)
 {
@@ -600,7 +631,7 @@ void fft_release(const Plan *p)
         } else ++i;
 }
 
-static const char *fft_build(const Plan &p, FftGeom *out, bool small)
+static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_k = 0)
 {
     FftGeom g;
     const int64_t L = p.L, M = p.M;
@@ -611,14 +642,14 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small)
     // candidates: power-of-two k with 7-smooth even half-lengths; take the largest block whose
     // transforms stay <= 2600 points (one 20 KB LDS buffer, least overlap waste), else the
     // smallest admissible one
-    for (int k = 1; k <= 4096; k *= 2) {
+    for (int k = force_k ? force_k : 1; k <= (force_k ? force_k : 4096); k *= 2) {
         const int64_t Nin = M * k, Nout = L * k;
         if (Nin % 2 || Nout % 2) continue;
-        if (Nin < 6 * (int64_t)T) continue;
+        if (!force_k && Nin < 6 * (int64_t)T) continue;
         if (Nin / 2 > 4096 || Nout / 2 > 4096) break;
         std::vector<int> ra, rb;
         if (!factor_radices((int)(Nin / 2), ra) || !factor_radices((int)(Nout / 2), rb)) continue;
-        if (g.k && (small || std::max(Nin, Nout) / 2 > 2600)) break;
+        if (!force_k && g.k && (small || std::max(Nin, Nout) / 2 > 2600)) break;
         g.k = k; g.N_in = (int32_t)Nin; g.N_out = (int32_t)Nout; g.A = g.N_in / 2; g.B = g.N_out / 2;
         g.radA = ra; g.radB = rb;
     }
@@ -633,6 +664,8 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small)
     g.hop_out = (int32_t)(g.hop_periods * L);
     g.lds_bytes = (size_t)(std::max(g.A, g.B) + 8) * sizeof(float2);
     if (g.lds_bytes > 150 * 1024) { *out = g; return nullptr; }
+    // a block must keep a worthwhile share of its outputs (long filters on short blocks do not)
+    if (force_k && 2 * (int64_t)g.hop_out < g.N_out) { *out = g; return nullptr; }
 
     const int A = g.A, B = g.B;
     std::vector<float2> tab((size_t)A + B + (A + 1) + B + (B + 1) + g.N_in + g.N_out);
@@ -684,23 +717,91 @@ bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &j)
 const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *handled)
 {
     *handled = false;
-    auto get = [&](bool small, FftGeom *g) -> const char * {
+    // geometry cache key: (plan, variant) with variant 0 = default search, 1 = small-block search,
+    // 2 + i = forced k of paired-kernel entry i
+    auto get = [&](int variant, int force_k, FftGeom *g) -> const char * {
         std::lock_guard<std::mutex> lk(g_fft_mu);
         for (auto &e : g_fft)
-            if (e.first.first == p && e.first.second == small) { *g = e.second; return nullptr; }
-        if (const char *err = fft_build(*p, g, small)) return err;
-        g_fft.push_back({{p, small}, *g});
+            if (e.first.first == p && e.first.second == variant) { *g = e.second; return nullptr; }
+        if (const char *err = fft_build(*p, g, variant == 1, force_k)) return err;
+        g_fft.push_back({{p, variant}, *g});
         return nullptr;
     };
+    // ---- paired-block kernels: compile-time schedules for the common ratios -------------------
+    struct PairEntry { int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; };
+    static const PairEntry pairs[] = {
+        {147, 160, 32, false, k_fft_pair<Pair5120x4704>, Pair5120x4704::NT},
+        {147, 160, 16, true, k_fft_pair<Pair2560x2352>, Pair2560x2352::NT},
+        {160, 147, 32, false, k_fft_pair<Pair4704x5120>, Pair4704x5120::NT},
+        {160, 147, 16, true, k_fft_pair<Pair2352x2560>, Pair2352x2560::NT},
+        {160, 441, 16, false, k_fft_pair<Pair7056x2560>, Pair7056x2560::NT},
+        {441, 160, 16, false, k_fft_pair<Pair2560x7056>, Pair2560x7056::NT},
+        {1, 2, 2048, false, k_fft_pair<Pair4096x2048>, Pair4096x2048::NT},
+        {2, 1, 2048, false, k_fft_pair<Pair2048x4096>, Pair2048x4096::NT},
+    };
+    static const bool no_pair = getenv("HIPSOXR_FFT_NO_PAIR") != nullptr;
+    const uint64_t cols_p = (uint64_t)j.n_clips * j.n_channels;
+    if (!no_pair && cols_p <= 65535) {
+        const PairEntry *big = nullptr, *sml = nullptr;
+        int big_i = 0, sml_i = 0;
+        for (int i = 0; i < (int)(sizeof pairs / sizeof pairs[0]); ++i)
+            if (pairs[i].L == p->L && pairs[i].M == p->M) {
+                if (pairs[i].small) { sml = &pairs[i]; sml_i = i; } else { big = &pairs[i]; big_i = i; }
+            }
+        if (big) {
+            FftGeom g;
+            if (const char *err = get(2 + big_i, big->k, &g)) return err;
+            const PairEntry *use = g.ok ? big : nullptr;
+            if (g.ok && sml) {
+                // few work items (one 60 s clip = 300 pairs): half-size blocks give twice as many,
+                // shorter workgroups, at the price of more overlap
+                const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
+                if ((wgs < 4 * 256 && !getenv("HIPSOXR_FFT_LARGE_ONLY")) || getenv("HIPSOXR_FFT_SMALL_ONLY")) {
+                    FftGeom gs;
+                    if (const char *err = get(2 + sml_i, sml->k, &gs)) return err;
+                    if (gs.ok) { g = gs; use = sml; }
+                }
+            }
+            if (use) {
+                FftArgs a;
+                a.in = j.in; a.out = j.out;
+                a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
+                a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
+                a.A = g.A; a.B = g.B; a.nA = a.nB = 0;
+                for (int i = 0; i < 8; ++i) a.radA[i] = a.radB[i] = 1;
+                a.L = p->L; a.M = p->M;
+                a.lead_periods = g.lead_periods; a.hop_periods = g.hop_periods; a.v0 = g.v0; a.hop_out = g.hop_out;
+                a.n_clips = j.n_clips; a.n_channels = j.n_channels;
+                a.ics = j.in_clip_stride; a.ifs = j.in_frame_stride; a.ichs = j.in_chan_stride;
+                a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
+                a.in_frames = j.in_frames; a.out_frames = j.out_frames;
+                const int64_t n_blocks = (j.out_frames + g.hop_out - 1) / g.hop_out;
+                if (n_blocks > 2147483647LL) return "job too long for one launch";
+                // interleaved data with an even channel count: pair channels (aligned float2 per frame)
+                a.chpair = (j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1 &&
+                            j.in_frame_stride % 2 == 0 && j.out_frame_stride % 2 == 0 && j.in_clip_stride % 2 == 0 &&
+                            j.out_clip_stride % 2 == 0 && ((uintptr_t)j.in & 7) == 0 && ((uintptr_t)j.out & 7) == 0 &&
+                            !getenv("HIPSOXR_FFT_NO_CHPAIR")) ? 1 : 0;
+                const size_t lds = (size_t)std::max(g.N_in, g.N_out) * sizeof(float2);
+                if (lds > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void *)use->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                const dim3 grid = a.chpair ? dim3((unsigned)n_blocks, (unsigned)(cols_p / 2), 1)
+                                           : dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols_p, 1);
+                hipLaunchKernelGGL(use->kern, grid, dim3(use->nt), lds, (hipStream_t)stream, a);
+                HIP_TRY(hipGetLastError());
+                *handled = true;
+                return nullptr;
+            }
+        }
+    }
+    // ---- general path: one block per workgroup ---------------------------------------------------
     FftGeom g;
-    if (const char *err = get(false, &g)) return err;
+    if (const char *err = get(0, 0, &g)) return err;
     if (g.ok) {
-        // few blocks (e.g. one 60 s clip = 600): half-size blocks give twice as many workgroups of
-        // half the latency, at the price of more overlap
         const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out) * (int64_t)j.n_clips * j.n_channels;
         if ((wgs < 8 * 256 && !getenv("HIPSOXR_FFT_LARGE_ONLY")) || getenv("HIPSOXR_FFT_SMALL_ONLY")) {
             FftGeom gs;
-            if (const char *err = get(true, &gs)) return err;
+            if (const char *err = get(1, 0, &gs)) return err;
             if (gs.ok && gs.k < g.k) g = gs;
         }
     }
@@ -721,19 +822,6 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
     if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";
     if (n_blocks > 2147483647LL) return "job too long for one launch";
-    // paired-block kernels (compile-time schedules of the 147/160 family)
-    static const bool no_pair = getenv("HIPSOXR_FFT_NO_PAIR") != nullptr;
-    if (!no_pair && ((g.N_in == 5120 && g.N_out == 4704) || (g.N_in == 2560 && g.N_out == 2352))) {
-        const bool big = g.N_in == 5120;
-        void (*pk)(FftArgs) = big ? k_fft_pair<Pair5120x4704> : k_fft_pair<Pair2560x2352>;
-        const unsigned nt = big ? Pair5120x4704::NT : Pair2560x2352::NT;
-        const size_t lds = (size_t)g.N_in * sizeof(float2);
-        hipLaunchKernelGGL(pk, dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols, 1), dim3(nt), lds,
-                           (hipStream_t)stream, a);
-        HIP_TRY(hipGetLastError());
-        *handled = true;
-        return nullptr;
-    }
     void (*kern)(FftArgs) = k_fft_block<SpecRuntime>;
     if (g.A == 2560 && g.B == 2352) kern = k_fft_block<Spec2560x2352>; // compile-time radix schedules
     if (g.A == 1280 && g.B == 1176) kern = k_fft_block<Spec1280x1176>; // for the 147/160 family
