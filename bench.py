@@ -264,6 +264,22 @@ def main():
                          "launch_us": bkern * 1e6, "direct_form_equiv_tflops": bflops / bkern / 1e12}}
         del xb, yb
 
+    # ---- configs[2] (context line, not the headline): 60 s x 8 channels interleaved, 44.1k -> 16k VHQ
+    if not args.no_batch and world == 1:
+        try:
+            plan2 = dev.Plan(44100, 16000, QUALITY)
+            x2 = torch.randn((44100 * args.seconds, 8), device=device, dtype=torch.float32, generator=g) * 0.25
+            w2, k2, y2 = time_workload(plan2, x2, max(5, args.steps // 10), 2, world, device, args.kernel)
+            bytes2 = 4.0 * (x2.numel() + y2.numel())
+            result["configs2"] = {"workload": f"BASELINE configs[2]: VHQ 44100->16000 float32, {args.seconds} s x 8 ch "
+                                              f"interleaved [frames, 8], device-resident",
+                                  "value": x2.numel() / k2 / 1e6, "unit": "Msamples/s", "launch_us": k2 * 1e6,
+                                  "roofline": {"bound": "hbm", "achieved": bytes2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
+                                               "unit": "GB/s", "frac": bytes2 / k2 / 1e9 / HBM_PEAK_GBS}}
+            del x2, y2, plan2
+        except RuntimeError as e:  # context only
+            result["configs2"] = {"error": str(e)}
+
     # the canonical-order (bit-exact) engine on the same workloads, for reference
     if args.kernel == 0 and world == 1:
         ew, ek, _ = time_workload(plan, x, max(10, args.steps // 4), 5, world, device, kernel=6)

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -20,6 +21,14 @@ using namespace hipsoxr;
 
 struct hipsoxr_plan {
     Plan p;
+    // plan cache (streams / one-shot calls created from rates): key and use count
+    bool cached = false;
+    double key_in = 0, key_out = 0;
+    unsigned long key_recipe = 0;
+    bool key_vr = false;
+    int key_device = -1;
+    int users = 0;
+    uint64_t last_use = 0;
 };
 
 namespace hipsoxr {
@@ -86,6 +95,78 @@ struct hipsoxr_stream {
 static const char *kNoDevice = "no HIP device available (hipsoxr has no CPU fallback)";
 
 // ------------------------------------------------------------------------------------------------
+// Plan cache.  soxr.resample designs a filter per call in the reference (soxr_create inside
+// csoxr_divide_proc, src/soxr_ext.cpp:230); here the design, its device tables and the FFT
+// geometry are kept and shared by every later stream / one-shot call with the same
+// (rates, recipe, device): a repeated call pays for transfers and launches only.
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_cache_mu;
+static std::vector<hipsoxr_plan *> g_cache;
+static uint64_t g_cache_clock = 0;
+static const size_t kCacheMax = 32;
+
+static const char *plan_acquire(double in_rate, double out_rate, unsigned long recipe, bool vr, hipsoxr_plan **out)
+{
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (hipsoxr_plan *h : g_cache)
+        if (h->key_in == in_rate && h->key_out == out_rate && h->key_recipe == recipe && h->key_vr == vr &&
+            h->key_device == dev) {
+            ++h->users; h->last_use = ++g_cache_clock;
+            *out = h;
+            return nullptr;
+        }
+    hipsoxr_plan *h = new (std::nothrow) hipsoxr_plan();
+    if (!h) return "out of memory";
+    if (const char *e = plan_design(in_rate, out_rate, recipe, &h->p, vr)) { delete h; return e; }
+    h->cached = true; h->key_in = in_rate; h->key_out = out_rate; h->key_recipe = recipe; h->key_vr = vr;
+    h->key_device = dev; h->users = 1; h->last_use = ++g_cache_clock;
+    if (g_cache.size() >= kCacheMax) { // evict the least recently used idle plan
+        size_t victim = g_cache.size();
+        for (size_t i = 0; i < g_cache.size(); ++i)
+            if (g_cache[i]->users == 0 && (victim == g_cache.size() || g_cache[i]->last_use < g_cache[victim]->last_use))
+                victim = i;
+        if (victim < g_cache.size()) { delete g_cache[victim]; g_cache.erase(g_cache.begin() + (long)victim); }
+    }
+    g_cache.push_back(h);
+    *out = h;
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stream-resource pool: HIP stream + device staging buffers of finished streams, handed to the
+// next stream on the same device (hipMalloc / hipFree / hipStreamCreate cost more than resampling a
+// short clip).  Capacities are kept in bytes; at most kPoolMax shells, kPoolBytes in total.
+// ------------------------------------------------------------------------------------------------
+struct StreamShell {
+    int device = -1;
+    hipStream_t st = nullptr;
+    void *d_in = nullptr, *d_in_alt = nullptr, *d_out = nullptr;
+    size_t in_bytes = 0, alt_bytes = 0, out_bytes = 0;
+    uint64_t *d_clips = nullptr;
+};
+static std::mutex g_pool_mu;
+static std::vector<StreamShell> g_pool;
+static const size_t kPoolMax = 8, kPoolBytes = (size_t)1 << 30;
+
+static void shell_free(StreamShell &sh)
+{
+    if (sh.d_in) (void)hipFree(sh.d_in);
+    if (sh.d_in_alt) (void)hipFree(sh.d_in_alt);
+    if (sh.d_out) (void)hipFree(sh.d_out);
+    if (sh.d_clips) (void)hipFree(sh.d_clips);
+    if (sh.st) (void)hipStreamDestroy(sh.st);
+    sh = StreamShell();
+}
+
+static void plan_release(hipsoxr_plan *h)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (h->users > 0) --h->users;
+}
+
+// ------------------------------------------------------------------------------------------------
 // library / plan
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -135,6 +216,7 @@ hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *h, const double *src, size
 {
     if (!h || !src) return "null argument";
     if (n != h->p.bank.size()) return "bank size mismatch";
+    if (h->cached) return "this plan is shared through the plan cache (it belongs to a stream); create one with hipsoxr_plan_create";
     device_bank_release(&h->p);
     fft_release(&h->p);
     std::memcpy(h->p.bank.data(), src, n * sizeof(double));
@@ -377,10 +459,29 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
     }
     const char *err = nullptr;
     do {
-        if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (size_t i = 0; i < g_pool.size(); ++i)
+                if (g_pool[i].device == dev) {
+                    StreamShell sh = g_pool[i];
+                    g_pool.erase(g_pool.begin() + (long)i);
+                    const size_t frame = (size_t)ch * esz(s);
+                    s->st = sh.st; s->d_clips = sh.d_clips;
+                    s->d_in = sh.d_in; s->in_cap = sh.in_bytes / frame;
+                    s->d_in_alt = sh.d_in_alt; s->alt_cap = sh.alt_bytes / frame;
+                    s->d_out = sh.d_out; s->out_cap = sh.out_bytes / frame;
+                    if (!s->in_cap && s->d_in) { (void)hipFree(s->d_in); s->d_in = nullptr; }
+                    if (!s->alt_cap && s->d_in_alt) { (void)hipFree(s->d_in_alt); s->d_in_alt = nullptr; }
+                    if (!s->out_cap && s->d_out) { (void)hipFree(s->d_out); s->d_out = nullptr; }
+                    break;
+                }
+        }
+        if (!s->st && hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
             err = "hipStreamCreate failed"; break;
         }
-        if (hipMalloc((void **)&s->d_clips, sizeof(uint64_t)) != hipSuccess) {
+        if (!s->d_clips && hipMalloc((void **)&s->d_clips, sizeof(uint64_t)) != hipSuccess) {
             err = "hipMalloc failed"; break;
         }
         if (hipMemsetAsync(s->d_clips, 0, sizeof(uint64_t), s->st) != hipSuccess) {
@@ -407,16 +508,13 @@ hipsoxr_error_t hipsoxr_stream_create(double in_rate, double out_rate, unsigned 
     if (!out) return "null argument";
     *out = nullptr;
     hipsoxr_plan_t *plan = nullptr;
-    if (flags & HIPSOXR_VR) { // positions are not tied to L/M: always the interpolated-phase table
-        plan = new (std::nothrow) hipsoxr_plan();
-        if (!plan) return "out of memory";
-        if (const char *e = plan_design(in_rate, out_rate, recipe, &plan->p, true)) { delete plan; return e; }
-    } else if (const char *e = hipsoxr_plan_create(in_rate, out_rate, recipe, &plan)) return e;
+    // variable rate: positions are not tied to L/M, always the interpolated-phase table
+    if (const char *e = plan_acquire(in_rate, out_rate, recipe, (flags & HIPSOXR_VR) != 0, &plan)) return e;
     if (const char *e = stream_new(plan, false, num_channels, io_type, flags, out)) {
-        hipsoxr_plan_delete(plan);
+        plan_release(plan);
         return e;
     }
-    (*out)->own_plan = true;
+    (*out)->own_plan = true; // "own" = holds a reference of the cached plan
     return nullptr;
 }
 
@@ -433,12 +531,22 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
 {
     if (!s) return;
     if (s->st) (void)hipStreamSynchronize(s->st);
-    if (s->d_in) (void)hipFree(s->d_in);
-    if (s->d_in_alt) (void)hipFree(s->d_in_alt);
-    if (s->d_out) (void)hipFree(s->d_out);
-    if (s->d_clips) (void)hipFree(s->d_clips);
-    if (s->st) (void)hipStreamDestroy(s->st);
-    if (s->own_plan) delete s->plan;
+    StreamShell sh;
+    (void)hipGetDevice(&sh.device);
+    const size_t frame = (size_t)s->ch * esz(s);
+    sh.st = s->st; sh.d_clips = s->d_clips;
+    sh.d_in = s->d_in; sh.in_bytes = s->d_in ? s->in_cap * frame : 0;
+    sh.d_in_alt = s->d_in_alt; sh.alt_bytes = s->d_in_alt ? s->alt_cap * frame : 0;
+    sh.d_out = s->d_out; sh.out_bytes = s->d_out ? s->out_cap * frame : 0;
+    bool pooled = false;
+    if (sh.st && sh.d_clips) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t total = sh.in_bytes + sh.alt_bytes + sh.out_bytes;
+        for (const StreamShell &o : g_pool) total += o.in_bytes + o.alt_bytes + o.out_bytes;
+        if (g_pool.size() < kPoolMax && total <= kPoolBytes) { g_pool.push_back(sh); pooled = true; }
+    }
+    if (!pooled) shell_free(sh);
+    if (s->own_plan) plan_release(s->plan);
     delete s;
 }
 
