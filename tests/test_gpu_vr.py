@@ -48,6 +48,31 @@ def test_vr_stream_bit_exact_vs_oracle(soxr, oracle, dtype, quality):
     assert rs.delay() < 2
 
 
+@pytest.mark.parametrize("chunk", [441, 4410])
+def test_configs4_variable_rate_int16_44k1_to_16k_chunked(soxr, oracle, chunk):
+    """BASELINE configs[4]: ResampleStream variable-rate 44100 -> 16000 int16, chunked input, state
+    carried on the device across calls; the ratio is moved mid-stream and back."""
+    rng = np.random.default_rng(chunk)
+    x = (rng.standard_normal(44100) * 5000).astype(np.int16)
+    rs = soxr.ResampleStream(44100, 16000, 1, dtype="int16", quality="VHQ", vr=True)
+    sim = VrSim(oracle, 44100, 16000, "VHQ", np.int16)
+    got, want = [], []
+    for i in range(0, len(x), chunk):
+        last = i + chunk >= len(x)
+        if i == 5 * chunk:
+            rs.set_io_ratio(44100, 22050, 300)
+            sim.set_io_ratio(44100 / 22050, 300)
+        if i == 8 * chunk:
+            rs.set_io_ratio(44100, 16000, 0)
+            sim.set_io_ratio(44100 / 16000, 0)
+        got.append(rs.resample_chunk(x[i:i + chunk], last=last))
+        want.append(sim.feed(x[i:i + chunk], last=last))
+        assert len(got[-1]) == len(want[-1])
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert got.dtype == np.int16 and np.array_equal(got, want)
+    assert rs.num_clips() == 0
+
+
 def test_vr_multichannel_and_chunking_of_calls(soxr, oracle):
     """Channels share the clock; cutting the same input into different process calls between the
     same ratio changes gives the same samples."""
