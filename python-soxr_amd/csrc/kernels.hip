@@ -262,6 +262,220 @@ __global__ void __launch_bounds__(256) k_interp(InterpArgs ia)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_interp_tile — throughput kernel for interpolated-phase plans and variable-rate launches
+// ---------------------------------------------------------------------------------------------
+// k_interp is bound by the texture-address path: the 64 lanes of a wave sit in 64 different phase
+// intervals, so every tap fetches 64 different 16-byte cubic records (1.9 Gsamples/s at VHQ).
+// Here a workgroup takes KO consecutive outputs of one column, stages their input span in LDS, and
+// SORTS the outputs by phase interval (counting sort in LDS).  A wave then processes outputs of ONE
+// interval at a time: the interval's cubic records are wave-uniform (one broadcast load per tap
+// instead of 64 scattered ones), each lane reads its own input window from LDS.
+// Same canonical arithmetic per output as k_interp / the oracle, so results stay bit-identical.
+struct InterpTileArgs {
+    InterpArgs ia;
+    int32_t KO;        // outputs per workgroup
+    int32_t span_cap;  // staged input samples (>= span of any workgroup)
+};
+
+template <typename Real> struct InterpPos { int64_t n0; uint32_t iv; uint64_t xq; };
+
+template <typename Real, bool VR>
+__device__ __forceinline__ InterpPos<Real> interp_locate(const InterpArgs &ia, int64_t idx)
+{
+    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
+    const GatherArgs &a = ia.g;
+    InterpPos<Real> r;
+    const int32_t H = a.T / 2;
+    if (VR) {
+        typedef unsigned __int128 u128;
+        const u128 T0 = ((u128)ia.t_hi << 64) | ia.t_lo, S0 = ((u128)ia.s_hi << 64) | ia.s_lo,
+                   D = ((u128)ia.d_hi << 64) | ia.d_lo;
+        const uint64_t i = (uint64_t)idx, m = i * (i - 1) / 2;
+        const u128 tt = T0 + (u128)i * S0 + D * (u128)(i ? m : 0);
+        const uint64_t frac = (uint64_t)tt;
+        r.n0 = (int64_t)(uint64_t)(tt >> 64) - (H - 1);
+        r.iv = ia.lgP ? (uint32_t)(frac >> (64 - ia.lgP)) : 0u;
+        r.xq = (frac << ia.lgP) >> (64 - SH);
+    } else {
+        const int64_t t = a.p0 + idx * a.M;
+        const int64_t q = t / a.L;
+        const uint64_t rr = (uint64_t)(t - q * a.L);
+        const uint64_t tp = rr * (uint64_t)ia.P, rem = tp % (uint64_t)a.L;
+        r.iv = (uint32_t)(tp / (uint64_t)a.L);
+        r.xq = (rem << SH) / (uint64_t)a.L;
+        r.n0 = a.d0 + q - (H - 1);
+    }
+    return r;
+}
+
+// floor(t / L) and t mod L for 0 <= t < 2^51, 0 < L < 2^31, through one double-precision multiply
+// and a +-1 correction (exact: the estimate is off by at most one).  Integer division proper costs
+// ~80 VALU instructions on this hardware and the tile kernel needs three per output.
+__device__ __forceinline__ uint64_t divmod_small(uint64_t t, uint32_t L, double invL, uint32_t *rem)
+{
+    uint64_t q = (uint64_t)((double)t * invL);
+    int64_t r = (int64_t)(t - q * (uint64_t)L);
+    if (r < 0) { --q; r += L; }
+    else if (r >= (int64_t)L) { ++q; r -= L; }
+    *rem = (uint32_t)r;
+    return q;
+}
+
+// interp_locate for local output i of a workgroup whose first output sits at (q_base, r_base):
+// (k_base + i) * M = L * (q_base + q) + r  with  r_base + i*M = L*q + r,  i*M < 2^45.
+template <typename Real>
+__device__ __forceinline__ InterpPos<Real> interp_locate_local(const InterpArgs &ia, int64_t n0_base, uint32_t r_base,
+                                                               double invL, int32_t i)
+{
+    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
+    const uint32_t L = (uint32_t)ia.g.L;
+    InterpPos<Real> p;
+    uint32_t r, rem;
+    const uint64_t q = divmod_small((uint64_t)r_base + (uint64_t)i * (uint64_t)ia.g.M, L, invL, &r);
+    p.n0 = n0_base + (int64_t)q;
+    p.iv = (uint32_t)divmod_small((uint64_t)r * (uint64_t)ia.P, L, invL, &rem);
+    // floor(rem * 2^SH / L) by long division in two digits of SH/2 bits (each dividend < 2^47)
+    uint32_t rem2;
+    const uint64_t hi = divmod_small((uint64_t)rem << (SH / 2), L, invL, &rem2);
+    const uint64_t lo = divmod_small((uint64_t)rem2 << (SH / 2), L, invL, &rem);
+    p.xq = (hi << (SH / 2)) | lo;
+    return p;
+}
+
+template <typename IO, typename Real, bool VR>
+__global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const InterpArgs &ia = ta.ia;
+    const GatherArgs &a = ia.g;
+    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
+    const int32_t KO = ta.KO, P = ia.P, T = a.T, H = T / 2;
+    Real *xs = reinterpret_cast<Real *>(smem_raw);                       // [span_cap]
+    uint64_t *rec = reinterpret_cast<uint64_t *>(xs + ta.span_cap);      // [KO]  iv:8 | n0_local:24 | xq:32
+    uint16_t *order = reinterpret_cast<uint16_t *>(rec + KO);            // [KO]  outputs sorted by interval
+    uint32_t *off = reinterpret_cast<uint32_t *>(order + KO);            // [P + 1] bucket offsets
+    uint32_t *cur = off + (P + 1);                                       // [P]     scatter cursors
+
+    const uint32_t col = blockIdx.y;
+    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    const int64_t o_base = (int64_t)blockIdx.x * KO;
+    const int32_t n_here = (int32_t)((a.out_frames - o_base) < KO ? (a.out_frames - o_base) : KO);
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+
+    // span of inputs this workgroup needs (positions are monotonic in the output index)
+    const int64_t n_first = interp_locate<Real, VR>(ia, o_base).n0;
+    const int64_t n_end = interp_locate<Real, VR>(ia, o_base + n_here - 1).n0 + T;
+    const int32_t span = (int32_t)(n_end - n_first);
+    // rational mode: position of the workgroup's first output, then cheap local arithmetic
+    uint32_t r_base = 0;
+    double invL = 0.;
+    if (!VR) {
+        const int64_t t = a.p0 + o_base * a.M;
+        r_base = (uint32_t)(t - (t / a.L) * a.L);
+        invL = 1. / (double)a.L;
+    }
+    auto locate = [&](int i) -> InterpPos<Real> {
+        if (VR) return interp_locate<Real, VR>(ia, o_base + i);
+        return interp_locate_local<Real>(ia, n_first, r_base, invL, i);
+    };
+
+    for (int i = threadIdx.x; i <= 2 * P; i += blockDim.x) off[i] = 0; // off[0..P] and cur[0..P-1] are contiguous
+    __syncthreads();
+    // 1. locate every output once; histogram of intervals
+    for (int i = threadIdx.x; i < n_here; i += blockDim.x) {
+        const InterpPos<Real> r = locate(i);
+        rec[i] = ((uint64_t)r.iv << 56) | ((uint64_t)(uint32_t)(r.n0 - n_first) << 32) | (uint64_t)(uint32_t)r.xq;
+        atomicAdd(&off[r.iv + 1], 1u);
+    }
+    // 2. stage the input span (zero outside the signal), converted to the engine precision
+    for (int m = threadIdx.x; m < span; m += blockDim.x) {
+        const int64_t l = n_first + m - a.in_abs0;
+        xs[m] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) { // inclusive scan of off[1..P] (P <= 256 = 64 lanes x 4) by the first wave
+        const int l = threadIdx.x;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (4 * l + e < P) ? off[1 + 4 * l + e] : 0u; sum += v[e]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (l >= d) incl += up;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { run += v[e]; if (4 * l + e < P) off[1 + 4 * l + e] = run; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_here; i += blockDim.x) {
+        const uint32_t iv = (uint32_t)(rec[i] >> 56);
+        order[off[iv] + atomicAdd(&cur[iv], 1u)] = (uint16_t)i;
+    }
+    __syncthreads();
+
+    // 3. one interval at a time per wave.  The interval's cubic records are the same for all 64
+    //    lanes, so they must not go through the vector memory path (a lane-uniform
+    //    global_load_dwordx4 still costs 64 x 16 bytes of texture-address bandwidth: measured
+    //    TA-bound at 640 us) — they are read four taps at a time with one scalar s_load_dwordx16
+    //    (wave-uniform pointer in the constant address space) and used as SGPR operands.
+    const int lane = threadIdx.x & 63;
+    const int n_waves = blockDim.x >> 6;
+    typedef Real RealX16 __attribute__((ext_vector_type(16)));
+    typedef const __attribute__((address_space(4))) RealX16 *CPtr16;
+    for (int iv_ = threadIdx.x >> 6; iv_ < P; iv_ += n_waves) {
+        const int iv = __builtin_amdgcn_readfirstlane(iv_);
+        const uint32_t b0 = __builtin_amdgcn_readfirstlane(off[iv]), b1 = __builtin_amdgcn_readfirstlane(off[iv + 1]);
+        CPtr16 row = (CPtr16)((const Real *)ia.tab + (size_t)iv * T * 4); // row[b] = taps 4b .. 4b+3
+        for (uint32_t g = b0; g < b1; g += 64) {
+            // the 64 outputs of this group, sorted by index across the lanes (bitonic, in registers):
+            // consecutive lanes then read input windows a near-constant distance apart, which keeps
+            // the per-tap ds_read_b32 spread over the LDS banks (the counting sort scatters within a
+            // bucket in arrival order)
+            uint32_t key = g + lane < b1 ? order[g + lane] : 0xFFFFu;
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    const uint32_t other = __shfl_xor(key, jj, 64);
+                    const bool take_min = ((lane & k) == 0) == ((lane & jj) == 0);
+                    key = take_min ? (key < other ? key : other) : (key > other ? key : other);
+                }
+            const bool live = key != 0xFFFFu;
+            const int i = live ? (int)key : (int)order[b0];
+            const uint64_t rc = rec[i];
+            const Real *xl = xs + (uint32_t)((rc >> 32) & 0xFFFFFFu);
+            const Real xx = (Real)(uint32_t)rc * (Real)(1. / (double)(1ULL << SH));
+            Real accL = 0, accR = 0;
+#pragma unroll 2
+            for (int b = 0; b < H / 4; ++b) { // T is a multiple of 8: H is a multiple of 4
+                const RealX16 c = row[b];
+                const Real *x4 = xl + 4 * b;
+                accL = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accL);
+                accL = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accL);
+                accL = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accL);
+                accL = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accL);
+            }
+#pragma unroll 2
+            for (int b = T / 4 - 1; b >= H / 4; --b) { // descending taps
+                const RealX16 c = row[b];
+                const Real *x4 = xl + 4 * b;
+                accR = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accR);
+                accR = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accR);
+                accR = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accR);
+                accR = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accR);
+            }
+            if (live) {
+                const int64_t idx = o_base + i;
+                store_out<Real>(yo + idx * a.ofs, accL + accR, a.oc, ch, a.out_k0 + idx);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_tile
 // ---------------------------------------------------------------------------------------------
 // Geometry (host-built, see build_tile_tables): the plan's period may be replicated c times so
@@ -1181,6 +1395,49 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             std::memset(&ia, 0, sizeof ia);
             ia.g = a; ia.tab = d.interp_tab; ia.P = p->phases;
             while ((1 << ia.lgP) < ia.P) ++ia.lgP;
+            // throughput kernel for large launches: KO outputs per workgroup, as many as LDS allows
+            // (input span + 10 bytes of bookkeeping per output), at least ~32 outputs per interval
+            static const bool no_itile = getenv("HIPSOXR_NO_INTERP_TILE") != nullptr;
+            int64_t KO = 0, span_cap = 0;
+            if (!no_itile && nf >= 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
+                double step = (double)p->M / (double)p->L; // input samples per output
+                if (vr) {
+                    const double two64 = 18446744073709551616.;
+                    const double s0 = (double)vr->s_hi + (double)vr->s_lo / two64;
+                    const double dd = (double)(int64_t)vr->d_hi + (double)vr->d_lo / two64;
+                    step = std::max(s0, s0 + dd * (double)(done + nf)) * (1. + 1e-9);
+                }
+                // a bucket (outputs of one interval) is served 64 at a time: aim at a mean of 60 per
+                // interval (30, 15 when LDS cannot hold that many outputs and their input span)
+                for (int per = 60; per >= 15 && !KO; per /= 2) {
+                    const int64_t k = (int64_t)per * p->phases;
+                    if (k > 15360 || k > nf) continue;
+                    span_cap = (int64_t)std::ceil((double)k * step) + p->T + 8;
+                    const int64_t bytes = span_cap * (int64_t)sizeof(Real) + k * 10 + (2 * p->phases + 2) * 4 + 64;
+                    if (bytes <= 150 * 1024) KO = k;
+                }
+            }
+            if (KO) {
+                InterpTileArgs ta;
+                ta.ia = ia; ta.KO = (int32_t)KO; ta.span_cap = (int32_t)((span_cap + 1) / 2 * 2);
+                if (vr) { // positions relative to the first output of this chunk
+                    typedef unsigned __int128 u128;
+                    const u128 T0 = ((u128)vr->t_hi << 64) | vr->t_lo, S0 = ((u128)vr->s_hi << 64) | vr->s_lo,
+                               D = ((u128)vr->d_hi << 64) | vr->d_lo;
+                    const u128 n = (u128)(uint64_t)done, m = n * (n - 1) / 2;
+                    const u128 T1 = T0 + n * S0 + D * (done ? m : 0), S1 = S0 + D * n;
+                    ta.ia.t_hi = (uint64_t)(T1 >> 64); ta.ia.t_lo = (uint64_t)T1;
+                    ta.ia.s_hi = (uint64_t)(S1 >> 64); ta.ia.s_lo = (uint64_t)S1;
+                    ta.ia.d_hi = vr->d_hi; ta.ia.d_lo = vr->d_lo;
+                }
+                const size_t lds = (size_t)ta.span_cap * sizeof(Real) + (size_t)KO * 10 + (size_t)(2 * p->phases + 2) * 4 + 64;
+                const dim3 tgrid((unsigned)((nf + KO - 1) / KO), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1);
+                void (*tk)(InterpTileArgs) = vr ? k_interp_tile<IO, Real, true> : k_interp_tile<IO, Real, false>;
+                HIP_TRY(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(tk, tgrid, dim3(1024), lds, st, ta);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
             if (vr) {
                 if ((1 << ia.lgP) != ia.P) return "variable-rate needs a power-of-two phase count";
                 // position of the first output of this launch: advance (T0, S0) by `done` outputs
