@@ -247,13 +247,25 @@ __device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store)
 #pragma unroll
             for (int t = 0; t < R; ++t) u[i][t] = load(j + t * nb);
             if (Ns > 1) {
-                // powers of the butterfly's twiddle by squaring (w^2t = (w^t)^2, w^(2t+1) = w^2t w):
-                // same number of complex products as a running product, but a dependency depth of
-                // log2 R instead of R, and rounding error that grows with log2 R
+                // Powers w^t of the butterfly's twiddle.  Any power formed from ONE rounded table
+                // entry inherits t times its phase error ((w(1+e))^t ~ w^t (1+te)), so for the large
+                // radices a second entry, w^4, is read and w^(4a+b) = (w^4)^a w^b: the error factor
+                // drops from R-1 to <= a+b, for the same number of complex products.
                 cf pw[R];
                 pw[1] = w1;
+                if constexpr (R >= 10) {
+                    const cf w4 = W[4 * k * wstep]; // 4*k*wstep < 4N/R <= N
 #pragma unroll
-                for (int t = 2; t < R; ++t) pw[t] = (t & 1) ? cmul(pw[t - 1], w1) : cmul(pw[t / 2], pw[t / 2]);
+                    for (int t = 2; t < R; ++t) {
+                        const int a4 = t / 4, b4 = t % 4;
+                        if (a4 == 0) pw[t] = cmul(pw[t - 1], w1);
+                        else if (b4 == 0) pw[t] = a4 == 1 ? w4 : (a4 % 2 == 0 ? cmul(pw[t / 2], pw[t / 2]) : cmul(pw[t - 4], w4));
+                        else pw[t] = cmul(pw[4 * a4], pw[b4]);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 2; t < R; ++t) pw[t] = (t & 1) ? cmul(pw[t - 1], w1) : cmul(pw[t / 2], pw[t / 2]);
+                }
 #pragma unroll
                 for (int t = 1; t < R; ++t) u[i][t] = cmul(u[i][t], pw[t]);
             }
