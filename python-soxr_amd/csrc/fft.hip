@@ -14,7 +14,7 @@
 // index multiple of L), overlap by more than the filter length, and only the outputs whose whole
 // filter support lies inside the block are kept.  ~70-80 flop per output instead of 592.
 // What is neglected is the aliasing of g's stop band (<= -176 dB for VHQ): measured against the
-// direct form 2.5e-10 relative RMS in float64, 1.4e-7 in float32 (FFT rounding) — inside the 1e-6
+// direct form 2.5e-10 relative RMS in float64, 1.5e-7 to 2.2e-7 in float32 (FFT rounding) — inside the 1e-6
 // bar, but NOT bit-identical to the canonical order, so this engine is used only where no
 // bit-exact contract exists: whole-signal float32 device jobs (hipsoxr_run_device).  The host
 // surface (soxr.resample / ResampleStream), integer and float64 I/O stay on the exact engine.

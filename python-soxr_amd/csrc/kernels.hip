@@ -1611,7 +1611,7 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     const int prec = engine_prec(j.elem);
     if (const char *e = device_bank_ensure(p, prec)) return e;
     // Frequency-domain engine: explicit request, or AUTO for large whole-signal float32 jobs.
-    // It is NOT bit-identical to the canonical order (1.4e-7 relative RMS), so it is never chosen
+    // It is NOT bit-identical to the canonical order (about 2e-7 relative RMS), so it is never chosen
     // for HIPSOXR_KERNEL_EXACT — which is what the stream / one-shot host entry points pass.
     if (!vr && (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO)) {
         static const bool no_fft = getenv("HIPSOXR_NO_FFT") != nullptr;
