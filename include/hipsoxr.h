@@ -83,7 +83,10 @@ typedef enum {
     HIPSOXR_KERNEL_TILE_MFMA = 4, /* period-tiled on the f32-input matrix pipe (f32 engine only) */
     HIPSOXR_KERNEL_FFT = 5,    /* frequency-domain overlap-save engine (whole-signal float32 jobs; 1e-6-class,
                                   not bit-identical to the canonical order) */
-    HIPSOXR_KERNEL_EXACT = 6   /* AUTO restricted to the canonical-order kernels (bit-exact invariances) */
+    HIPSOXR_KERNEL_EXACT = 6,  /* AUTO restricted to the canonical-order kernels (bit-exact invariances) */
+    HIPSOXR_KERNEL_WAVE_DOT = 7 /* reference point only: one wavefront per output sample + shuffle reduction
+                                  (the shape BASELINE.json's north star describes); 64-way tree order, so
+                                  1e-6-class like FFT, never chosen automatically */
 } hipsoxr_kernel_t;
 
 typedef struct hipsoxr_plan hipsoxr_plan_t;     /* immutable: ratio + polyphase bank (host + device) */

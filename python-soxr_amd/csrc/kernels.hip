@@ -168,6 +168,41 @@ __global__ void __launch_bounds__(256) k_gather(GatherArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_wave_dot — the shape BASELINE.json's north star describes, kept as a measured reference point:
+// one wavefront per output sample, the taps of the phase spread over the 64 lanes (coefficient row
+// and input window both read coalesced), partial dot products combined by a wavefront shuffle
+// reduction.  NOT in the canonical order (a 64-way tree instead of two serial chains), so it is
+// never chosen automatically and its results are 1e-6-class, not bit-identical.  Measured (DESIGN.md
+// §6): far slower than the tiled kernels — six cross-lane steps and two loads per ~4.6 FMAs.
+// ---------------------------------------------------------------------------------------------
+template <typename IO, typename Real>
+__global__ void __launch_bounds__(256) k_wave_dot(GatherArgs a, const Real *__restrict__ phase_major, int32_t per_wave)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t ch = blockIdx.y % a.n_channels, clip = blockIdx.y / a.n_channels;
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+    const int32_t T = a.T, H = T / 2;
+    for (int32_t o = 0; o < per_wave; ++o) {
+        const int64_t idx = wave * per_wave + o;
+        if (idx >= a.out_frames) return; // wave-uniform
+        const int64_t t = a.p0 + idx * a.M, q = t / a.L, p = t - q * a.L;
+        const int64_t loc0 = a.d0 + q - (H - 1) - a.in_abs0;
+        const Real *c = phase_major + p * T;
+        Real acc = 0;
+        for (int j = lane; j < T; j += 64) {
+            const int64_t l = loc0 + j;
+            const Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+            acc = fma_r(c[j], xv, acc);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) store_out<Real>(yo + idx * a.ofs, acc, a.oc, ch, a.out_k0 + idx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_interp — interpolated-phase plans (ratios without a small rational form; plan.cpp)
 // ---------------------------------------------------------------------------------------------
 // One lane per output sample, as k_gather, but the coefficient of tap j is evaluated from the cubic
@@ -1339,6 +1374,7 @@ void device_bank_release(Plan *p)
     for (int i = 0; i < 2; ++i) {
         DeviceBank &d = p->dev[i];
         if (d.tap_major) (void)hipFree(d.tap_major);
+        if (d.phase_major) (void)hipFree(d.phase_major);
         if (d.interp_tab) (void)hipFree(d.interp_tab);
         if (d.tile_tab) (void)hipFree(d.tile_tab);
         if (d.tile_i0) (void)hipFree(d.tile_i0);
@@ -1544,6 +1580,41 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
 }
 
 template <typename IO, typename Real>
+static const char *launch_wave_dot(Plan *p, const hipsoxr_job_t &j, hipStream_t st)
+{
+    DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
+    if (p->phases) return "wave-dot kernel needs an exact-bank plan";
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (!d.phase_major) {
+            std::vector<Real> pm(p->bank.size());
+            for (size_t i = 0; i < pm.size(); ++i) pm[i] = (Real)p->bank[i];
+            HIP_TRY(hipMalloc(&d.phase_major, pm.size() * sizeof(Real)));
+            HIP_TRY(hipMemcpy(d.phase_major, pm.data(), pm.size() * sizeof(Real), hipMemcpyHostToDevice));
+        }
+    }
+    const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
+    if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";
+    if (j.out_frames > ((int64_t)1 << 30)) return "job too long for the wave-dot kernel";
+    GatherArgs a;
+    a.in = j.in; a.out = j.out; a.bank = nullptr; a.Lpad = 0; a.L = p->L; a.M = p->M; a.T = p->T;
+    a.n_clips = j.n_clips; a.n_channels = j.n_channels;
+    a.ics = j.in_clip_stride; a.ifs = j.in_frame_stride; a.ichs = j.in_chan_stride;
+    a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
+    a.in_abs0 = j.in_abs0; a.in_frames = j.in_frames; a.out_k0 = j.out_k0; a.out_frames = j.out_frames;
+    __int128 kM = (__int128)j.out_k0 * p->M;
+    a.d0 = (int64_t)(kM / p->L); a.p0 = (int64_t)(kM % p->L);
+    a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed;
+    a.ch_fast = 0;
+    const int32_t per_wave = 16;
+    const int64_t waves = (j.out_frames + per_wave - 1) / per_wave;
+    hipLaunchKernelGGL((k_wave_dot<IO, Real>), dim3((unsigned)((waves + 3) / 4), (unsigned)cols, 1), dim3(256), 0, st, a,
+                       (const Real *)d.phase_major, per_wave);
+    HIP_TRY(hipGetLastError());
+    return nullptr;
+}
+
+template <typename IO, typename Real>
 static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr)
 {
     const int prec = sizeof(Real) == 4 ? 0 : 1;
@@ -1554,6 +1625,7 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st,
         if (TileGeom *gp = geom_find(p, prec, 1)) gm = *gp;
     }
     int kernel = j.kernel;
+    if (kernel == HIPSOXR_KERNEL_WAVE_DOT) return vr ? "wave-dot kernel does not do variable rate" : launch_wave_dot<IO, Real>(p, j, st);
     if (kernel == HIPSOXR_KERNEL_EXACT || kernel == HIPSOXR_KERNEL_FFT) kernel = HIPSOXR_KERNEL_AUTO;
     if (p->phases) { // interpolated-phase plan: one kernel (k_interp, dispatched by launch_gather)
         if (kernel != HIPSOXR_KERNEL_AUTO && kernel != HIPSOXR_KERNEL_GATHER)

@@ -20,6 +20,7 @@ struct QualitySpec {
 // Device-resident tables for one engine precision (float or double).
 struct DeviceBank {
     void *tap_major = nullptr;   // [T][Lpad]   (gather kernel: lanes read neighbouring phases)
+    void *phase_major = nullptr; // [L][T] (k_wave_dot only; uploaded on first use)
     void *interp_tab = nullptr;  // interpolated-phase plans: [P][T] of Real4 (a0..a3)
     int64_t Lpad = 0;
     // tile kernel: per output-tile skewed, zero-padded half tables (see kernels.hip)

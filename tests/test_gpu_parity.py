@@ -128,3 +128,18 @@ def test_int_clipping_and_counter(soxr, oracle):
     assert np.array_equal(y, want)
     assert rs.num_clips() == clips
     assert clips > 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wave_dot_reference_kernel_within_tolerance(oracle, dtype):
+    """HIPSOXR_KERNEL_WAVE_DOT — one wavefront per output + shuffle reduction, the shape the north
+    star describes — sums in a 64-way tree, not the canonical order: 1e-6 relative RMS against the
+    float64 reference, not bit-identical."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(17)
+    x = _signal(rng, 30000, 2, dtype)
+    plan = dev.Plan(48000, 44100, "VHQ")
+    y = dev.resample_tensor(plan, torch.from_numpy(x).cuda(), kernel=dev.KERNEL_WAVE_DOT).cpu().numpy()
+    ref = oracle.resample(x, 48000, 44100, "VHQ", mode="ref")
+    assert y.shape == ref.shape and _rel_rms(y, ref) <= 1e-6
