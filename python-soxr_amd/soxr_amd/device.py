@@ -73,6 +73,38 @@ class Plan:
         _n.check(_n.lib.hipsoxr_run_device(self._h, _C.byref(j), stream))
 
 
+class PreparedJob:
+    """A device job whose descriptor is built once: `launch()` is a single C call
+    (hipsoxr_run_device).  For loops that re-run the same conversion on the same buffers
+    (benchmarks, fixed-shape pipelines) where Python-side argument handling would otherwise
+    cost as much as the 13 us kernel."""
+
+    def __init__(self, plan, x, out, kernel=_n.KERNEL_AUTO, dither=False, clip_counter=None):
+        import torch
+        x3 = x[None, :, None] if x.ndim == 1 else (x[None] if x.ndim == 2 else x)
+        o3 = out[None, :, None] if out.ndim == 1 else (out[None] if out.ndim == 2 else out)
+        clips, frames, ch = x3.shape
+        if tuple(o3.shape) != (clips, plan.out_len(frames), ch):
+            raise ValueError("out has the wrong shape for this plan")
+        j = _n.Job()
+        j.in_, j.out, j.elem, j.kernel = x3.data_ptr(), o3.data_ptr(), _torch_elem(x.dtype), kernel
+        j.n_clips, j.n_channels = clips, ch
+        j.in_clip_stride, j.in_frame_stride, j.in_chan_stride = x3.stride()
+        j.out_clip_stride, j.out_frame_stride, j.out_chan_stride = o3.stride()
+        j.in_abs0, j.in_frames, j.out_k0, j.out_frames = 0, frames, 0, o3.shape[1]
+        j.clip_counter = clip_counter.data_ptr() if clip_counter is not None else None
+        j.dither, j.dither_seed = int(bool(dither)), 0
+        self._job, self._ref = j, _C.byref(j)
+        self._plan, self._keep = plan, (x, out, clip_counter)
+        self._stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._fn, self._h = _n.lib.hipsoxr_run_device, plan.handle
+
+    def launch(self):
+        err = self._fn(self._h, self._ref, self._stream)
+        if err:
+            _n.check(err)
+
+
 _TORCH_ELEM = None
 
 

@@ -107,3 +107,24 @@ def test_config4_int16_stream(soxr, oracle, chunk, channels):
         v = oracle.resample_channel(pl, x[:, 0].astype(np.float32), "port_f32", k0=k0, n_out=200)
         q, _ = oracle.quantize(v, np.int16, channel=0, k0=k0, dither=True, seed=0)
         assert np.array_equal(y[k0:k0 + 200, 0], q)
+
+
+def test_prepared_job_equals_resample_tensor():
+    """device.PreparedJob (what bench.py times: one C call per step) launches the same job."""
+    import torch
+    from soxr_amd import device as dev
+    plan = dev.Plan(48000, 44100, "VHQ")
+    x = torch.randn(300000, device="cuda") * 0.25
+    y1 = dev.resample_tensor(plan, x)
+    y2 = torch.empty_like(y1)
+    job = dev.PreparedJob(plan, x, y2)
+    job.launch()
+    job.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    xb = torch.randn((3, 50000, 2), device="cuda") * 0.25
+    yb = dev.resample_tensor(plan, xb, kernel=dev.KERNEL_EXACT)
+    yb2 = torch.empty_like(yb)
+    dev.PreparedJob(plan, xb, yb2, kernel=dev.KERNEL_EXACT).launch()
+    torch.cuda.synchronize()
+    assert torch.equal(yb, yb2)
