@@ -558,6 +558,9 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
                            (lb >= 0 && lb < a.in_frames) ? xin[lb * a.ifs + (cp ? 1 : 0)] : 0.f);
     }, lds_store, false);
     __syncthreads();
+#if defined(FFT_ABL) && (FFT_ABL & 4) // timing ablation (tools/fft_latency.sh): stop after the forward transform
+    if (a.out_frames >= 0) return;
+#endif
 
     // ---- inverse: bin n of the output grid <- bin n (n <= NB/2) or n + NA - NB (negative
     //      frequencies) of the input grid, times H (Hermitian); result n = (y_a[n], y_b[n]) ---------

@@ -100,10 +100,10 @@ class ResampleStream:
                                               elem, recipe, flags, _C.byref(self._h)))
         self._ended = False
 
-    def __del__(self):
+    def __del__(self, _delete=_n.lib.hipsoxr_stream_delete):  # bound early: globals may be gone at exit
         h = getattr(self, "_h", None)
         if h:
-            _n.lib.hipsoxr_stream_delete(h)
+            _delete(h)
             self._h = None
 
     # -- the counterpart of CSoxr::process (src/soxr_ext.cpp:129-188) ---------------------------

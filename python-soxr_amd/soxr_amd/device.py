@@ -32,10 +32,10 @@ class Plan:
         self.precision_bits, self.passband_end = info.precision_bits, info.passband_end
         self.stopband_begin, self.att_db, self.kaiser_beta = info.stopband_begin, info.att_db, info.kaiser_beta
 
-    def __del__(self):
+    def __del__(self, _delete=_n.lib.hipsoxr_plan_delete):  # bound early: module globals may be gone at exit
         h = getattr(self, "_h", None)
         if h:
-            _n.lib.hipsoxr_plan_delete(h)
+            _delete(h)
             self._h = None
 
     @property
