@@ -83,8 +83,42 @@ struct hipsoxr_stream {
     size_t out_cap = 0; // frames
     uint64_t *d_clips = nullptr;
     hipStream_t st = nullptr;
+    // pinned bounce buffers for small chunks: a pageable hipMemcpyAsync is staged by the runtime
+    // with a blocking hand-shake per call (~30 us each way); a memcpy into pinned memory + a true
+    // async copy costs a few us
+    void *h_in = nullptr, *h_out = nullptr;
+    size_t h_in_bytes = 0, h_out_bytes = 0;
+    hipEvent_t ev = nullptr; // completion of a call's last operation (see stream_wait)
     char engine_name[32] = {0};
 };
+
+// Wait for everything queued on the stream.  A chunked call is a 20-30 us round trip on the GPU;
+// the runtime's blocking hipStreamSynchronize adds an interrupt-and-wake-up latency of the same
+// order, so the first ~100 us are spent polling an event instead.
+static hipError_t stream_wait(hipsoxr_stream *s)
+{
+    if (s->ev && hipEventRecord(s->ev, s->st) == hipSuccess) {
+        for (int spin = 0; spin < 20000; ++spin) {
+            const hipError_t q = hipEventQuery(s->ev);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) break;
+        }
+    }
+    return hipStreamSynchronize(s->st);
+}
+static const size_t kPinnedMax = (size_t)1 << 20; // chunks up to 1 MiB go through the bounce buffers
+
+static const char *pinned_ensure(void **buf, size_t *cap, size_t bytes)
+{
+    if (*cap >= bytes) return nullptr;
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr; *cap = 0;
+    size_t want = 4096;
+    while (want < bytes) want <<= 1;
+    if (hipHostMalloc(buf, want, hipHostMallocDefault) != hipSuccess) { *buf = nullptr; return "hipHostMalloc failed"; }
+    *cap = want;
+    return nullptr;
+}
 
 #define HIP_TRY(expr)                                       \
     do {                                                    \
@@ -145,6 +179,9 @@ struct StreamShell {
     void *d_in = nullptr, *d_in_alt = nullptr, *d_out = nullptr;
     size_t in_bytes = 0, alt_bytes = 0, out_bytes = 0;
     uint64_t *d_clips = nullptr;
+    void *h_in = nullptr, *h_out = nullptr;
+    size_t h_in_bytes = 0, h_out_bytes = 0;
+    hipEvent_t ev = nullptr;
 };
 static std::mutex g_pool_mu;
 static std::vector<StreamShell> g_pool;
@@ -156,6 +193,9 @@ static void shell_free(StreamShell &sh)
     if (sh.d_in_alt) (void)hipFree(sh.d_in_alt);
     if (sh.d_out) (void)hipFree(sh.d_out);
     if (sh.d_clips) (void)hipFree(sh.d_clips);
+    if (sh.h_in) (void)hipHostFree(sh.h_in);
+    if (sh.h_out) (void)hipHostFree(sh.h_out);
+    if (sh.ev) (void)hipEventDestroy(sh.ev);
     if (sh.st) (void)hipStreamDestroy(sh.st);
     sh = StreamShell();
 }
@@ -334,14 +374,24 @@ static const char *stream_append(hipsoxr_stream *s, const void *in, size_t ilen)
         while (cap < need) cap <<= 1;
         if (const char *e = stream_compact(s, cap)) return e;
     }
+    const size_t chunk_bytes = ilen * s->ch * esz(s);
+    const bool bounce = chunk_bytes <= kPinnedMax && !pinned_ensure(&s->h_in, &s->h_in_bytes, chunk_bytes);
     if (!s->split) {
-        HIP_TRY(hipMemcpyAsync((char *)s->d_in + s->in_fill * s->ch * esz(s), in,
-                               ilen * s->ch * esz(s), hipMemcpyHostToDevice, s->st));
+        const void *src = in;
+        if (bounce) { std::memcpy(s->h_in, in, chunk_bytes); src = s->h_in; }
+        HIP_TRY(hipMemcpyAsync((char *)s->d_in + s->in_fill * s->ch * esz(s), src, chunk_bytes,
+                               hipMemcpyHostToDevice, s->st));
     } else {
         const void *const *chans = (const void *const *)in;
-        for (unsigned c = 0; c < s->ch; ++c)
-            HIP_TRY(hipMemcpyAsync((char *)s->d_in + ((size_t)c * s->in_cap + s->in_fill) * esz(s),
-                                   chans[c], ilen * esz(s), hipMemcpyHostToDevice, s->st));
+        for (unsigned c = 0; c < s->ch; ++c) {
+            const void *src = chans[c];
+            if (bounce) {
+                src = (char *)s->h_in + (size_t)c * ilen * esz(s);
+                std::memcpy((void *)src, chans[c], ilen * esz(s));
+            }
+            HIP_TRY(hipMemcpyAsync((char *)s->d_in + ((size_t)c * s->in_cap + s->in_fill) * esz(s), src,
+                                   ilen * esz(s), hipMemcpyHostToDevice, s->st));
+        }
     }
     s->in_fill += ilen;
     s->n_in_total += ilen;
@@ -391,7 +441,7 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     if (v.on && v.n_slew && s->k_done + n > v.k_s + v.n_slew) n = (size_t)(v.k_s + v.n_slew - s->k_done);
     *odone = n;
     if (n == 0) {
-        HIP_TRY(hipStreamSynchronize(s->st)); // the caller's input buffer is borrowed only for the call
+        HIP_TRY(stream_wait(s)); // the caller's input buffer is borrowed only for the call
         return nullptr;
     }
     if (n > s->out_cap) {
@@ -427,15 +477,23 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
                     (uint64_t)((u128)D >> 64), (uint64_t)(u128)D};
         if (const char *e = launch_job(&s->plan->p, j, s->st, &vp)) return e;
     } else if (const char *e = launch_job(&s->plan->p, j, s->st)) return e;
+    const size_t out_bytes = n * s->ch * esz(s);
+    const bool bounce = out_bytes <= kPinnedMax && !pinned_ensure(&s->h_out, &s->h_out_bytes, out_bytes);
     if (!s->split) {
-        HIP_TRY(hipMemcpyAsync(out, s->d_out, n * s->ch * esz(s), hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(hipMemcpyAsync(bounce ? s->h_out : out, s->d_out, out_bytes, hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(stream_wait(s));
+        if (bounce) std::memcpy(out, s->h_out, out_bytes);
     } else {
         void *const *chans = (void *const *)out;
         for (unsigned c = 0; c < s->ch; ++c)
-            HIP_TRY(hipMemcpyAsync(chans[c], (char *)s->d_out + (size_t)c * s->out_cap * esz(s),
-                                   n * esz(s), hipMemcpyDeviceToHost, s->st));
+            HIP_TRY(hipMemcpyAsync(bounce ? (void *)((char *)s->h_out + (size_t)c * n * esz(s)) : chans[c],
+                                   (char *)s->d_out + (size_t)c * s->out_cap * esz(s), n * esz(s),
+                                   hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(stream_wait(s));
+        if (bounce)
+            for (unsigned c = 0; c < s->ch; ++c)
+                std::memcpy(chans[c], (char *)s->h_out + (size_t)c * n * esz(s), n * esz(s));
     }
-    HIP_TRY(hipStreamSynchronize(s->st));
     s->k_done += n;
     return nullptr;
 }
@@ -468,7 +526,8 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
                     StreamShell sh = g_pool[i];
                     g_pool.erase(g_pool.begin() + (long)i);
                     const size_t frame = (size_t)ch * esz(s);
-                    s->st = sh.st; s->d_clips = sh.d_clips;
+                    s->st = sh.st; s->d_clips = sh.d_clips; s->ev = sh.ev;
+                    s->h_in = sh.h_in; s->h_in_bytes = sh.h_in_bytes; s->h_out = sh.h_out; s->h_out_bytes = sh.h_out_bytes;
                     s->d_in = sh.d_in; s->in_cap = sh.in_bytes / frame;
                     s->d_in_alt = sh.d_in_alt; s->alt_cap = sh.alt_bytes / frame;
                     s->d_out = sh.d_out; s->out_cap = sh.out_bytes / frame;
@@ -481,6 +540,7 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
         if (!s->st && hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
             err = "hipStreamCreate failed"; break;
         }
+        if (!s->ev && hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) s->ev = nullptr;
         if (!s->d_clips && hipMalloc((void **)&s->d_clips, sizeof(uint64_t)) != hipSuccess) {
             err = "hipMalloc failed"; break;
         }
@@ -534,7 +594,8 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
     StreamShell sh;
     (void)hipGetDevice(&sh.device);
     const size_t frame = (size_t)s->ch * esz(s);
-    sh.st = s->st; sh.d_clips = s->d_clips;
+    sh.st = s->st; sh.d_clips = s->d_clips; sh.ev = s->ev;
+    sh.h_in = s->h_in; sh.h_in_bytes = s->h_in_bytes; sh.h_out = s->h_out; sh.h_out_bytes = s->h_out_bytes;
     sh.d_in = s->d_in; sh.in_bytes = s->d_in ? s->in_cap * frame : 0;
     sh.d_in_alt = s->d_in_alt; sh.alt_bytes = s->d_in_alt ? s->alt_cap * frame : 0;
     sh.d_out = s->d_out; sh.out_bytes = s->d_out ? s->out_cap * frame : 0;
@@ -562,7 +623,7 @@ hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size
         if (const char *e = stream_append(s, in, ilen)) return e;
     }
     if (olen == 0 || out == nullptr) {
-        if (in && ilen) HIP_TRY(hipStreamSynchronize(s->st)); // host buffer is borrowed only for the call
+        if (in && ilen) HIP_TRY(stream_wait(s)); // host buffer is borrowed only for the call
         return nullptr;
     }
     return stream_emit(s, out, olen, odone);
@@ -576,7 +637,7 @@ hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
         s->vr.k_s = 0; s->vr.t_s = 0; s->vr.s0 = s->vr.s1; s->vr.delta = 0; s->vr.n_slew = 0;
     }
     HIP_TRY(hipMemsetAsync(s->d_clips, 0, sizeof(uint64_t), s->st));
-    HIP_TRY(hipStreamSynchronize(s->st));
+    HIP_TRY(stream_wait(s));
     return nullptr;
 }
 

@@ -145,22 +145,27 @@ __global__ void __launch_bounds__(256) k_gather(GatherArgs a)
     const Real *c = (const Real *)a.bank + p;
     const int32_t T = a.T, H = T / 2;
     Real accL = 0, accR = 0;
+    // The two half-chains are independent: they advance together (each in its own canonical order),
+    // eight taps of each per trip, so 32 loads are in flight per lane.  This kernel serves the small
+    // launches of streaming calls, where its latency — a serial chain of T dependent FMAs fed by L2
+    // loads — is the whole cost (81 us -> ~20 us for T = 736).
     if (loc0 >= 0 && loc0 + T <= a.in_frames) {
         const IO *xp = xin + loc0 * a.ifs;
-        for (int j = 0; j < H; ++j)
-            accL = fma_r(c[(int64_t)j * a.Lpad], (Real)xp[(int64_t)j * a.ifs], accL);
-        for (int j = T - 1; j >= H; --j)
-            accR = fma_r(c[(int64_t)j * a.Lpad], (Real)xp[(int64_t)j * a.ifs], accR);
-    } else {
-        for (int j = 0; j < H; ++j) {
-            int64_t l = loc0 + j;
-            Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-            accL = fma_r(c[(int64_t)j * a.Lpad], xv, accL);
+#pragma unroll 8
+        for (int i = 0; i < H; ++i) {
+            const int jr = T - 1 - i;
+            accL = fma_r(c[(int64_t)i * a.Lpad], (Real)xp[(int64_t)i * a.ifs], accL);
+            accR = fma_r(c[(int64_t)jr * a.Lpad], (Real)xp[(int64_t)jr * a.ifs], accR);
         }
-        for (int j = T - 1; j >= H; --j) {
-            int64_t l = loc0 + j;
-            Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-            accR = fma_r(c[(int64_t)j * a.Lpad], xv, accR);
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < H; ++i) {
+            const int jr = T - 1 - i;
+            const int64_t ll = loc0 + i, lr = loc0 + jr;
+            const Real xl = (ll >= 0 && ll < a.in_frames) ? (Real)xin[ll * a.ifs] : (Real)0;
+            const Real xr = (lr >= 0 && lr < a.in_frames) ? (Real)xin[lr * a.ifs] : (Real)0;
+            accL = fma_r(c[(int64_t)i * a.Lpad], xl, accL);
+            accR = fma_r(c[(int64_t)jr * a.Lpad], xr, accR);
         }
     }
     IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + idx * a.ofs + (int64_t)ch * a.ochs;
@@ -506,6 +511,88 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
                 const int64_t idx = o_base + i;
                 store_out<Real>(yo + idx * a.ofs, accL + accR, a.oc, ch, a.out_k0 + idx);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chain — low-latency kernel for SMALL launches (streaming chunks: tens to a few thousand outputs)
+// ---------------------------------------------------------------------------------------------
+// k_gather's cost on a small launch is pure latency: every lane walks T taps, each a pair of L2 loads
+// feeding a dependent FMA (81 us for T = 736, whatever the chunk size).  Here a workgroup of 256
+// threads takes NO consecutive outputs: ALL threads first stage the NO coefficient rows and input
+// windows into LDS (every load of the workgroup in flight at once: one round trip, not T), then
+// 2*NO lanes run the canonical half-chains out of LDS (lane o: left half of output o, lane NO+o:
+// right half), and the two halves are added.  Same arithmetic, bit for bit.
+// MODE 0: exact bank (phase-major [L][T]); 1: interpolated-phase plan; 2: variable rate.  In the
+// interpolated modes the staging thread evaluates the tap's cubic (the canonical Horner FMAs).
+struct ChainArgs {
+    InterpArgs ia;           // .g: job geometry; .tab/.P/...: interpolated plans
+    const void *phase_major; // exact plans: [L][T] Real
+    int32_t NO;              // outputs per workgroup (power of two, <= 32)
+};
+
+template <typename IO, typename Real, int MODE>
+__global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const InterpArgs &ia = ca.ia;
+    const GatherArgs &a = ia.g;
+    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
+    const int32_t T = a.T, H = T / 2, NO = ca.NO, S = NO + 1; // S: row stride (odd: conflict-free transposes)
+    Real *cs = reinterpret_cast<Real *>(smem_raw); // [T][S] coefficients
+    Real *xs = cs + (size_t)T * S;                 // [T][S] samples
+    int64_t *n0s = reinterpret_cast<int64_t *>(xs + (size_t)T * S); // [NO] first-tap input index (relative to in[0])
+    uint64_t *aux = reinterpret_cast<uint64_t *>(n0s + NO);         // [NO] phase (MODE 0) or iv<<32 | xq (MODE 1, 2)
+
+    const uint32_t ch = blockIdx.y % a.n_channels, clip = blockIdx.y / a.n_channels;
+    const int64_t o_base = (int64_t)blockIdx.x * NO;
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    typedef typename Vec4<Real>::type V4;
+
+    if ((int)threadIdx.x < NO) { // one thread per output: where it sits
+        const int64_t idx = o_base + threadIdx.x < a.out_frames ? o_base + threadIdx.x : a.out_frames - 1;
+        if (MODE == 0) {
+            const int64_t t = a.p0 + idx * a.M, q = t / a.L;
+            n0s[threadIdx.x] = a.d0 + q - (H - 1) - a.in_abs0;
+            aux[threadIdx.x] = (uint64_t)(t - q * a.L);
+        } else {
+            const InterpPos<Real> r = interp_locate<Real, MODE == 2>(ia, idx);
+            n0s[threadIdx.x] = r.n0 - a.in_abs0;
+            aux[threadIdx.x] = ((uint64_t)r.iv << 32) | (uint64_t)(uint32_t)r.xq; // xq < 2^32
+        }
+    }
+    __syncthreads();
+    // stage: element e = (output o, tap j); a wave covers 64 consecutive taps of one output
+    for (int e = threadIdx.x; e < NO * T; e += 256) {
+        const int o = e / T, j = e - o * T;
+        const int64_t l = n0s[o] + j;
+        xs[(size_t)j * S + o] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+        Real c;
+        if (MODE == 0) {
+            c = ((const Real *)ca.phase_major)[aux[o] * (uint64_t)T + j];
+        } else {
+            const uint64_t ax = aux[o];
+            const Real xx = (Real)(uint32_t)ax * (Real)(1. / (double)(1ULL << SH));
+            const V4 v = ((const V4 *)ia.tab)[(size_t)(ax >> 32) * T + j];
+            c = fma_r(fma_r(fma_r(v.w, xx, v.z), xx, v.y), xx, v.x);
+        }
+        cs[(size_t)j * S + o] = c;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * NO) { // first wave: the half-chains
+        const int o = threadIdx.x < NO ? threadIdx.x : threadIdx.x - NO;
+        const bool right = (int)threadIdx.x >= NO;
+        const Real *cp = cs + (right ? (size_t)(T - 1) * S : 0) + o, *xp = xs + (right ? (size_t)(T - 1) * S : 0) + o;
+        const int step = right ? -S : S;
+        Real acc = 0;
+#pragma unroll 8
+        for (int i = 0; i < H; ++i) acc = fma_r(cp[i * step], xp[i * step], acc);
+        const Real accR = __shfl(acc, (int)threadIdx.x + NO, 64); // NO <= 32: partner in the same wave
+        const int64_t idx = o_base + o;
+        if (!right && idx < a.out_frames) {
+            IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + idx * a.ofs + (int64_t)ch * a.ochs;
+            store_out<Real>(yo, acc + accR, a.oc, ch, a.out_k0 + idx);
         }
     }
 }
@@ -1425,6 +1512,59 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 return "too many (clip, channel) columns for one launch (max 65535)";
             }
             grid = dim3((unsigned)((nf + 255) / 256), (unsigned)cols, 1);
+        }
+        // small launches (streaming chunks): the low-latency chain kernel
+        static const bool no_chain = getenv("HIPSOXR_NO_CHAIN") != nullptr;
+        if (!no_chain && nf < 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
+            int NO = 32;
+            while (NO > 2 && (size_t)2 * p->T * (NO + 1) * sizeof(Real) + (size_t)NO * 16 > 150 * 1024) NO /= 2;
+            const size_t lds = (size_t)2 * p->T * (NO + 1) * sizeof(Real) + (size_t)NO * 16;
+            if (lds <= 150 * 1024) {
+                ChainArgs ca;
+                std::memset(&ca, 0, sizeof ca);
+                ca.ia.g = a; ca.NO = NO;
+                const char *err = nullptr;
+                void (*ck)(ChainArgs) = nullptr;
+                if (p->phases) {
+                    ca.ia.tab = d.interp_tab; ca.ia.P = p->phases;
+                    while ((1 << ca.ia.lgP) < ca.ia.P) ++ca.ia.lgP;
+                    if (vr) {
+                        if ((1 << ca.ia.lgP) != ca.ia.P) return "variable-rate needs a power-of-two phase count";
+                        typedef unsigned __int128 u128;
+                        const u128 T0 = ((u128)vr->t_hi << 64) | vr->t_lo, S0 = ((u128)vr->s_hi << 64) | vr->s_lo,
+                                   D = ((u128)vr->d_hi << 64) | vr->d_lo;
+                        const u128 n = (u128)(uint64_t)done, m = n * (n - 1) / 2;
+                        const u128 T1 = T0 + n * S0 + D * (done ? m : 0), S1 = S0 + D * n;
+                        ca.ia.t_hi = (uint64_t)(T1 >> 64); ca.ia.t_lo = (uint64_t)T1;
+                        ca.ia.s_hi = (uint64_t)(S1 >> 64); ca.ia.s_lo = (uint64_t)S1;
+                        ca.ia.d_hi = vr->d_hi; ca.ia.d_lo = vr->d_lo;
+                        ck = k_chain<IO, Real, 2>;
+                    } else {
+                        ck = k_chain<IO, Real, 1>;
+                    }
+                } else {
+                    DeviceBank &dm = p->dev[sizeof(Real) == 4 ? 0 : 1];
+                    {
+                        std::lock_guard<std::mutex> lk(p->mu);
+                        if (!dm.phase_major) {
+                            std::vector<Real> pm(p->bank.size());
+                            for (size_t i = 0; i < pm.size(); ++i) pm[i] = (Real)p->bank[i];
+                            if (hipMalloc(&dm.phase_major, pm.size() * sizeof(Real)) != hipSuccess) err = "hipMalloc failed";
+                            else if (hipMemcpy(dm.phase_major, pm.data(), pm.size() * sizeof(Real), hipMemcpyHostToDevice) != hipSuccess)
+                                err = "hipMemcpy failed";
+                        }
+                    }
+                    if (err) return err;
+                    ca.phase_major = dm.phase_major;
+                    ck = k_chain<IO, Real, 0>;
+                }
+                if (lds > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(ck, dim3((unsigned)((nf + NO - 1) / NO), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1),
+                                   dim3(256), lds, st, ca);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
         }
         if (p->phases) {
             InterpArgs ia;
