@@ -370,7 +370,10 @@ static const char *stream_append(hipsoxr_stream *s, const void *in, size_t ilen)
         int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base),
                                               s->in_base + (int64_t)s->in_fill);
         size_t keep = s->in_fill - (size_t)(keep_from - s->in_base);
-        size_t need = keep + ilen, cap = std::max<size_t>(s->in_cap, 1024);
+        // room for the history plus four chunks of this size: compaction (a device-to-device copy)
+        // then runs every fourth call instead of every call
+        size_t need = keep + 4 * ilen, cap = std::max<size_t>(s->in_cap, 1024);
+        if (need > ((size_t)1 << 24)) need = keep + ilen;
         while (cap < need) cap <<= 1;
         if (const char *e = stream_compact(s, cap)) return e;
     }
@@ -452,16 +455,21 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
         HIP_TRY(hipMalloc(&s->d_out, cap * s->ch * esz(s)));
         s->out_cap = cap;
     }
+    // Small results are written by the kernel straight into pinned host memory (it is mapped into
+    // the device's address space): no device-to-host copy call, just the completion wait.
+    const size_t out_bytes = n * s->ch * esz(s);
+    const bool direct = out_bytes <= kPinnedMax && !pinned_ensure(&s->h_out, &s->h_out_bytes, out_bytes);
     hipsoxr_job_t j;
     std::memset(&j, 0, sizeof j);
-    j.in = s->d_in; j.out = s->d_out; j.elem = s->elem; j.kernel = HIPSOXR_KERNEL_EXACT; // bit-exact chunk invariance
+    j.in = s->d_in; j.out = direct ? s->h_out : s->d_out; j.elem = s->elem;
+    j.kernel = HIPSOXR_KERNEL_EXACT; // bit-exact chunk invariance
     j.n_clips = 1; j.n_channels = s->ch;
     if (!s->split) {
         j.in_frame_stride = s->ch; j.in_chan_stride = 1;
         j.out_frame_stride = s->ch; j.out_chan_stride = 1;
     } else {
         j.in_frame_stride = 1; j.in_chan_stride = (int64_t)s->in_cap;
-        j.out_frame_stride = 1; j.out_chan_stride = (int64_t)s->out_cap;
+        j.out_frame_stride = 1; j.out_chan_stride = direct ? (int64_t)n : (int64_t)s->out_cap;
     }
     j.in_abs0 = s->in_base; j.in_frames = (int64_t)s->in_fill;
     j.out_k0 = (int64_t)s->k_done; j.out_frames = (int64_t)n;
@@ -477,22 +485,24 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
                     (uint64_t)((u128)D >> 64), (uint64_t)(u128)D};
         if (const char *e = launch_job(&s->plan->p, j, s->st, &vp)) return e;
     } else if (const char *e = launch_job(&s->plan->p, j, s->st)) return e;
-    const size_t out_bytes = n * s->ch * esz(s);
-    const bool bounce = out_bytes <= kPinnedMax && !pinned_ensure(&s->h_out, &s->h_out_bytes, out_bytes);
-    if (!s->split) {
-        HIP_TRY(hipMemcpyAsync(bounce ? s->h_out : out, s->d_out, out_bytes, hipMemcpyDeviceToHost, s->st));
+    if (direct) {
         HIP_TRY(stream_wait(s));
-        if (bounce) std::memcpy(out, s->h_out, out_bytes);
+        if (!s->split) {
+            std::memcpy(out, s->h_out, out_bytes);
+        } else {
+            void *const *chans = (void *const *)out;
+            for (unsigned c = 0; c < s->ch; ++c)
+                std::memcpy(chans[c], (char *)s->h_out + (size_t)c * n * esz(s), n * esz(s));
+        }
+    } else if (!s->split) {
+        HIP_TRY(hipMemcpyAsync(out, s->d_out, out_bytes, hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(stream_wait(s));
     } else {
         void *const *chans = (void *const *)out;
         for (unsigned c = 0; c < s->ch; ++c)
-            HIP_TRY(hipMemcpyAsync(bounce ? (void *)((char *)s->h_out + (size_t)c * n * esz(s)) : chans[c],
-                                   (char *)s->d_out + (size_t)c * s->out_cap * esz(s), n * esz(s),
+            HIP_TRY(hipMemcpyAsync(chans[c], (char *)s->d_out + (size_t)c * s->out_cap * esz(s), n * esz(s),
                                    hipMemcpyDeviceToHost, s->st));
         HIP_TRY(stream_wait(s));
-        if (bounce)
-            for (unsigned c = 0; c < s->ch; ++c)
-                std::memcpy(chans[c], (char *)s->h_out + (size_t)c * n * esz(s), n * esz(s));
     }
     s->k_done += n;
     return nullptr;

@@ -563,21 +563,37 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
         }
     }
     __syncthreads();
-    // stage: element e = (output o, tap j); a wave covers 64 consecutive taps of one output
-    for (int e = threadIdx.x; e < NO * T; e += 256) {
-        const int o = e / T, j = e - o * T;
-        const int64_t l = n0s[o] + j;
-        xs[(size_t)j * S + o] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-        Real c;
-        if (MODE == 0) {
-            c = ((const Real *)ca.phase_major)[aux[o] * (uint64_t)T + j];
-        } else {
-            const uint64_t ax = aux[o];
-            const Real xx = (Real)(uint32_t)ax * (Real)(1. / (double)(1ULL << SH));
-            const V4 v = ((const V4 *)ia.tab)[(size_t)(ax >> 32) * T + j];
-            c = fma_r(fma_r(fma_r(v.w, xx, v.z), xx, v.y), xx, v.x);
+    // stage: element e = (output o, tap j); a wave covers 64 consecutive taps of one output.
+    // Eight elements per trip, loads first: 16 global loads in flight per thread.
+    const int n_el = NO * T;
+    for (int e0 = threadIdx.x; e0 < n_el; e0 += 256 * 8) {
+        Real xv[8], cv[8];
+        V4 pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            xv[u] = 0; cv[u] = 0;
+            if (e < n_el) {
+                const int o = e / T, j = e - o * T;
+                const int64_t l = n0s[o] + j;
+                if (l >= 0 && l < a.in_frames) xv[u] = (Real)xin[l * a.ifs];
+                if (MODE == 0) cv[u] = ((const Real *)ca.phase_major)[aux[o] * (uint64_t)T + j];
+                else pv[u] = ((const V4 *)ia.tab)[(size_t)(aux[o] >> 32) * T + j];
+            }
         }
-        cs[(size_t)j * S + o] = c;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            if (e < n_el) {
+                const int o = e / T, j = e - o * T;
+                if (MODE != 0) {
+                    const Real xx = (Real)(uint32_t)aux[o] * (Real)(1. / (double)(1ULL << SH));
+                    cv[u] = fma_r(fma_r(fma_r(pv[u].w, xx, pv[u].z), xx, pv[u].y), xx, pv[u].x);
+                }
+                xs[(size_t)j * S + o] = xv[u];
+                cs[(size_t)j * S + o] = cv[u];
+            }
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < 2 * NO) { // first wave: the half-chains
@@ -1516,7 +1532,9 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
         // small launches (streaming chunks): the low-latency chain kernel
         static const bool no_chain = getenv("HIPSOXR_NO_CHAIN") != nullptr;
         if (!no_chain && nf < 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
-            int NO = 32;
+            // few outputs per workgroup: the staging loop is then two or three trips of 16 loads per
+            // thread (its latency is the kernel's latency), and there are enough workgroups anyway
+            int NO = nf <= 2048 ? 8 : 32;
             while (NO > 2 && (size_t)2 * p->T * (NO + 1) * sizeof(Real) + (size_t)NO * 16 > 150 * 1024) NO /= 2;
             const size_t lds = (size_t)2 * p->T * (NO + 1) * sizeof(Real) + (size_t)NO * 16;
             if (lds <= 150 * 1024) {
