@@ -28,6 +28,29 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream, const Vr
 
 int device_count();
 
+// Engine-selection and timing-experiment switches, read ONCE from the environment.  None of them
+// changes results beyond what the selected engine implies; they exist so that every number in
+// DESIGN.md §6 / tools/*.sh can be reproduced without rebuilding.
+struct Switches {
+    // engine selection (A/B measurements)
+    bool no_fft = false;          // HIPSOXR_NO_FFT           AUTO never picks the frequency-domain engine
+    bool fft_no_pair = false;     // HIPSOXR_FFT_NO_PAIR      one block per workgroup instead of the paired kernel
+    bool fft_no_chpair = false;   // HIPSOXR_FFT_NO_CHPAIR    pair blocks even for interleaved even-channel data
+    bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
+    bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
+    bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
+    bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
+    bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp
+    // timing experiments on the tile kernels (results may be wrong with dbg_flags != 0)
+    int dbg_flags = 0;            // HIPSOXR_DEBUG_FLAGS      1 no staging, 2 no LDS reads, 4 no coefficient loads, 8 no stores
+    int dbg_nrt = 0, dbg_nw = 0;  // HIPSOXR_DEBUG_NRT / _NW  tiles / waves per workgroup
+    int dbg_split = 0;            // HIPSOXR_DEBUG_SPLIT      grid.z unit split
+    size_t dbg_lds = 0;           // HIPSOXR_DEBUG_LDS        extra dynamic LDS (occupancy experiments)
+    size_t dbg_fft_lds = 0;       // HIPSOXR_DEBUG_FFT_LDS    the same for k_fft_block
+    const char *dbg_trace = nullptr; // HIPSOXR_DEBUG_TRACE   path for per-wave s_memtime stamps (k_tile_mfma_p)
+};
+const Switches &switches();
+
 // measurement helper: mode 0 = copy src -> dst, 1 = read src only (dst: >= 4 bytes)
 const char *stream_kernel(void *dst, const void *src, size_t bytes, int mode, void *stream);
 

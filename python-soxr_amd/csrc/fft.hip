@@ -754,7 +754,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         {1, 2, 2048, false, k_fft_pair<Pair4096x2048>, Pair4096x2048::NT},
         {2, 1, 2048, false, k_fft_pair<Pair2048x4096>, Pair2048x4096::NT},
     };
-    static const bool no_pair = getenv("HIPSOXR_FFT_NO_PAIR") != nullptr;
+    const bool no_pair = switches().fft_no_pair;
     const uint64_t cols_p = (uint64_t)j.n_clips * j.n_channels;
     if (!no_pair && cols_p <= 65535) {
         const PairEntry *big = nullptr, *sml = nullptr;
@@ -771,7 +771,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 // few work items (one 60 s clip = 300 pairs): half-size blocks give twice as many,
                 // shorter workgroups, at the price of more overlap
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
-                if ((wgs < 4 * 256 && !getenv("HIPSOXR_FFT_LARGE_ONLY")) || getenv("HIPSOXR_FFT_SMALL_ONLY")) {
+                if ((wgs < 4 * 256 && !switches().fft_large_only) || switches().fft_small_only) {
                     FftGeom gs;
                     if (const char *err = get(2 + sml_i, sml->k, &gs)) return err;
                     if (gs.ok) { g = gs; use = sml; }
@@ -796,7 +796,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.chpair = (j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1 &&
                             j.in_frame_stride % 2 == 0 && j.out_frame_stride % 2 == 0 && j.in_clip_stride % 2 == 0 &&
                             j.out_clip_stride % 2 == 0 && ((uintptr_t)j.in & 7) == 0 && ((uintptr_t)j.out & 7) == 0 &&
-                            !getenv("HIPSOXR_FFT_NO_CHPAIR")) ? 1 : 0;
+                            !switches().fft_no_chpair) ? 1 : 0;
                 const size_t lds = (size_t)std::max(g.N_in, g.N_out) * sizeof(float2);
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)use->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -814,7 +814,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     if (const char *err = get(0, 0, &g)) return err;
     if (g.ok) {
         const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out) * (int64_t)j.n_clips * j.n_channels;
-        if ((wgs < 8 * 256 && !getenv("HIPSOXR_FFT_LARGE_ONLY")) || getenv("HIPSOXR_FFT_SMALL_ONLY")) {
+        if ((wgs < 8 * 256 && !switches().fft_large_only) || switches().fft_small_only) {
             FftGeom gs;
             if (const char *err = get(1, 0, &gs)) return err;
             if (gs.ok && gs.k < g.k) g = gs;
@@ -844,7 +844,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)g.lds_bytes));
     const unsigned nt = 256u;
-    static const size_t dbg_lds = getenv("HIPSOXR_DEBUG_FFT_LDS") ? (size_t)atoi(getenv("HIPSOXR_DEBUG_FFT_LDS")) : 0;
+    const size_t dbg_lds = switches().dbg_fft_lds;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks, (unsigned)cols, 1), dim3(nt), std::max(g.lds_bytes, dbg_lds),
                        (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());

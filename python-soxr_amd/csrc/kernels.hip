@@ -42,6 +42,24 @@
 
 namespace hipsoxr {
 
+const Switches &switches()
+{
+    static const Switches sw = [] {
+        Switches w;
+        auto on = [](const char *n) { return getenv(n) != nullptr; };
+        auto num = [](const char *n) { const char *v = getenv(n); return v ? atoi(v) : 0; };
+        w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
+        w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
+        w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.no_planes = on("HIPSOXR_NO_PLANES");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
+        w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
+        w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
+        w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
+        return w;
+    }();
+    return sw;
+}
+
 // ---------------------------------------------------------------------------------------------
 // conversions
 // ---------------------------------------------------------------------------------------------
@@ -1431,7 +1449,7 @@ static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out, TileG
     if (sizeof(Real) == 4 && geom_m_out) {
         std::vector<float> tabm;
         TileGeom gm = build_mfma_planes(*p, &tabm);
-        if (!gm.ok || getenv("HIPSOXR_NO_PLANES")) gm = build_tile_tables<float>(*p, &tabm, 1);
+        if (!gm.ok || switches().no_planes) gm = build_tile_tables<float>(*p, &tabm, 1);
         if (gm.ok) {
             HIP_TRY(hipMalloc(&d.tile_tab_m, tabm.size() * sizeof(Real)));
             HIP_TRY(hipMemcpy(d.tile_tab_m, tabm.data(), tabm.size() * sizeof(Real), hipMemcpyHostToDevice));
@@ -1530,7 +1548,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             grid = dim3((unsigned)((nf + 255) / 256), (unsigned)cols, 1);
         }
         // small launches (streaming chunks): the low-latency chain kernel
-        static const bool no_chain = getenv("HIPSOXR_NO_CHAIN") != nullptr;
+        const bool no_chain = switches().no_chain;
         if (!no_chain && nf < 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
             // few outputs per workgroup: the staging loop is then two or three trips of 16 loads per
             // thread (its latency is the kernel's latency), and there are enough workgroups anyway
@@ -1591,7 +1609,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             while ((1 << ia.lgP) < ia.P) ++ia.lgP;
             // throughput kernel for large launches: KO outputs per workgroup, as many as LDS allows
             // (input span + 10 bytes of bookkeeping per output), at least ~32 outputs per interval
-            static const bool no_itile = getenv("HIPSOXR_NO_INTERP_TILE") != nullptr;
+            const bool no_itile = switches().no_interp_tile;
             int64_t KO = 0, span_cap = 0;
             if (!no_itile && nf >= 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
                 double step = (double)p->M / (double)p->L; // input samples per output
@@ -1689,12 +1707,11 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         nw = best;
     }
     if (g.variant == 2) nw = 4; // k_tile_mfma_p: one wave per SIMD, 2*n_rt units dealt round-robin
-    if (const char *dn = getenv("HIPSOXR_DEBUG_NRT")) { a.n_rt = atoi(dn); nw = a.n_rt; }
-    if (const char *dw = getenv("HIPSOXR_DEBUG_NW")) nw = atoi(dw);
+    if (switches().dbg_nrt) { a.n_rt = switches().dbg_nrt; nw = a.n_rt; }
+    if (switches().dbg_nw) nw = switches().dbg_nw;
     a.n_waves = nw;
     {
-        static const char *df = getenv("HIPSOXR_DEBUG_FLAGS");
-        a.dbg = df ? atoi(df) : 0;
+        a.dbg = switches().dbg_flags;
     }
     // (HIPSOXR_DEBUG_* are timing experiments only; results may be wrong when they are set)
     void (*kern)(TileArgs) = g.aligned ? k_tile<IO, Real, 16, true> : k_tile<IO, Real, 16, false>;
@@ -1709,16 +1726,16 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         // ceil(2*n_rt/4) workgroups so that every CU gets an equal share (3 resident per CU)
         const int64_t wgs = n_blocks * (int64_t)cols;
         int split = (int)std::min<int64_t>((2 * g.n_rt + 3) / 4, (2 * 3 * 256) / std::max<int64_t>(wgs, 1));
-        if (const char *e = getenv("HIPSOXR_DEBUG_SPLIT")) split = atoi(e);
+        if (switches().dbg_split) split = switches().dbg_split;
         grid.z = (unsigned)std::max(1, split);
     }
     size_t lds_bytes = g.lds_bytes;
-    if (const char *e = getenv("HIPSOXR_DEBUG_LDS")) lds_bytes = std::max<size_t>(lds_bytes, (size_t)atoi(e)); // occupancy experiments
+    lds_bytes = std::max<size_t>(lds_bytes, switches().dbg_lds); // occupancy experiments
     if (lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
     a.trace = nullptr;
-    const char *trace_path = getenv("HIPSOXR_DEBUG_TRACE");
+    const char *trace_path = switches().dbg_trace;
     size_t trace_n = 0;
     if (trace_path && g.variant == 2) {
         trace_n = (size_t)grid.x * cols * grid.z * 4 * 16;
@@ -1844,7 +1861,7 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     // It is NOT bit-identical to the canonical order (about 2e-7 relative RMS), so it is never chosen
     // for HIPSOXR_KERNEL_EXACT — which is what the stream / one-shot host entry points pass.
     if (!vr && (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO)) {
-        static const bool no_fft = getenv("HIPSOXR_NO_FFT") != nullptr;
+        const bool no_fft = switches().no_fft;
         const bool eligible = fft_job_eligible(*p, j);
         const bool big = (int64_t)j.out_frames * j.n_clips * j.n_channels >= (1 << 18);
         if (j.kernel == HIPSOXR_KERNEL_FFT && !eligible)
