@@ -527,11 +527,16 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     // interleaved data with an even channel count (a.chpair) — the same block of two neighbouring
     // channels, whose samples are one aligned float2 in memory: loads and stores then move 8
     // contiguous bytes per lane instead of two 4-byte words with a channel stride between lanes.
+    // Grid: block pairs along x, columns along y; in channel-pair mode the channel pairs of a clip
+    // are the FASTEST index (x = block * pairs + pair, y = clip), so that the workgroups that share
+    // cache lines of the interleaved frames run together (otherwise every line is fetched from HBM
+    // once per channel pair: 4.4x the algorithmic traffic at 8 channels).
     const bool cp = a.chpair != 0;
-    const uint32_t col = blockIdx.y;
     const uint32_t cpr = cp ? a.n_channels / 2 : a.n_channels;
-    const uint32_t ch = cp ? 2 * (col % cpr) : col % cpr, clip = col / cpr;
-    const int64_t pa = (cp ? 1 : 2) * (int64_t)blockIdx.x * a.hop_periods - a.lead_periods; // first period of block a
+    const uint32_t ch = cp ? 2 * (blockIdx.x % cpr) : blockIdx.y % cpr;
+    const uint32_t clip = cp ? blockIdx.y : blockIdx.y / cpr;
+    const int64_t bx = cp ? blockIdx.x / cpr : blockIdx.x;
+    const int64_t pa = (cp ? 1 : 2) * bx * a.hop_periods - a.lead_periods; // first period of block a
     const int64_t pb = cp ? pa : pa + a.hop_periods;                                         // ... of block b
     const int64_t ina = pa * a.M, inb = pb * a.M, outa = pa * a.L, outb = pb * a.L;
     const float *xin = (const float *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
@@ -800,7 +805,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const size_t lds = (size_t)std::max(g.N_in, g.N_out) * sizeof(float2);
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)use->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                const dim3 grid = a.chpair ? dim3((unsigned)n_blocks, (unsigned)(cols_p / 2), 1)
+                if (a.chpair && n_blocks * (int64_t)(j.n_channels / 2) > 2147483647LL) a.chpair = 0;
+                const dim3 grid = a.chpair ? dim3((unsigned)(n_blocks * (j.n_channels / 2)), j.n_clips, 1)
                                            : dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols_p, 1);
                 hipLaunchKernelGGL(use->kern, grid, dim3(use->nt), lds, (hipStream_t)stream, a);
                 HIP_TRY(hipGetLastError());
