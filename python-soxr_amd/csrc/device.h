@@ -38,6 +38,7 @@ struct Switches {
     bool fft_no_chpair = false;   // HIPSOXR_FFT_NO_CHPAIR    pair blocks even for interleaved even-channel data
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
+    bool fft_small_3pass = false; // HIPSOXR_FFT_SMALL_3PASS  small 147/160 blocks on the 3-pass (radix 16/21) schedule
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
     bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp

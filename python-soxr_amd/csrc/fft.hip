@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "device.h"
@@ -232,10 +233,14 @@ __device__ __forceinline__ void fft_pass(cf *buf, int N, int Ns, const cf *W)
 // `load(n)` supplies element n of the pass input (LDS, or global memory for the first pass) and
 // `store(n, v)` consumes element n of the pass output (LDS, or the output signal for the last
 // pass), so the first/last passes stream straight from/to HBM without an extra LDS round trip.
-template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, typename Load, typename Store>
-__device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store)
+// PRE: the butterfly's twiddle was fetched earlier (pre_w1, one butterfly per thread) — for small
+// jobs, whose cost is the latency of a single workgroup, every table read that follows a barrier
+// is an exposed L2 round trip; fetched at kernel start they all overlap with the input loads.
+template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, bool PRE = false, typename Load, typename Store>
+__device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store, cf pre_w1 = cf())
 {
     constexpr int nb = N / R, wstep = N / (Ns * R), NB = (nb + NT - 1) / NT;
+    static_assert(!PRE || (NB == 1 && R < 10), "prefetched twiddles: one butterfly per thread, radix < 10");
     cf u[NB][R];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -243,9 +248,12 @@ __device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store)
         if (NB * NT == nb || j < nb) {
             const int k = j % Ns;
             cf w1 = make_float2(1.f, 0.f);
-            if (Ns > 1) w1 = W[k * wstep]; // issued before the data reads: the latencies overlap
+            if (Ns > 1) w1 = PRE ? pre_w1 : W[k * wstep]; // issued before the data reads: the latencies overlap
 #pragma unroll
-            for (int t = 0; t < R; ++t) u[i][t] = load(j + t * nb);
+            for (int t = 0; t < R; ++t) {
+                if constexpr (std::is_invocable_v<Load, int, int>) u[i][t] = load(j + t * nb, t); // t: input slot
+                else u[i][t] = load(j + t * nb);
+            }
             if (Ns > 1) {
                 // Powers w^t of the butterfly's twiddle.  Any power formed from ONE rounded table
                 // entry inherits t times its phase error ((w(1+e))^t ~ w^t (1+te)), so for the large
@@ -299,6 +307,30 @@ __device__ __forceinline__ void fft_ct(cf *buf, const cf *W, Load first_load, St
     fft_pass_ct<N, R0 * R1, R2, SIGN, NT, true>(W, lds_load, lds_store);
     __syncthreads();
     fft_pass_ct<N, R0 * R1 * R2, R3, SIGN, NT, false>(W, lds_load, last_store);
+}
+
+// Twiddle of pass (Ns, R) for this thread's (single) butterfly, to be fetched ahead of time.
+template <int N, int Ns, int R, int NT> __device__ __forceinline__ cf pass_twiddle(const cf *W)
+{
+    constexpr int nb = N / R, wstep = N / (Ns * R);
+    const int j = threadIdx.x < nb ? threadIdx.x : 0;
+    return W[(j % Ns) * wstep];
+}
+// Four-pass transform whose twiddles (passes 2-4) were fetched by the caller.
+template <int N, int SIGN, int NT, int R0, int R1, int R2, int R3, typename Load, typename Store>
+__device__ __forceinline__ void fft_ct_pre(cf *buf, const cf *W, Load first_load, Store last_store, bool first_in_lds,
+                                           cf w1, cf w2, cf w3)
+{
+    auto lds_load = [&](int n) -> cf { return buf[n]; };
+    auto lds_store = [&](int n, cf v) { buf[n] = v; };
+    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, lds_store);
+    else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, lds_store);
+    __syncthreads();
+    fft_pass_ct<N, R0, R1, SIGN, NT, true, true>(W, lds_load, lds_store, w1);
+    __syncthreads();
+    fft_pass_ct<N, R0 * R1, R2, SIGN, NT, true, true>(W, lds_load, lds_store, w2);
+    __syncthreads();
+    fft_pass_ct<N, R0 * R1 * R2, R3, SIGN, NT, false, true>(W, lds_load, last_store, w3);
 }
 
 // Three-pass variant (larger radices: fewer LDS round trips and barriers).
@@ -499,11 +531,37 @@ __global__ void __launch_bounds__(256, Spec::ct ? 5 : 2) k_fft_block(FftArgs a)
 template <int NA_, int NB_, int NT_, int A0, int A1, int A2, bool ASWZ, int B0, int B1, int B2, bool BSWZ>
 struct PairSpec {
     static constexpr int NA = NA_, NB = NB_, NT = NT_;
-    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    static constexpr bool prefetch = false;
+    static constexpr int RB0 = B0;
+    struct Tw {};
+    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
     { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ>(b, W, ld, st, in_lds); }
-    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds)
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
     { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ>(b, W, ld, st, in_lds); }
 };
+// Four-pass variant (radices <= 8): more barriers but much shorter butterfly chains per pass —
+// the better trade for SMALL jobs, whose cost is the latency of one workgroup, not throughput.
+template <int NA_, int NB_, int NT_, int A0, int A1, int A2, int A3, int B0, int B1, int B2, int B3>
+struct PairSpec4 {
+    static constexpr int NA = NA_, NB = NB_, NT = NT_;
+    static constexpr bool prefetch = true;
+    static constexpr int RB0 = B0; // radix of the first inverse pass: how many filter values a thread needs
+    struct Tw { cf a1, a2, a3, b1, b2, b3; };
+    static __device__ __forceinline__ Tw twiddles(const cf *WA, const cf *WB)
+    {
+        Tw t;
+        t.a1 = pass_twiddle<NA, A0, A1, NT>(WA); t.a2 = pass_twiddle<NA, A0 * A1, A2, NT>(WA);
+        t.a3 = pass_twiddle<NA, A0 * A1 * A2, A3, NT>(WA);
+        t.b1 = pass_twiddle<NB, B0, B1, NT>(WB); t.b2 = pass_twiddle<NB, B0 * B1, B2, NT>(WB);
+        t.b3 = pass_twiddle<NB, B0 * B1 * B2, B3, NT>(WB);
+        return t;
+    }
+    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &t)
+    { fft_ct_pre<NA, -1, NT, A0, A1, A2, A3>(b, W, ld, st, in_lds, t.a1, t.a2, t.a3); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &t)
+    { fft_ct_pre<NB, +1, NT, B0, B1, B2, B3>(b, W, ld, st, in_lds, t.b1, t.b2, t.b3); }
+};
+typedef PairSpec4<2560, 2352, 512, 5, 8, 8, 8, 6, 7, 7, 8> Pair2560x2352L; // low-latency schedule
 // 48k <-> 44.1k (L/M = 147/160 and 160/147): k = 32, and k = 16 for small jobs
 typedef PairSpec<5120, 4704, 384, 16, 16, 20, true, 21, 16, 14, false> Pair5120x4704;
 typedef PairSpec<2560, 2352, 384, 16, 16, 10, true, 21, 16, 7, false> Pair2560x2352;
@@ -545,6 +603,22 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
     // (one instantiation of the transform for interior and edge blocks alike, so that both run the
     // same instruction sequence and round identically)
+    // small-job specs: every table value the workgroup will need (twiddles of the six twiddled
+    // passes, the filter values of the first inverse pass) is requested now, behind the input loads
+    typename Spec::Tw tw;
+    cf hpre[Spec::prefetch ? Spec::RB0 : 1];
+    if constexpr (Spec::prefetch) {
+        tw = Spec::twiddles(a.WA2, a.WB2);
+        constexpr int nbB = NB / Spec::RB0;
+        const int jb = (int)threadIdx.x < nbB ? (int)threadIdx.x : 0;
+#pragma unroll
+        for (int t = 0; t < Spec::RB0; ++t) {
+            const int n = jb + t * nbB, q = n > NB / 2 ? NB - n : n;
+            cf h = a.Hs[q];
+            if (n > NB / 2) h.y = -h.y;
+            hpre[t] = h;
+        }
+    }
     const bool interior = ina >= 0 && inb + NA <= a.in_frames && a.ifs < (1 << 16);
     const int32_t ifs32 = (int32_t)a.ifs;
     const bool unit = a.ifs == 1 && !cp;
@@ -561,7 +635,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
         const int64_t la = ina + n, lb = inb + n;
         return make_float2((la >= 0 && la < a.in_frames) ? xin[la * a.ifs] : 0.f,
                            (lb >= 0 && lb < a.in_frames) ? xin[lb * a.ifs + (cp ? 1 : 0)] : 0.f);
-    }, lds_store, false);
+    }, lds_store, false, tw);
     __syncthreads();
 #if defined(FFT_ABL) && (FFT_ABL & 4) // timing ablation (tools/fft_latency.sh): stop after the forward transform
     if (a.out_frames >= 0) return;
@@ -571,11 +645,16 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     //      frequencies) of the input grid, times H (Hermitian); result n = (y_a[n], y_b[n]) ---------
     float *yo = (float *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out;
-    auto h_load = [&](int n) -> cf {
+    auto h_load = [&](int n, int t) -> cf { // t: which of the butterfly's inputs (selects the prefetched H)
         const bool neg = n > NB / 2;
         const int q = neg ? NB - n : n; // |frequency| in bins
-        cf h = a.Hs[q];
-        if (neg) h.y = -h.y;
+        cf h;
+        if constexpr (Spec::prefetch) {
+            h = hpre[t];
+        } else {
+            h = a.Hs[q];
+            if (neg) h.y = -h.y;
+        }
         if constexpr (NA >= NB) { // down-sampling: the spectrum is truncated
             cf y = cmul(cur[neg ? n + (NA - NB) : n], h);
             if (n == NB / 2) y = cadd(y, cmul(cur[n + (NA - NB)], cconj(h)));
@@ -605,7 +684,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
             }
         }
     };
-    Spec::inv(cur, a.WB2, h_load, out_store, true);
+    Spec::inv(cur, a.WB2, h_load, out_store, true, tw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -781,6 +860,14 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     if (const char *err = get(2 + sml_i, sml->k, &gs)) return err;
                     if (gs.ok) { g = gs; use = sml; }
                 }
+            }
+            // Latency-bound jobs (everything resident at once, about one workgroup per CU slot):
+            // the four-pass schedule with prefetched tables has the shorter critical path (7.1 vs
+            // 9.0 us for one workgroup); from ~900 workgroups on, the three-pass one wins on work.
+            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT};
+            if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && !switches().fft_small_3pass) {
+                const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
+                if (wgs < 900) use = &low_latency;
             }
             if (use) {
                 FftArgs a;

@@ -50,7 +50,7 @@ const Switches &switches()
         auto num = [](const char *n) { const char *v = getenv(n); return v ? atoi(v) : 0; };
         w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
-        w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.no_planes = on("HIPSOXR_NO_PLANES");
+        w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_small_3pass = on("HIPSOXR_FFT_SMALL_3PASS"); w.no_planes = on("HIPSOXR_NO_PLANES");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
@@ -1863,7 +1863,7 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     if (!vr && (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO)) {
         const bool no_fft = switches().no_fft;
         const bool eligible = fft_job_eligible(*p, j);
-        const bool big = (int64_t)j.out_frames * j.n_clips * j.n_channels >= (1 << 18);
+        const bool big = (int64_t)j.out_frames * j.n_clips * j.n_channels >= (1 << 13); // even one block pair beats the tiled exact kernels (7 vs 10 us)
         if (j.kernel == HIPSOXR_KERNEL_FFT && !eligible)
             return "FFT engine needs a whole-signal float32 job (in_abs0 == 0, out_k0 == 0)";
         if (eligible && (j.kernel == HIPSOXR_KERNEL_FFT || (big && !no_fft))) {
