@@ -563,16 +563,29 @@ struct PairSpec4 {
 };
 typedef PairSpec4<2560, 2352, 512, 5, 8, 8, 8, 6, 7, 7, 8> Pair2560x2352L; // low-latency schedule
 // 48k <-> 44.1k (L/M = 147/160 and 160/147): k = 32, and k = 16 for small jobs
-typedef PairSpec<5120, 4704, 384, 16, 16, 20, true, 21, 16, 14, false> Pair5120x4704;
-typedef PairSpec<2560, 2352, 384, 16, 16, 10, true, 21, 16, 7, false> Pair2560x2352;
-typedef PairSpec<4704, 5120, 384, 21, 16, 14, false, 16, 16, 20, true> Pair4704x5120;
-typedef PairSpec<2352, 2560, 384, 21, 16, 7, false, 16, 16, 10, true> Pair2352x2560;
-// 44.1k <-> 16k (160/441 and 441/160): k = 16
-typedef PairSpec<7056, 2560, 448, 21, 16, 21, false, 16, 16, 10, true> Pair7056x2560;
-typedef PairSpec<2560, 7056, 448, 16, 16, 10, true, 21, 16, 21, false> Pair2560x7056;
-// 2:1 and 1:2: k = 2048
-typedef PairSpec<4096, 2048, 256, 16, 16, 16, true, 16, 16, 8, true> Pair4096x2048;
-typedef PairSpec<2048, 4096, 256, 16, 16, 8, true, 16, 16, 16, true> Pair2048x4096;
+// Three-pass schedule of each transform length in use (first radix 21: conflict-free as it is;
+// first radix 16: swizzled layout between pass 1 and 2).
+template <int N> struct Sched;
+#define HIPSOXR_SCHED(N, r0, r1, r2, swz) \
+    template <> struct Sched<N> { static constexpr int R0 = r0, R1 = r1, R2 = r2; static constexpr bool SWZ = swz; }
+HIPSOXR_SCHED(7056, 21, 16, 21, false);
+HIPSOXR_SCHED(5376, 21, 16, 16, false);
+HIPSOXR_SCHED(5120, 16, 16, 20, true);
+HIPSOXR_SCHED(4704, 21, 16, 14, false);
+HIPSOXR_SCHED(4096, 16, 16, 16, true);
+HIPSOXR_SCHED(3584, 14, 16, 16, false);
+HIPSOXR_SCHED(2560, 16, 16, 10, true);
+HIPSOXR_SCHED(2352, 21, 16, 7, false);
+HIPSOXR_SCHED(2048, 16, 16, 8, true);
+HIPSOXR_SCHED(1792, 7, 16, 16, false);
+HIPSOXR_SCHED(1280, 5, 16, 16, false);
+HIPSOXR_SCHED(1176, 21, 8, 7, false);
+HIPSOXR_SCHED(896, 7, 16, 8, false);
+#undef HIPSOXR_SCHED
+template <int NA, int NB, int NT>
+using PairOf = PairSpec<NA, NB, NT, Sched<NA>::R0, Sched<NA>::R1, Sched<NA>::R2, Sched<NA>::SWZ, Sched<NB>::R0, Sched<NB>::R1,
+                        Sched<NB>::R2, Sched<NB>::SWZ>;
+typedef PairOf<2560, 2352, 384> Pair2560x2352; // 147/160, small blocks (three-pass)
 
 template <typename Spec>
 __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
@@ -828,16 +841,24 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     };
     // ---- paired-block kernels: compile-time schedules for the common ratios -------------------
     struct PairEntry { int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; };
+#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT}
     static const PairEntry pairs[] = {
-        {147, 160, 32, false, k_fft_pair<Pair5120x4704>, Pair5120x4704::NT},
-        {147, 160, 16, true, k_fft_pair<Pair2560x2352>, Pair2560x2352::NT},
-        {160, 147, 32, false, k_fft_pair<Pair4704x5120>, Pair4704x5120::NT},
-        {160, 147, 16, true, k_fft_pair<Pair2352x2560>, Pair2352x2560::NT},
-        {160, 441, 16, false, k_fft_pair<Pair7056x2560>, Pair7056x2560::NT},
-        {441, 160, 16, false, k_fft_pair<Pair2560x7056>, Pair2560x7056::NT},
-        {1, 2, 2048, false, k_fft_pair<Pair4096x2048>, Pair4096x2048::NT},
-        {2, 1, 2048, false, k_fft_pair<Pair2048x4096>, Pair2048x4096::NT},
+        // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
+        HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
+        HIPSOXR_PAIR(160, 147, 32, false, 4704, 5120, 384), HIPSOXR_PAIR(160, 147, 16, true, 2352, 2560, 384),   // 44.1k -> 48k
+        HIPSOXR_PAIR(160, 441, 16, false, 7056, 2560, 448), HIPSOXR_PAIR(441, 160, 16, false, 2560, 7056, 448),  // 44.1k <-> 16k
+        HIPSOXR_PAIR(1, 2, 2048, false, 4096, 2048, 256), HIPSOXR_PAIR(2, 1, 2048, false, 2048, 4096, 256),      // 2:1, 1:2
+        HIPSOXR_PAIR(1, 3, 1792, false, 5376, 1792, 384), HIPSOXR_PAIR(3, 1, 1792, false, 1792, 5376, 384),      // 48k <-> 16k
+        HIPSOXR_PAIR(2, 3, 1792, false, 5376, 3584, 384), HIPSOXR_PAIR(3, 2, 1792, false, 3584, 5376, 384),      // 48k <-> 32k
+        HIPSOXR_PAIR(1, 4, 1280, false, 5120, 1280, 320), HIPSOXR_PAIR(4, 1, 1280, false, 1280, 5120, 320),      // 4:1, 1:4
+        HIPSOXR_PAIR(1, 6, 896, false, 5376, 896, 384), HIPSOXR_PAIR(6, 1, 896, false, 896, 5376, 384),          // 48k <-> 8k
+        HIPSOXR_PAIR(320, 441, 16, false, 7056, 5120, 448), HIPSOXR_PAIR(441, 320, 16, false, 5120, 7056, 448),  // 44.1k <-> 32k
+        HIPSOXR_PAIR(80, 147, 32, false, 4704, 2560, 384), HIPSOXR_PAIR(147, 80, 32, false, 2560, 4704, 384),    // 88.2k <-> 48k
+        HIPSOXR_PAIR(147, 320, 16, false, 5120, 2352, 384), HIPSOXR_PAIR(320, 147, 16, false, 2352, 5120, 384),  // 96k <-> 44.1k
+        HIPSOXR_PAIR(80, 441, 16, false, 7056, 1280, 448), HIPSOXR_PAIR(441, 80, 16, false, 1280, 7056, 448),    // 44.1k <-> 8k
+        HIPSOXR_PAIR(147, 640, 8, false, 5120, 1176, 320), HIPSOXR_PAIR(640, 147, 8, false, 1176, 5120, 320),    // 192k <-> 44.1k
     };
+#undef HIPSOXR_PAIR
     const bool no_pair = switches().fft_no_pair;
     const uint64_t cols_p = (uint64_t)j.n_clips * j.n_channels;
     if (!no_pair && cols_p <= 65535) {

@@ -96,6 +96,29 @@ def test_paired_kernel_families_at_size(oracle, in_rate, out_rate, frames):
     assert seg.max() <= 4e-6 * _rms(ref)
 
 
+@pytest.mark.parametrize("in_rate,out_rate", [(48000, 16000), (16000, 48000), (48000, 32000), (32000, 48000),
+                                              (192000, 48000), (48000, 192000), (48000, 8000), (8000, 48000),
+                                              (44100, 32000), (32000, 44100), (88200, 48000), (48000, 88200),
+                                              (96000, 44100), (44100, 96000), (44100, 8000), (8000, 44100),
+                                              (192000, 44100), (44100, 192000)])
+def test_paired_kernel_schedule_table(oracle, in_rate, out_rate):
+    """Every further ratio with a compile-time schedule (hipsoxr::launch_fft `pairs` table), HQ and
+    VHQ, mono (block pairing) and stereo interleaved (channel pairing), against the float64 oracle."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(int(in_rate + out_rate))
+    frames = int(0.9 * in_rate) + 17
+    x = (rng.standard_normal((frames, 2)) * 0.25).astype(np.float32)
+    for quality in ("VHQ", "HQ"):
+        plan = dev.Plan(in_rate, out_rate, quality)
+        ref = oracle.resample(x, in_rate, out_rate, quality, mode="ref")
+        y2 = dev.resample_tensor(plan, torch.from_numpy(x).cuda(), kernel=FFT).cpu().numpy()
+        y1 = dev.resample_tensor(plan, torch.from_numpy(np.ascontiguousarray(x[:, 0])).cuda(), kernel=FFT).cpu().numpy()
+        assert y2.shape == ref.shape
+        assert _rms(y2 - ref) <= 1e-6 * _rms(ref)
+        assert _rms(y1 - ref[:, 0]) <= 1e-6 * _rms(ref[:, 0])
+
+
 def test_fft_engine_refuses_what_it_cannot_do():
     import torch
     from soxr_amd import device as dev
