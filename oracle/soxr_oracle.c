@@ -94,23 +94,43 @@ API int oracle_ratio(double in_rate, double out_rate, int64_t *L, int64_t *M)
         return 0;
     }
     {
+        /* Continued fraction of out/in.  A convergent that reproduces the double ratio to 1e-15 is
+         * accepted at once; if the next convergent would leave the 31-bit range first, the best
+         * semiconvergent inside the range is taken instead (error below 1/(k*k_prev), i.e. still far
+         * below anything audible or measurable: a drift of less than one sample in 2^31). */
+        const int64_t LIM = 2147483647LL;
         double r = out_rate / in_rate, x = r;
         int64_t h0 = 0, h1 = 1, k0 = 1, k1 = 0;
         int it;
         for (it = 0; it < 64; ++it) {
             double a = floor(x);
             int64_t ai, h2, k2;
-            if (a > 2147483647.) return -1;
-            ai = (int64_t)a;
+            int over = a > (double)LIM;
+            ai = over ? LIM : (int64_t)a;
+            if (!over) {
+                over = (h1 && ai > (LIM - h0) / h1) || (k1 && ai > (LIM - k0) / k1);
+            }
+            if (over) {
+                int64_t amax = LIM;
+                if (k1 == 0) return -1; /* ratio itself beyond 2^31 */
+                if (h1 && (LIM - h0) / h1 < amax) amax = (LIM - h0) / h1;
+                if ((LIM - k0) / k1 < amax) amax = (LIM - k0) / k1;
+                if (amax >= 1) {
+                    int64_t hs = amax * h1 + h0, ks = amax * k1 + k0;
+                    if (fabs((double)hs / (double)ks - r) < fabs((double)h1 / (double)k1 - r)) { h1 = hs; k1 = ks; }
+                }
+                break;
+            }
             h2 = ai * h1 + h0; k2 = ai * k1 + k0;
-            if (h2 > 2147483647LL || k2 > 2147483647LL) return -1;
             h0 = h1; h1 = h2; k0 = k1; k1 = k2;
-            if (fabs((double)h1 / (double)k1 - r) <= 1e-15 * r) { *L = h1; *M = k1; return 0; }
-            if (x - a < 1e-300) return -1;
+            if (fabs((double)h1 / (double)k1 - r) <= 1e-15 * r) break;
+            if (x - a < 1e-300) break;
             x = 1. / (x - a);
         }
+        if (k1 <= 0 || h1 <= 0) return -1;
+        *L = h1; *M = k1;
+        return 0;
     }
-    return -1;
 }
 
 /* Modified Bessel function of the first kind, order 0 (power series, float64). */

@@ -884,11 +884,11 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             }
             // Latency-bound jobs (everything resident at once, about one workgroup per CU slot):
             // the four-pass schedule with prefetched tables has the shorter critical path (7.1 vs
-            // 9.0 us for one workgroup); from ~900 workgroups on, the three-pass one wins on work.
+            // 9.0 us for one workgroup); from ~400 workgroups on, the three-pass one wins on work.
             static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT};
             if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && !switches().fft_small_3pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
-                if (wgs < 900) use = &low_latency;
+                if (wgs < 400) use = &low_latency;
             }
             if (use) {
                 FftArgs a;

@@ -49,20 +49,37 @@ const char *reduce_ratio(double in_rate, double out_rate, int64_t *L, int64_t *M
         *L = a / g; *M = b / g;
         return nullptr;
     }
-    // continued fraction of out/in; accept a convergent that reproduces the double ratio
+    // Continued fraction of out/in.  A convergent that reproduces the double ratio to 1e-15 is taken
+    // at once; when the next convergent would leave the 31-bit range first, the best semiconvergent
+    // inside the range stands in (error < 1/(k k_prev): a drift below one sample in 2^31).
+    const int64_t LIM = 2147483647LL;
     double r = out_rate / in_rate, x = r;
     int64_t h0 = 0, h1 = 1, k0 = 1, k1 = 0;
     for (int it = 0; it < 64; ++it) {
-        double a = std::floor(x);
-        if (a > 2147483647.) break;
-        int64_t ai = (int64_t)a, h2 = ai * h1 + h0, k2 = ai * k1 + k0;
-        if (h2 > 2147483647LL || k2 > 2147483647LL) break;
+        const double a = std::floor(x);
+        bool over = a > (double)LIM;
+        const int64_t ai = over ? LIM : (int64_t)a;
+        if (!over) over = (h1 && ai > (LIM - h0) / h1) || (k1 && ai > (LIM - k0) / k1);
+        if (over) {
+            if (k1 == 0) return "rate ratio is out of range";
+            int64_t amax = LIM;
+            if (h1 && (LIM - h0) / h1 < amax) amax = (LIM - h0) / h1;
+            if ((LIM - k0) / k1 < amax) amax = (LIM - k0) / k1;
+            if (amax >= 1) {
+                const int64_t hs = amax * h1 + h0, ks = amax * k1 + k0;
+                if (std::fabs((double)hs / (double)ks - r) < std::fabs((double)h1 / (double)k1 - r)) { h1 = hs; k1 = ks; }
+            }
+            break;
+        }
+        const int64_t h2 = ai * h1 + h0, k2 = ai * k1 + k0;
         h0 = h1; h1 = h2; k0 = k1; k1 = k2;
-        if (std::fabs((double)h1 / (double)k1 - r) <= 1e-15 * r) { *L = h1; *M = k1; return nullptr; }
+        if (std::fabs((double)h1 / (double)k1 - r) <= 1e-15 * r) break;
         if (x - a < 1e-300) break;
         x = 1. / (x - a);
     }
-    return "rate ratio is not a usable rational number";
+    if (k1 <= 0 || h1 <= 0) return "rate ratio is out of range";
+    *L = h1; *M = k1;
+    return nullptr;
 }
 
 static double bessel_i0(double x)
