@@ -17,3 +17,11 @@ def test_random_cases_bit_identical_to_oracle(seed):
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "150/150" in p.stdout
+
+
+def test_fft_engine_random_cases_within_tolerance():
+    """tools/fuzz_fft_engine.py: random standard ratios, sizes, channel counts and layouts through the
+    device API (AUTO / FFT) against the float64 oracle, 1e-6 relative RMS and exact shapes."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_fft_engine.py"), "120", "21"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
