@@ -134,7 +134,7 @@ class ResampleStream:
                 if done.value == 0:
                     break
                 pos += done.value
-        return y[:pos].copy() if pos != cap else y
+        return y if pos == y.shape[0] else y[:pos].copy()  # (y may have grown during the flush)
 
     def resample_chunk(self, x, last=False):
         """Feed one chunk (1-D mono or 2-D [frame, channel], dtype as constructed); returns the

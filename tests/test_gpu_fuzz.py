@@ -25,3 +25,11 @@ def test_fft_engine_random_cases_within_tolerance():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_fft_engine.py"), "120", "21"],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_variable_rate_random_schedules_bit_identical():
+    """tools/fuzz_vr.py: random largest ratio, recipe, dtype, chunk sizes and ratio changes (jumps and
+    slews, also during a slew), against the oracle driven by tests/vr_sim.py — bit for bit per chunk."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vr.py"), "250", "31"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
