@@ -33,3 +33,11 @@ def test_variable_rate_random_schedules_bit_identical():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vr.py"), "250", "31"],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_device_api_exact_engine_random_cases_bit_identical():
+    """tools/fuzz_device_exact.py: random dtypes, ratios, batches, channel counts, layouts and
+    explicit kernel choices through resample_tensor — bit-identical to the oracle port."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_device_exact.py"), "200", "41"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
