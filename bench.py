@@ -37,9 +37,9 @@ KERNEL_NAMES = {0: "k_fft_pair (AUTO: frequency-domain engine, paired-block kern
                 1: "k_gather<float,float>", 2: "k_tile_mfma_p<float>", 3: "k_tile<float,float,16,true>",
                 4: "k_tile_mfma_p<float>", 5: "k_fft_pair", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
 # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 +
-# WRITE_SIZE, see profiles/r01e_traffic.json); bench.py cannot collect counters itself.
-TRAFFIC_BYTES = {("configs1", 0): 25196236, ("configs1", 5): 25196236,
-                 ("batch_shard", 0): 518897868, ("batch_shard", 5): 518897868}  # profiles/r01e_traffic.json
+# WRITE_SIZE, see profiles/r01f_traffic.json); bench.py cannot collect counters itself.
+TRAFFIC_BYTES = {("configs1", 0): 25155379, ("configs1", 5): 25155379,
+                 ("batch_shard", 0): 518675865, ("batch_shard", 5): 518675865}  # profiles/r01f_traffic.json
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
