@@ -36,6 +36,7 @@ struct Switches {
     bool no_fft = false;          // HIPSOXR_NO_FFT           AUTO never picks the frequency-domain engine
     bool fft_no_pair = false;     // HIPSOXR_FFT_NO_PAIR      one block per workgroup instead of the paired kernel
     bool fft_no_chpair = false;   // HIPSOXR_FFT_NO_CHPAIR    pair blocks even for interleaved even-channel data
+    bool fft_no_xcd_map = false;  // HIPSOXR_FFT_NO_XCD_MAP   plain (block, column) workgroup ids for interleaved data
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
     bool fft_small_3pass = false; // HIPSOXR_FFT_SMALL_3PASS  small 147/160 blocks on the 3-pass (radix 16/21) schedule

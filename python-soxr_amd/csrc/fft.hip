@@ -370,7 +370,8 @@ struct FftArgs {
     int64_t ics, ifs, ichs, ocs, ofs, ochs;
     int64_t in_frames, out_frames;
     int32_t chpair; // paired kernel: 1 = pair neighbouring channels of interleaved data instead of blocks
-    int64_t pairs_per_col; // channel-pair mode: number of blocks (grid.x is padded to a multiple of 8 of them)
+    int64_t pairs_per_col; // xcd_map: work items (blocks, or pairs of blocks) per channel unit
+    int32_t xcd_map;       // interleaved multi-channel data: XCD-aware workgroup ids (see k_fft_pair)
 };
 
 // butterflies per thread are bounded by N/(R*256) rounded up; lengths up to 4096
@@ -605,13 +606,16 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     // ids that are congruent mod 8 and adjacent in dispatch order (x = 8*(slot) + xcd,
     // slot = chunk*pairs + pair, block = 8*chunk + xcd).  Without this each line is fetched and
     // (partially) written once per channel pair: 2.3x / 4x the algorithmic bytes at 8 channels.
-    const bool cp = a.chpair != 0;
+    const bool cp = a.chpair != 0, xm = a.xcd_map != 0; // xcd_map: interleaved data (pairs of channels or single channels)
     const uint32_t cpr = cp ? a.n_channels / 2 : a.n_channels;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t ch = cp ? 2 * (slot % cpr) : blockIdx.y % cpr;
-    const uint32_t clip = cp ? blockIdx.y : blockIdx.y / cpr;
-    const int64_t bx = cp ? (int64_t)(slot / cpr) * 8 + xcd : blockIdx.x;
-    if (cp && bx >= a.pairs_per_col) return; // grid padded to a multiple of 8 blocks (pairs_per_col = blocks here)
+    // (integer division by a run-time divisor goes through the vector ALU: tell the compiler that the
+    // results are wave-uniform, or every address derived from them lives in VGPRs — +22 registers)
+    const uint32_t cu = __builtin_amdgcn_readfirstlane(xm ? slot % cpr : blockIdx.y % cpr); // channel unit: pair (cp) or channel
+    const uint32_t ch = cp ? 2 * cu : cu;
+    const uint32_t clip = __builtin_amdgcn_readfirstlane(xm ? blockIdx.y : blockIdx.y / cpr);
+    const int64_t bx = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane(xm ? (slot / cpr) * 8 + xcd : blockIdx.x);
+    if (xm && bx >= a.pairs_per_col) return; // grid.x is padded to a multiple of 8 work items per channel unit
     const int64_t pa = (cp ? 1 : 2) * bx * a.hop_periods - a.lead_periods; // first period of block a
     const int64_t pb = cp ? pa : pa + a.hop_periods;                                         // ... of block b
     const int64_t ina = pa * a.M, inb = pb * a.M, outa = pa * a.L, outb = pb * a.L;
@@ -918,11 +922,15 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const size_t lds = (size_t)std::max(g.N_in, g.N_out) * sizeof(float2);
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)use->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                const int64_t blocks8 = (n_blocks + 7) / 8 * 8;
-                if (a.chpair && blocks8 * (int64_t)(j.n_channels / 2) > 2147483647LL) a.chpair = 0;
-                a.pairs_per_col = n_blocks;
-                const dim3 grid = a.chpair ? dim3((unsigned)(blocks8 * (j.n_channels / 2)), j.n_clips, 1)
-                                           : dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols_p, 1);
+                // work items per channel unit: blocks (channel pairs) or pairs of blocks (single channels)
+                const int64_t items = a.chpair ? n_blocks : (n_blocks + 1) / 2, items8 = (items + 7) / 8 * 8;
+                const int64_t units = a.chpair ? j.n_channels / 2 : j.n_channels;
+                a.xcd_map = (j.n_channels > 1 && j.in_chan_stride == 1 && j.out_chan_stride == 1 && j.n_clips <= 65535 &&
+                             items8 * units <= 2147483647LL && !switches().fft_no_xcd_map) ? 1 : 0;
+                if (a.chpair && !a.xcd_map) a.chpair = 0; // (channel pairing is only laid out through the XCD map)
+                a.pairs_per_col = items;
+                const dim3 grid = a.xcd_map ? dim3((unsigned)(items8 * units), j.n_clips, 1)
+                                            : dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols_p, 1);
                 hipLaunchKernelGGL(use->kern, grid, dim3(use->nt), lds, (hipStream_t)stream, a);
                 HIP_TRY(hipGetLastError());
                 *handled = true;
