@@ -415,7 +415,9 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     uint32_t *cur = off + (P + 1);                                       // [P]     scatter cursors
 
     const uint32_t col = blockIdx.y;
-    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
+    // address derived from them) on the scalar side
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
     const int64_t o_base = (int64_t)blockIdx.x * KO;
     const int32_t n_here = (int32_t)((a.out_frames - o_base) < KO ? (a.out_frames - o_base) : KO);
     const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
@@ -740,7 +742,9 @@ __global__ void __launch_bounds__(1024) k_tile(TileArgs a)
     Real *xs = reinterpret_cast<Real *>(smem_raw);
 
     const uint32_t col = blockIdx.y;
-    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
+    // address derived from them) on the scalar side
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
     const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64; // first period of this workgroup
     const int32_t Mc = (int32_t)a.Mc, pad = a.pad;
 
@@ -871,7 +875,9 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
     Real *xs = reinterpret_cast<Real *>(smem_raw);
 
     const uint32_t col = blockIdx.y;
-    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
+    // address derived from them) on the scalar side
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
     const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64;
     const int32_t Mc = (int32_t)a.Mc, pad = a.pad, S = Mc + pad;
 
@@ -1150,7 +1156,9 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
     Real *xs = reinterpret_cast<Real *>(smem_raw) + R; // one row of slack below (pipelined reads run one group past the end)
 
     const uint32_t col = blockIdx.y;
-    const uint32_t ch = col % a.n_channels, clip = col / a.n_channels;
+    // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
+    // address derived from them) on the scalar side
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
     const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64;
     const int64_t k_end = a.out_k0 + a.out_frames;
     unsigned long long *tr = a.trace ? a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 : nullptr;
