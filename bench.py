@@ -57,8 +57,9 @@ def broadcast_bank(plan, rank, world, device):
     import torch.distributed as dist
     if world == 1:
         return
-    bank = torch.from_numpy(plan.bank()).to(device) if rank == 0 else \
-        torch.empty((plan.L, plan.taps), dtype=torch.float64, device=device)
+    dev_c = device if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo: test harness only)
+    bank = torch.from_numpy(plan.bank()).to(dev_c) if rank == 0 else \
+        torch.empty((plan.L, plan.taps), dtype=torch.float64, device=dev_c)
     dist.broadcast(bank, src=0)
     if rank != 0:
         plan.set_bank(bank.cpu().numpy())
@@ -91,7 +92,7 @@ def time_workload(plan, x, steps, warmup, world, device, kernel=0):
     wall = time.perf_counter() - t0
     kern = ev0.elapsed_time(ev1) * 1e-3 / steps
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        t = torch.tensor([wall], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, kern, y
@@ -228,11 +229,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # BENCH_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than
+    # ranks (ranks then share devices; for testing the harness, never for numbers)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     plan = dev.Plan(IN_RATE, OUT_RATE, QUALITY)
     broadcast_bank(plan, rank, world, device)

@@ -128,3 +128,25 @@ def test_prepared_job_equals_resample_tensor():
     dev.PreparedJob(plan, xb, yb2, kernel=dev.KERNEL_EXACT).launch()
     torch.cuda.synchronize()
     assert torch.equal(yb, yb2)
+
+
+def test_bench_two_ranks_harness():
+    """bench.py's N > 1 path (env ranks, bank broadcast, barrier-bracketed timing, max over ranks, one
+    JSON line from rank 0), exercised with two ranks sharing this box's GPU over gloo
+    (BENCH_DIST_BACKEND=gloo is a test harness switch; real runs use RCCL, one rank per GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "3", "--no-batch"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["cpu_baseline"] is None and "roofline" in d
