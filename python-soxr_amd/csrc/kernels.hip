@@ -51,7 +51,7 @@ const Switches &switches()
         w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_small_3pass = on("HIPSOXR_FFT_SMALL_3PASS"); w.no_planes = on("HIPSOXR_NO_PLANES");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
         w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
@@ -661,6 +661,10 @@ struct TileArgs {
     int64_t out_k0, out_frames;
     int64_t b_first;     // absolute (replicated) period index handled by lane 0 of block x = 0
     OutCtx oc;
+    // k_tile_mfma_p with a unit split Z > 1: XCD-aware ids.  The Z workgroups of a slab stage the
+    // same input; consecutive ids go to different XCDs (private L2s), so they are laid out as
+    // id = 8*(chunk*Z + z) + xcd  <->  slab = 8*chunk + xcd: same XCD, adjacent in dispatch order.
+    int32_t xz, nx;      // Z (0: plain 3-D grid), number of slabs
 };
 
 // Stage the input slab of one workgroup: samples [bw*Mc + i_min, +x_count) of column (clip, ch)
@@ -1159,7 +1163,15 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
     // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
     // address derived from them) on the scalar side
     const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64;
+    uint32_t bxi = blockIdx.x, bz = blockIdx.z, nz = gridDim.z;
+    if (a.xz) {
+        const uint32_t slot = blockIdx.x >> 3;
+        nz = (uint32_t)a.xz;
+        bz = __builtin_amdgcn_readfirstlane(slot % nz);
+        bxi = __builtin_amdgcn_readfirstlane((slot / nz) * 8 + (blockIdx.x & 7u));
+        if (bxi >= (uint32_t)a.nx) return; // grid.x is padded to a multiple of 8 slabs
+    }
+    const int64_t bw = a.b_first + (int64_t)bxi * 64;
     const int64_t k_end = a.out_k0 + a.out_frames;
     unsigned long long *tr = a.trace ? a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 : nullptr;
     int tri = 0;
@@ -1186,7 +1198,7 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
     // because 10-wave workgroups land 3/3/2/2 on the SIMDs and leave 17 % of the matrix pipe idle
     // (tools/ubench/mfma_loop.hip) — and its 2*n_rt equal units are dealt round-robin.
     // Small jobs additionally split a slab's units over gridDim.z workgroups (each stages the slab).
-    for (int u_ = wave + n_waves * (int)blockIdx.z; u_ < 2 * a.n_rt; u_ += n_waves * (int)gridDim.z) {
+    for (int u_ = wave + n_waves * (int)bz; u_ < 2 * a.n_rt; u_ += n_waves * (int)nz) {
         const int unit = __builtin_amdgcn_readfirstlane(u_);
         const int rt = unit >> 1, ph = unit & 1; // periods 32*ph .. 32*ph + 31
         const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]); // multiples of 16
@@ -1736,6 +1748,14 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         int split = (int)std::min<int64_t>((2 * g.n_rt + 3) / 4, (2 * 3 * 256) / std::max<int64_t>(wgs, 1));
         if (switches().dbg_split) split = switches().dbg_split;
         grid.z = (unsigned)std::max(1, split);
+        a.xz = 0; a.nx = (int32_t)n_blocks;
+        if (grid.z > 1 && !switches().no_xcd_split && (n_blocks + 7) / 8 * 8 * (int64_t)grid.z < 2147483647LL) {
+            a.xz = (int32_t)grid.z; // XCD-aware 1-D ids instead of the z dimension
+            grid.x = (unsigned)((n_blocks + 7) / 8 * 8 * (int64_t)grid.z);
+            grid.z = 1;
+        }
+    } else {
+        a.xz = 0; a.nx = (int32_t)n_blocks;
     }
     size_t lds_bytes = g.lds_bytes;
     lds_bytes = std::max<size_t>(lds_bytes, switches().dbg_lds); // occupancy experiments
