@@ -885,7 +885,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 // few work items (one 60 s clip = 300 pairs): half-size blocks give twice as many,
                 // shorter workgroups, at the price of more overlap
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
-                if ((wgs < 4 * 256 && !switches().fft_large_only) || switches().fft_small_only) {
+                if ((wgs < 480 && !switches().fft_large_only) || switches().fft_small_only) { // measured crossover: ~470 pairs of large blocks
                     FftGeom gs;
                     if (const char *err = get(2 + sml_i, sml->k, &gs)) return err;
                     if (gs.ok) { g = gs; use = sml; }
