@@ -40,6 +40,11 @@ KERNEL_NAMES = {0: "k_fft_pair (AUTO: frequency-domain engine, paired-block kern
 # WRITE_SIZE, see profiles/r01f_traffic.json); bench.py cannot collect counters itself.
 TRAFFIC_BYTES = {("configs1", 0): 25155379, ("configs1", 5): 25155379,
                  ("batch_shard", 0): 518675865, ("batch_shard", 5): 518675865}  # profiles/r01f_traffic.json
+# VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/r01f_rocprofv3_summary.txt): the other
+# resource the frequency-domain kernel is limited by.  An fp32 wave-instruction occupies a SIMD for
+# 2 cycles (SIMD-32, wave64); 256 CUs x 4 SIMDs at 2.4 GHz.
+VALU_INSTS = {("configs1", 0): 3820144, ("configs1", 5): 3820144, ("batch_shard", 0): 69569280, ("batch_shard", 5): 69569280}
+VALU_SLOTS_PER_S = 256 * 4 * 2.4e9 / 2
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
@@ -271,6 +276,8 @@ def main():
                      "traffic": TRAFFIC_BYTES.get(("configs1", args.kernel)) if args.seconds == 60 else None,
                      "kernel": KERNEL_NAMES.get(args.kernel, "auto"), "launch_us": kern * 1e6,
                      "algorithmic_bytes_per_launch": algo_bytes,
+                     "valu_issue_frac": (VALU_INSTS[("configs1", args.kernel)] / (VALU_SLOTS_PER_S * kern)
+                                         if ("configs1", args.kernel) in VALU_INSTS and args.seconds == 60 else None),
                      "direct_form_equiv_tflops": flops / kern / 1e12},
     }
 
@@ -293,6 +300,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": bbytes / bkern / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bbytes / bkern / 1e9 / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES.get(("batch_shard", args.kernel)) if clips == 128 else None,
+                         "valu_issue_frac": (VALU_INSTS[("batch_shard", args.kernel)] / (VALU_SLOTS_PER_S * bkern)
+                                             if ("batch_shard", args.kernel) in VALU_INSTS and clips == 128 else None),
                          "launch_us": bkern * 1e6, "direct_form_equiv_tflops": bflops / bkern / 1e12}}
         del xb, yb
 
