@@ -2,9 +2,9 @@
 """Randomised check of the exact engine through the device API (resample_tensor, KERNEL_EXACT and
 the explicit kernels): random dtypes, ratios (standard / arbitrary), batches, channel counts,
 layouts — bit-identical to the oracle's canonical-order port.
-`python tools/fuzz_device_exact.py [cases] [seed]`"""
+`python tests/fuzz/fuzz_device_exact.py [cases] [seed]`"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "python-soxr_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 import torch

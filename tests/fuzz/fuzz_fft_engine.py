@@ -2,9 +2,9 @@
 """Randomised check of the frequency-domain engine (device API, AUTO/FFT) against the float64
 oracle: random ratios from the schedule table and outside it, lengths, channel counts, layouts
 (interleaved / planar / batched).  Bar: 1e-6 relative RMS, exact shapes.
-`python tools/fuzz_fft_engine.py [cases] [seed]`"""
+`python tests/fuzz/fuzz_fft_engine.py [cases] [seed]`"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "python-soxr_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 import torch

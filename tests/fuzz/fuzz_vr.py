@@ -2,9 +2,9 @@
 """Randomised check of variable-rate streams against the oracle driven by the integer clock
 restatement (tests/vr_sim.py): random largest ratio, recipe, dtype, chunk sizes, ratio changes with
 random slew lengths (including changes during a slew and zero-length chunks).  Bit-exact, chunk by
-chunk.  `python tools/fuzz_vr.py [cases] [seed]`"""
+chunk.  `python tests/fuzz/fuzz_vr.py [cases] [seed]`"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(ROOT, "python-soxr_amd"), ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Randomised differential test: soxr_amd (GPU) against the CPU oracle, bit for bit, over random
 rates (standard, random integer, random float), dtypes, recipes, lengths, channel counts, layouts,
-one-shot and chunked.  `python tools/fuzz_vs_oracle.py [cases] [seed]`"""
+one-shot and chunked.  `python tests/fuzz/fuzz_vs_oracle.py [cases] [seed]`"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "python-soxr_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 import soxr_amd as soxr

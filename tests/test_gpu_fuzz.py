@@ -1,4 +1,4 @@
-"""GPU: randomised differential test against the oracle (tools/fuzz_vs_oracle.py) — random standard /
+"""GPU: randomised differential test against the oracle (tests/fuzz/fuzz_vs_oracle.py) — random standard /
 integer / float rate pairs, dtypes, recipes, lengths (including 0, 1, 2), channel counts, C and
 Fortran layouts, one-shot and chunked streams; every case must be bit-identical."""
 import os
@@ -13,31 +13,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_cases_bit_identical_to_oracle(seed):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_oracle.py"), "150", str(seed)],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_vs_oracle.py"), "150", str(seed)],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "150/150" in p.stdout
 
 
 def test_fft_engine_random_cases_within_tolerance():
-    """tools/fuzz_fft_engine.py: random standard ratios, sizes, channel counts and layouts through the
+    """tests/fuzz/fuzz_fft_engine.py: random standard ratios, sizes, channel counts and layouts through the
     device API (AUTO / FFT) against the float64 oracle, 1e-6 relative RMS and exact shapes."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_fft_engine.py"), "120", "21"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_fft_engine.py"), "120", "21"],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
 
 
 def test_variable_rate_random_schedules_bit_identical():
-    """tools/fuzz_vr.py: random largest ratio, recipe, dtype, chunk sizes and ratio changes (jumps and
+    """tests/fuzz/fuzz_vr.py: random largest ratio, recipe, dtype, chunk sizes and ratio changes (jumps and
     slews, also during a slew), against the oracle driven by tests/vr_sim.py — bit for bit per chunk."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vr.py"), "250", "31"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_vr.py"), "250", "31"],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
 
 
 def test_device_api_exact_engine_random_cases_bit_identical():
-    """tools/fuzz_device_exact.py: random dtypes, ratios, batches, channel counts, layouts and
+    """tests/fuzz/fuzz_device_exact.py: random dtypes, ratios, batches, channel counts, layouts and
     explicit kernel choices through resample_tensor — bit-identical to the oracle port."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_device_exact.py"), "200", "41"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_device_exact.py"), "200", "41"],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]

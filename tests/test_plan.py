@@ -88,7 +88,7 @@ def test_invalid_plans():
 INTERP_RATES = [(48000, 44101), (44100.123456789, 47999.987654321), (95999, 8001), (8000.5, 96000.25),
                 (12345.678, 54321.9), (77777, 33333.3),
                 # a ratio whose continued fraction leaves the 31-bit range before reaching 1e-15: the
-                # best semiconvergent inside the range stands in (found by tools/fuzz_vs_oracle.py)
+                # best semiconvergent inside the range stands in (found by tests/fuzz/fuzz_vs_oracle.py)
                 (51387.21808175107, 37891.91119494756)]
 
 
