@@ -230,7 +230,11 @@ hipsoxr_error_t hipsoxr_plan_create(double in_rate, double out_rate, unsigned lo
     return nullptr;
 }
 
-void hipsoxr_plan_delete(hipsoxr_plan_t *h) { delete h; }
+void hipsoxr_plan_delete(hipsoxr_plan_t *h)
+{
+    if (h && h->cached) return; // a stream's plan (hipsoxr_stream_plan) belongs to the plan cache, not to the caller
+    delete h;
+}
 
 hipsoxr_error_t hipsoxr_plan_info(const hipsoxr_plan_t *h, hipsoxr_plan_info_t *info)
 {
