@@ -115,6 +115,10 @@ typedef struct {
 
 HIPSOXR_API hipsoxr_error_t hipsoxr_plan_create(double in_rate, double out_rate,
                                                 unsigned long recipe, hipsoxr_plan_t **out);
+/* The plan a variable-rate stream created with the same arguments uses (always an interpolated-phase
+ * table, designed for the largest io ratio in_rate/out_rate; reference: src/soxr_ext.cpp:74).  Host only. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_plan_create_vr(double in_rate, double out_rate,
+                                                   unsigned long recipe, hipsoxr_plan_t **out);
 HIPSOXR_API void hipsoxr_plan_delete(hipsoxr_plan_t *);
 HIPSOXR_API hipsoxr_error_t hipsoxr_plan_info(const hipsoxr_plan_t *, hipsoxr_plan_info_t *info);
 /* Copy the float64 bank (phase-major [L][taps], or [P][taps][4]) into dst (n = bank_elems doubles). */

@@ -5,6 +5,16 @@ product package (python-soxr_amd/).  See the header of soxr_oracle.c for what it
 parity status ("parity unpinned" against libsoxr itself; pinned against the reference's
 known-answer tests).
 
+Two halves: the filter DESIGN is oracle/design.py (numpy/scipy, a formulation deliberately unlike the
+product's plan.cpp); the ARITHMETIC, given a bank, is soxr_oracle.c.  Which bank a comparison
+uses decides what it tests:
+  mode="ref"  always runs on the oracle's OWN bank (design.py): GPU-vs-ref comparisons (<= 1e-6)
+              therefore check design and arithmetic against independently written code;
+  mode="port" checks the ORDER of the arithmetic bit for bit, which is only meaningful on identical
+              coefficients: when `bank_provider` is set (tests/conftest.py, smoke(), installed from
+              the product's C ABI: hipsoxr_plan_get_bank) port mode runs on the product's float64
+              bank; the two banks themselves are compared in tests/test_design_independent.py.
+
 `resample(x, in_rate, out_rate, quality, mode)` mirrors soxr.resample's array contract
 (/root/reference/src/soxr/__init__.py:182-231): 1-D or 2-D [frame, channel] input of dtype
 float32/float64/int16/int32, same ndim/dtype out, floor(n*out/in + 1/2) frames.
@@ -17,6 +27,8 @@ import os
 import subprocess
 
 import numpy as np
+
+from . import design
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
@@ -45,25 +57,16 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         i64, i32, u32, u64, dbl = C.c_int64, C.c_int32, C.c_uint32, C.c_uint64, C.c_double
         P = C.POINTER
-        L.oracle_quality.argtypes = [C.c_ulong, P(dbl), P(dbl), P(dbl)]
-        L.oracle_ratio.argtypes = [dbl, dbl, P(i64), P(i64)]
-        L.oracle_plan.argtypes = [dbl, dbl, C.c_ulong, P(i64), P(i64), P(i32), P(dbl), P(dbl)]
-        L.oracle_design_bank.argtypes = [dbl, dbl, C.c_ulong, C.c_void_p]
         L.oracle_out_len.argtypes = [u64, i64, i64]
         L.oracle_out_len.restype = u64
         for name in ("oracle_resample_ref", "oracle_resample_port_f64", "oracle_resample_port_f32"):
             getattr(L, name).argtypes = [C.c_void_p, i64, i64, i32, C.c_void_p, i64, i64,
                                          C.c_void_p, i64, i64]
             getattr(L, name).restype = None
-        L.oracle_plan_phases.argtypes = [dbl, dbl, C.c_ulong]
-        L.oracle_plan_phases.restype = i32
-        L.oracle_design_interp.argtypes = [dbl, dbl, C.c_ulong, C.c_void_p]
-        L.oracle_interp_exact_coefs.argtypes = [dbl, dbl, C.c_ulong, dbl, C.c_void_p]
         for name in ("oracle_interp_ref", "oracle_interp_port_f64", "oracle_interp_port_f32"):
             getattr(L, name).argtypes = [C.c_void_p, i32, i64, i64, i32, C.c_void_p, i64, i64,
                                          C.c_void_p, i64, i64]
             getattr(L, name).restype = None
-        L.oracle_design_vr.argtypes = [dbl, dbl, C.c_ulong, P(i32), P(i32), C.c_void_p]
         for name in ("oracle_vr_ref", "oracle_vr_port_f64", "oracle_vr_port_f32"):
             getattr(L, name).argtypes = [C.c_void_p, i32, i32, C.c_void_p, i64, i64, C.c_void_p, i64] + [u64] * 6
             getattr(L, name).restype = None
@@ -84,42 +87,43 @@ def quality_enum(q):
 
 
 def quality(recipe):
-    b, p, s = C.c_double(), C.c_double(), C.c_double()
-    if lib().oracle_quality(quality_enum(recipe), b, p, s):
-        raise ValueError("bad recipe")
-    return b.value, p.value, s.value
+    return design.quality(quality_enum(recipe))
+
+
+# Optional source of the PRODUCT's float64 bank for port-mode (bit-exact arithmetic-order) checks:
+# callable(in_rate, out_rate, recipe, vr) -> ndarray, installed by tests/conftest.py and smoke().
+bank_provider = None
 
 
 class Plan:
-    """Geometry + float64 bank for (in_rate, out_rate, recipe): [L][T] for an exact plan
-    (phases == 0), else the interpolated-phase table [P][T][4] (phases == P)."""
+    """Geometry + float64 bank for (in_rate, out_rate, recipe), designed by oracle/design.py:
+    [L][T] for an exact plan (phases == 0), else the interpolated-phase table [P][T][4]."""
 
     def __init__(self, in_rate, out_rate, recipe="HQ"):
         self.in_rate, self.out_rate, self.recipe = float(in_rate), float(out_rate), quality_enum(recipe)
-        L, M, T = C.c_int64(), C.c_int64(), C.c_int32()
-        att, beta = C.c_double(), C.c_double()
-        rc = lib().oracle_plan(self.in_rate, self.out_rate, self.recipe, L, M, T, att, beta)
-        if rc:
-            raise ValueError(f"oracle_plan failed ({rc})")
-        self.L, self.M, self.T, self.att_db, self.beta = L.value, M.value, T.value, att.value, beta.value
-        self.phases = int(lib().oracle_plan_phases(self.in_rate, self.out_rate, self.recipe))
-        if self.phases < 0:
-            raise ValueError("oracle_plan_phases failed")
+        g = design.geometry(self.in_rate, self.out_rate, self.recipe)
+        self.L, self.M, self.T, self.att_db, self.beta = g["L"], g["M"], g["T"], g["att_db"], g["beta"]
+        self.phases = g["phases"]
         if self.phases:
-            self.bank = np.empty((self.phases, self.T, 4), np.float64)
-            if lib().oracle_design_interp(self.in_rate, self.out_rate, self.recipe, self.bank.ctypes.data):
-                raise ValueError("oracle_design_interp failed")
+            self.bank = design.interp_table(self.in_rate, self.out_rate, self.recipe)
         else:
-            self.bank = np.empty((self.L, self.T), np.float64)
-            if lib().oracle_design_bank(self.in_rate, self.out_rate, self.recipe, self.bank.ctypes.data):
-                raise ValueError("oracle_design_bank failed")
+            self.bank = design.bank(self.in_rate, self.out_rate, self.recipe)
+        self._port_bank = None
+
+    @property
+    def port_bank(self):
+        """Bank for port-mode runs: the product's when a provider is installed, else our own."""
+        if bank_provider is None:
+            return self.bank
+        if self._port_bank is None:
+            b = np.ascontiguousarray(bank_provider(self.in_rate, self.out_rate, self.recipe, False), np.float64)
+            assert b.shape == self.bank.shape, (b.shape, self.bank.shape)
+            self._port_bank = b
+        return self._port_bank
 
     def exact_coefs(self, f):
         """Un-interpolated coefficients c_j(f) of an interpolated-phase plan (accuracy checks)."""
-        c = np.empty(self.T, np.float64)
-        if lib().oracle_interp_exact_coefs(self.in_rate, self.out_rate, self.recipe, float(f), c.ctypes.data):
-            raise ValueError("oracle_interp_exact_coefs failed")
-        return c
+        return design.exact_coefs(self.in_rate, self.out_rate, self.recipe, f)
 
     def out_len(self, n_in):
         return int(lib().oracle_out_len(int(n_in), self.L, self.M))
@@ -138,7 +142,9 @@ def plan(in_rate, out_rate, recipe="HQ"):
 def resample_channel(pl, x, mode, k0=0, n_out=None, in_abs0=0, bank=None):
     """One planar channel.  x: float32 (port f32), float64 (port f64 / ref).  Returns the engine
     output before integer quantisation."""
-    bank = pl.bank if bank is None else np.ascontiguousarray(bank, np.float64)
+    if bank is None:
+        bank = pl.bank if mode == "ref" else pl.port_bank
+    bank = np.ascontiguousarray(bank, np.float64)
     if n_out is None:
         n_out = pl.out_len(len(x)) - k0
     if mode == "ref":
@@ -164,16 +170,19 @@ def resample_channel(pl, x, mode, k0=0, n_out=None, in_abs0=0, bank=None):
 
 
 class VrPlan:
-    """The table of a variable-rate stream created with (in_rate, out_rate) = the largest io ratio."""
+    """The table of a variable-rate stream created with (in_rate, out_rate) = the largest io ratio:
+    always an interpolated-phase table, whatever the ratio."""
 
     def __init__(self, in_rate, out_rate, recipe="HQ"):
-        T, P = C.c_int32(), C.c_int32()
         r = quality_enum(recipe)
-        if lib().oracle_design_vr(float(in_rate), float(out_rate), r, T, P, None):
-            raise ValueError("oracle_design_vr failed")
-        self.T, self.phases = T.value, P.value
-        self.bank = np.empty((self.phases, self.T, 4), np.float64)
-        lib().oracle_design_vr(float(in_rate), float(out_rate), r, T, P, self.bank.ctypes.data)
+        self.T = design.geometry(float(in_rate), float(out_rate), r)["T"]
+        self.phases = design.vr_phases(r)
+        self.bank = design.interp_table(float(in_rate), float(out_rate), r, self.phases)
+        self.port_bank = self.bank
+        if bank_provider is not None:
+            b = np.ascontiguousarray(bank_provider(float(in_rate), float(out_rate), r, True), np.float64)
+            assert b.shape == self.bank.shape, (b.shape, self.bank.shape)
+            self.port_bank = b
 
 
 def vr_run(vp, x, mode, n_out, T0, S0, D, in_abs0=0):
@@ -186,7 +195,8 @@ def vr_run(vp, x, mode, n_out, T0, S0, D, in_abs0=0):
     for v in (T0, S0, D):
         v &= (1 << 128) - 1
         words += [v >> 64, v & ((1 << 64) - 1)]
-    getattr(lib(), "oracle_vr_" + mode)(vp.bank.ctypes.data, vp.phases, vp.T, x.ctypes.data, in_abs0, len(x),
+    bank = vp.bank if mode == "ref" else vp.port_bank
+    getattr(lib(), "oracle_vr_" + mode)(bank.ctypes.data, vp.phases, vp.T, x.ctypes.data, in_abs0, len(x),
                                         y.ctypes.data, n_out, *words)
     return y
 

@@ -230,6 +230,21 @@ hipsoxr_error_t hipsoxr_plan_create(double in_rate, double out_rate, unsigned lo
     return nullptr;
 }
 
+hipsoxr_error_t hipsoxr_plan_create_vr(double in_rate, double out_rate, unsigned long recipe,
+                                       hipsoxr_plan_t **out)
+{
+    if (!out) return "null argument";
+    *out = nullptr;
+    hipsoxr_plan *h = new (std::nothrow) hipsoxr_plan();
+    if (!h) return "out of memory";
+    if (const char *e = plan_design(in_rate, out_rate, recipe, &h->p, /*force_interp=*/true)) {
+        delete h;
+        return e;
+    }
+    *out = h;
+    return nullptr;
+}
+
 void hipsoxr_plan_delete(hipsoxr_plan_t *h)
 {
     if (h && h->cached) return; // a stream's plan (hipsoxr_stream_plan) belongs to the plan cache, not to the caller
@@ -277,7 +292,7 @@ hipsoxr_error_t hipsoxr_run_device(hipsoxr_plan_t *h, const hipsoxr_job_t *job, 
     if (!h || !job) return "null argument";
     if (job->elem < 0 || job->elem > 3) return "invalid element type";
     if (job->out_frames < 0 || job->in_frames < 0 || job->out_k0 < 0) return "invalid job extent";
-    if (job->out_frames > 0 && (!job->in || !job->out) && job->in_frames > 0) return "null buffer";
+    if ((job->out_frames > 0 && !job->out) || (job->out_frames > 0 && job->in_frames > 0 && !job->in)) return "null buffer";
     if (device_count() <= 0) return kNoDevice;
     return launch_job(&h->p, *job, hip_stream);
 }

@@ -919,7 +919,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                             j.in_frame_stride % 2 == 0 && j.out_frame_stride % 2 == 0 && j.in_clip_stride % 2 == 0 &&
                             j.out_clip_stride % 2 == 0 && ((uintptr_t)j.in & 7) == 0 && ((uintptr_t)j.out & 7) == 0 &&
                             !switches().fft_no_chpair) ? 1 : 0;
-                const size_t lds = (size_t)std::max(g.N_in, g.N_out) * sizeof(float2);
+                const size_t lds = std::max((size_t)std::max(g.N_in, g.N_out) * sizeof(float2), switches().dbg_fft_lds);
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)use->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 // work items per channel unit: blocks (channel pairs) or pairs of blocks (single channels)

@@ -49,16 +49,27 @@ const char *reduce_ratio(double in_rate, double out_rate, int64_t *L, int64_t *M
         *L = a / g; *M = b / g;
         return nullptr;
     }
-    // Continued fraction of out/in.  A convergent that reproduces the double ratio to 1e-15 is taken
-    // at once; when the next convergent would leave the 31-bit range first, the best semiconvergent
-    // inside the range stands in (error < 1/(k k_prev): a drift below one sample in 2^31).
+    // Continued fraction of the double quotient r = out/in, expanded EXACTLY: r = mant * 2^ex is a
+    // rational with a power-of-two denominator, so Euclid's algorithm on (numerator, denominator) in
+    // 128-bit integers yields its true partial quotients (iterating x -> 1/(x - a) in doubles drifts
+    // off them after ~10 levels).  A convergent that reproduces r to 1e-15 (tested in doubles, the
+    // way the result will be used) is taken at once; when the next convergent would leave the 31-bit
+    // range first, the best semiconvergent inside the range stands in (error < 1/(k k_prev): a drift
+    // below one sample in 2^31).
     const int64_t LIM = 2147483647LL;
-    double r = out_rate / in_rate, x = r;
+    const double r = out_rate / in_rate;
+    if (!(r > 0) || !std::isfinite(r)) return "rate ratio is out of range";
+    int ex = 0;
+    const double fr = std::frexp(r, &ex); // r = fr * 2^ex, fr in [0.5, 1)
+    unsigned __int128 num = (unsigned __int128)(uint64_t)std::ldexp(fr, 53), den = 1;
+    ex -= 53;                              // r = num * 2^ex
+    if (ex > 40 || ex < -110) return "rate ratio is out of range";
+    if (ex >= 0) num <<= ex; else den <<= -ex;
     int64_t h0 = 0, h1 = 1, k0 = 1, k1 = 0;
-    for (int it = 0; it < 64; ++it) {
-        const double a = std::floor(x);
-        bool over = a > (double)LIM;
-        const int64_t ai = over ? LIM : (int64_t)a;
+    for (int it = 0; it < 128 && den != 0; ++it) {
+        const unsigned __int128 a128 = num / den, rem = num % den;
+        bool over = a128 > (unsigned __int128)LIM;
+        const int64_t ai = over ? LIM : (int64_t)a128;
         if (!over) over = (h1 && ai > (LIM - h0) / h1) || (k1 && ai > (LIM - k0) / k1);
         if (over) {
             if (k1 == 0) return "rate ratio is out of range";
@@ -74,8 +85,7 @@ const char *reduce_ratio(double in_rate, double out_rate, int64_t *L, int64_t *M
         const int64_t h2 = ai * h1 + h0, k2 = ai * k1 + k0;
         h0 = h1; h1 = h2; k0 = k1; k1 = k2;
         if (std::fabs((double)h1 / (double)k1 - r) <= 1e-15 * r) break;
-        if (x - a < 1e-300) break;
-        x = 1. / (x - a);
+        num = den; den = rem;
     }
     if (k1 <= 0 || h1 <= 0) return "rate ratio is out of range";
     *L = h1; *M = k1;

@@ -77,6 +77,7 @@ SIGNATURES = {
     "hipsoxr_version": (C.c_char_p, []),
     "hipsoxr_device_count": (C.c_int, []),
     "hipsoxr_plan_create": (_err, [C.c_double, C.c_double, C.c_ulong, _P(C.c_void_p)]),
+    "hipsoxr_plan_create_vr": (_err, [C.c_double, C.c_double, C.c_ulong, _P(C.c_void_p)]),
     "hipsoxr_plan_delete": (None, [C.c_void_p]),
     "hipsoxr_plan_info": (_err, [C.c_void_p, _P(PlanInfo)]),
     "hipsoxr_plan_get_bank": (_err, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -18,12 +18,13 @@ from ._native import (KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILE, KERNEL_TILE_VALU,
 class Plan:
     """Immutable conversion plan: ratio L/M, polyphase bank, device tables (built lazily)."""
 
-    def __init__(self, in_rate, out_rate, quality="HQ"):
+    def __init__(self, in_rate, out_rate, quality="HQ", vr=False):
+        """vr=True: the plan of a variable-rate stream (always an interpolated-phase table)."""
         if in_rate <= 0 or out_rate <= 0:
             raise ValueError("Sample rate should be over 0")
         self._h = _C.c_void_p()
-        _n.check(_n.lib.hipsoxr_plan_create(float(in_rate), float(out_rate), _quality_to_enum(quality),
-                                            _C.byref(self._h)))
+        create = _n.lib.hipsoxr_plan_create_vr if vr else _n.lib.hipsoxr_plan_create
+        _n.check(create(float(in_rate), float(out_rate), _quality_to_enum(quality), _C.byref(self._h)))
         info = _n.PlanInfo()
         _n.check(_n.lib.hipsoxr_plan_info(self._h, _C.byref(info)))
         self.in_rate, self.out_rate = info.in_rate, info.out_rate

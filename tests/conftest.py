@@ -43,8 +43,19 @@ def _init_torch_first():
         pass
 
 
+def product_bank(in_rate, out_rate, recipe, vr):
+    """The product's float64 bank through its C ABI (host only: hipsoxr_plan_create[_vr] +
+    hipsoxr_plan_get_bank) — what oracle port-mode runs on, so that a bit-for-bit comparison tests
+    the order of the arithmetic and nothing else.  The DESIGN is compared separately, against the
+    oracle's own numpy design (tests/test_design_independent.py)."""
+    from soxr_amd import device as dev
+    return dev.Plan(in_rate, out_rate, int(recipe), vr=bool(vr)).bank()
+
+
 def pytest_sessionstart(session):
     _init_torch_first()
+    from oracle import oracle as o
+    o.bank_provider = product_bank
 
 
 def pytest_report_header(config):

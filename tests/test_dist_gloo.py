@@ -55,9 +55,11 @@ def test_two_rank_sharding_and_bank_broadcast(tmp_path, n_clips, oracle):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, n_clips, str(tmp_path)), nprocs=world, join=True)
     r = [np.load(os.path.join(tmp_path, f"rank{i}.npz")) for i in range(world)]
-    # both ranks hold rank 0's bank, bit for bit, and it is the designed bank
+    # both ranks hold rank 0's bank, bit for bit, and it is the designed bank (the product's own,
+    # which in turn equals the oracle's independent numpy design to 1e-13: test_design_independent.py)
     assert np.array_equal(r[0]["bank"], r[1]["bank"])
-    assert np.array_equal(r[0]["bank"], oracle.plan(48000, 44100, "HQ").bank)
+    assert np.array_equal(r[0]["bank"], oracle.plan(48000, 44100, "HQ").port_bank)
+    assert np.abs(r[0]["bank"] - oracle.plan(48000, 44100, "HQ").bank).max() <= 1e-13
     # shards are disjoint, contiguous and cover every clip
     assert int(r[0]["lo"]) == 0 and int(r[0]["hi"]) == int(r[1]["lo"]) and int(r[1]["hi"]) == n_clips
     # the union of per-rank results equals the unsharded computation

@@ -12,15 +12,16 @@ QUALS = ["VHQ", "HQ", "MQ", "LQ", "QQ"]
 
 @pytest.mark.parametrize("in_rate,out_rate", RATES)
 @pytest.mark.parametrize("quality", QUALS)
-def test_bank_identical_to_oracle(oracle, in_rate, out_rate, quality):
-    """Two independent implementations of the same specification (plan.cpp, soxr_oracle.c)
-    must produce the same float64 bank, bit for bit."""
+def test_bank_matches_independent_design(oracle, in_rate, out_rate, quality):
+    """Two independently written implementations of the same specification — plan.cpp (C++, scalar
+    loops, power-series I0) and oracle/design.py (numpy/scipy, Chebyshev I0, vectorised layout) —
+    agree on the geometry exactly and on the float64 bank to 2e-13 of its scale."""
     from soxr_amd import device as dev
     p = dev.Plan(in_rate, out_rate, quality)
     o = oracle.plan(in_rate, out_rate, quality)
     assert (p.L, p.M, p.taps) == (o.L, o.M, o.T)
     assert p.taps % 8 == 0
-    assert np.array_equal(p.bank(), o.bank)
+    assert np.abs(p.bank() - o.bank).max() <= 2e-13 * np.abs(o.bank).max()
 
 
 def _response(plan, nfft=1 << 22):
@@ -94,13 +95,13 @@ INTERP_RATES = [(48000, 44101), (44100.123456789, 47999.987654321), (95999, 8001
 
 @pytest.mark.parametrize("in_rate,out_rate", INTERP_RATES)
 @pytest.mark.parametrize("quality", QUALS)
-def test_interp_plan_identical_to_oracle(oracle, in_rate, out_rate, quality):
+def test_interp_plan_matches_independent_design(oracle, in_rate, out_rate, quality):
     from soxr_amd import device as dev
     p = dev.Plan(in_rate, out_rate, quality)
     o = oracle.plan(in_rate, out_rate, quality)
     assert (p.L, p.M, p.taps, p.phases) == (o.L, o.M, o.T, o.phases)
     assert abs(p.L / p.M - out_rate / in_rate) <= 4e-15 * out_rate / in_rate and 0 < p.L < 2 ** 31 and 0 < p.M < 2 ** 31
-    assert np.array_equal(p.bank(), o.bank)
+    assert np.abs(p.bank() - o.bank).max() <= 1e-12 * np.abs(o.bank).max()
     if p.phases:
         assert p.L * p.taps > 1 << 22
         n = 123457
