@@ -40,6 +40,7 @@ struct Switches {
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
     bool fft_small_3pass = false; // HIPSOXR_FFT_SMALL_3PASS  small 147/160 blocks on the 3-pass (radix 16/21) schedule
+    bool fft_pair_v1 = false;     // HIPSOXR_FFT_PAIR_V1      unit-stride jobs on k_fft_pair instead of k_fft_pair2
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids

@@ -339,7 +339,7 @@ __device__ __forceinline__ void fft_ct_pre(cf *buf, const cf *W, Load first_load
 // conflict.  An odd-ish R0 (5, 21: stride 40 / 168 bytes) is conflict-free as it is; for R0 = 16
 // (stride 128 bytes = every lane on the same two banks, a 16-way conflict) the buffer between pass
 // 1 and pass 2 is kept in a swizzled layout  n -> n ^ ((n >> 4) & 15)  (SWZ).
-template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, typename Load, typename Store>
+template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, bool LASTSYNC = false, typename Load, typename Store>
 __device__ __forceinline__ void fft_ct3(cf *buf, const cf *W, Load first_load, Store last_store, bool first_in_lds)
 {
     static_assert(R0 * R1 * R2 == N, "radix schedule");
@@ -352,7 +352,7 @@ __device__ __forceinline__ void fft_ct3(cf *buf, const cf *W, Load first_load, S
     __syncthreads();
     fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, swz_load, lds_store);
     __syncthreads();
-    fft_pass_ct<N, R0 * R1, R2, SIGN, NT, false>(W, lds_load, last_store);
+    fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load, last_store);
 }
 
 struct FftArgs {
@@ -534,12 +534,15 @@ template <int NA_, int NB_, int NT_, int A0, int A1, int A2, bool ASWZ, int B0, 
 struct PairSpec {
     static constexpr int NA = NA_, NB = NB_, NT = NT_;
     static constexpr bool prefetch = false;
-    static constexpr int RB0 = B0;
+    static constexpr int RB0 = B0, RA0 = A0;
     struct Tw {};
     template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
     { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ>(b, W, ld, st, in_lds); }
     template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
     { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ>(b, W, ld, st, in_lds); }
+    // last pass stores into LDS in another layout (output staging): all its inputs must be in registers first
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv_staged(cf *b, const cf *W, Ld ld, St st)
+    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, true>(b, W, ld, st, true); }
 };
 // Four-pass variant (radices <= 8): more barriers but much shorter butterfly chains per pass —
 // the better trade for SMALL jobs, whose cost is the latency of one workgroup, not throughput.
@@ -710,6 +713,110 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Paired-block kernel, second generation, for unit-stride columns (mono / planar data; batches).
+// Same transform chain and schedules as k_fft_pair; what differs is how it touches HBM:
+//   * input: raw buffer loads whose descriptor covers [first sample of block a, end of the column):
+//     the hardware range check returns 0 past the end of the signal (no per-element bounds code,
+//     one path for interior and last pairs), and the per-butterfly offsets t*N/R0 ride in the
+//     instruction's scalar offset instead of 64-bit vector address arithmetic;
+//   * output: the last inverse pass writes its kept outputs into LDS as the two contiguous runs they
+//     are in memory (block a then block b: 2*hop_out consecutive floats of the column), and the
+//     workgroup then stores that run with 16-byte-aligned float4 stores — every wave writes 1 KB of
+//     whole 16-byte granules instead of 256 unaligned bytes per instruction (k_fft_pair: write traffic
+//     1.17x the algorithmic bytes with streaming stores).
+// ---------------------------------------------------------------------------------------------
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+template <typename Spec>
+__global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *cur = reinterpret_cast<cf *>(smem_raw);
+    float *stage = reinterpret_cast<float *>(smem_raw);
+    constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0;
+
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(blockIdx.y % a.n_channels);
+    const uint32_t clip = __builtin_amdgcn_readfirstlane(blockIdx.y / a.n_channels);
+    const int64_t bx = blockIdx.x;
+    const int64_t pa = 2 * bx * a.hop_periods - a.lead_periods; // first period of block a; block b starts hop_periods later
+    const int64_t ina = pa * a.M, outa = pa * a.L;
+    const int32_t hop_in = (int32_t)(a.hop_periods * a.M);
+    const float *xin = (const float *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    auto lds_store = [&](int n, cf v) { cur[n] = v; };
+    typename Spec::Tw tw;
+
+    // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
+    if (ina >= 0) {
+        const int64_t left = (a.in_frames - ina) * 4; // bytes from block a's first sample to the end of the column
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(xin + ina), 0, (int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left), 0x00020000);
+        Spec::fwd(cur, a.WA2, [&](int n, int t) -> cf {
+            const int j4 = (n - t * nbA) * 4; // the butterfly's own offset (one VGPR for all t)
+            return make_float2(buf_load_f32(rs, j4, t * nbA * 4), buf_load_f32(rs, j4, (t * nbA + hop_in) * 4));
+        }, lds_store, false, tw);
+    } else { // the first pair of a column reaches before its start: explicit zero-extension
+        const int64_t inb = ina + hop_in;
+        Spec::fwd(cur, a.WA2, [&](int n, int) -> cf {
+            const int64_t la = ina + n, lb = inb + n;
+            return make_float2((la >= 0 && la < a.in_frames) ? xin[la] : 0.f, (lb >= 0 && lb < a.in_frames) ? xin[lb] : 0.f);
+        }, lds_store, false, tw);
+    }
+    __syncthreads();
+
+    // ---- inverse (see k_fft_pair), last pass into the staging layout -------------------------------
+    const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
+    float *ybase = (float *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
+    const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) >> 2) & 3); // LDS float index == run index + sh: 16-byte phases agree
+    auto h_load = [&](int n, int) -> cf {
+        const bool neg = n > NB / 2;
+        const int q = neg ? NB - n : n;
+        cf h = a.Hs[q];
+        if (neg) h.y = -h.y;
+        if constexpr (NA >= NB) {
+            cf y = cmul(cur[neg ? n + (NA - NB) : n], h);
+            if (n == NB / 2) y = cadd(y, cmul(cur[n + (NA - NB)], cconj(h)));
+            return y;
+        } else {
+            const bool in_band = q < NA / 2;
+            const cf y = cmul(cur[in_band ? (neg ? NA - q : q) : 0], h);
+            return in_band ? y : make_float2(0.f, 0.f);
+        }
+    };
+    Spec::inv_staged(cur, a.WB2, h_load, [&](int n, cf w) {
+        if (n >= v0 && n < v1) {
+            stage[n - v0 + sh] = w.x;
+            stage[n - v0 + sh + hop_out] = w.y;
+        }
+    });
+    __syncthreads();
+
+    // ---- store the run: floats [0, valid) of it exist in the column -----------------------------------
+    const int64_t remain = a.out_frames - (outa + v0);
+    const int32_t valid = (int32_t)(remain < 0 ? 0 : remain > 2 * (int64_t)hop_out ? 2 * (int64_t)hop_out : remain);
+    const int32_t nq = (valid + sh + 3) >> 2;
+    for (int32_t q = threadIdx.x; q < nq; q += NT) {
+        const float4 v = *reinterpret_cast<const float4 *>(stage + 4 * q);
+        const int32_t i0 = 4 * q - sh;
+        if (i0 >= 0 && i0 + 3 < valid) {
+#ifdef FFT2_NT_STORE
+            __builtin_nontemporal_store(v, reinterpret_cast<float4 *>(ybase + i0));
+#else
+            *reinterpret_cast<float4 *>(ybase + i0) = v;
+#endif
+        } else {
+            if (i0 >= 0 && i0 < valid) ybase[i0] = v.x;
+            if (i0 + 1 >= 0 && i0 + 1 < valid) ybase[i0 + 1] = v.y;
+            if (i0 + 2 >= 0 && i0 + 2 < valid) ybase[i0 + 2] = v.z;
+            if (i0 + 3 >= 0 && i0 + 3 < valid) ybase[i0 + 3] = v.w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host: geometry, tables
 // ---------------------------------------------------------------------------------------------
 struct FftGeom {
@@ -849,8 +956,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         return nullptr;
     };
     // ---- paired-block kernels: compile-time schedules for the common ratios -------------------
-    struct PairEntry { int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; };
-#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT}
+    struct PairEntry { int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); };
+#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT, k_fft_pair2<PairOf<NA, NB, NT>>}
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
         HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
@@ -894,7 +1001,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             // Latency-bound jobs (everything resident at once, about one workgroup per CU slot):
             // the four-pass schedule with prefetched tables has the shorter critical path (7.1 vs
             // 9.0 us for one workgroup); from ~400 workgroups on, the three-pass one wins on work.
-            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT};
+            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr};
             if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && !switches().fft_small_3pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
                 if (wgs < 400) use = &low_latency;
@@ -931,7 +1038,15 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.pairs_per_col = items;
                 const dim3 grid = a.xcd_map ? dim3((unsigned)(items8 * units), j.n_clips, 1)
                                             : dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols_p, 1);
-                hipLaunchKernelGGL(use->kern, grid, dim3(use->nt), lds, (hipStream_t)stream, a);
+                // unit-stride columns (mono / planar): the second-generation kernel (buffer loads, staged aligned stores)
+                void (*kern)(FftArgs) = use->kern;
+                if (use->kern2 && !a.xcd_map && !a.chpair && j.in_frame_stride == 1 && j.out_frame_stride == 1 &&
+                    2 * (size_t)g.hop_out * sizeof(float) + 16 <= lds && !switches().fft_pair_v1) {
+                    kern = use->kern2;
+                    if (lds > 64 * 1024)
+                        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                }
+                hipLaunchKernelGGL(kern, grid, dim3(use->nt), lds, (hipStream_t)stream, a);
                 HIP_TRY(hipGetLastError());
                 *handled = true;
                 return nullptr;

@@ -1,6 +1,7 @@
 import sys, time; sys.path.insert(0,'python-soxr_amd'); sys.path.insert(0,'.')
 import numpy as np, soxr_amd as soxr
 from oracle import oracle
+import _provider  # noqa: F401  (port mode on the product's bank: arithmetic-order check)
 rng=np.random.default_rng(0)
 x=(rng.standard_normal(20_000_000)*0.25).astype(np.float32)
 t=time.time(); y=soxr.resample(x,48000,44100,'HQ'); dt=time.time()-t

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 from soxr_amd import device as dev
 from oracle import oracle
+import _provider  # noqa: F401  (port mode on the product's bank: arithmetic-order check)
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 r = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)

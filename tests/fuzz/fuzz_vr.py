@@ -10,6 +10,7 @@ for p in (os.path.join(ROOT, "python-soxr_amd"), ROOT, os.path.join(ROOT, "tests
 import numpy as np
 import soxr_amd as soxr
 from oracle import oracle
+import _provider  # noqa: F401  (port mode on the product's bank: arithmetic-order check)
 from vr_sim import VrSim
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60

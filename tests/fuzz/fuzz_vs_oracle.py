@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "python-soxr_amd")); sys.path.insert(0, RO
 import numpy as np
 import soxr_amd as soxr
 from oracle import oracle
+import _provider  # noqa: F401  (port mode on the product's bank: arithmetic-order check)
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 r = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
