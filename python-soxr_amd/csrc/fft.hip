@@ -360,6 +360,7 @@ struct FftArgs {
     void *out;
     const float2 *WA, *WB, *P, *Q, *Hs; // twiddles of both transforms, (un)tangling twiddles, filter
     const float2 *WA2, *WB2;            // paired-block kernel: twiddles of the full-length transforms
+    const float *Hr;                    // paired-block kernels, 2nd/3rd generation: the filter as REAL values (see fft_build)
     int32_t A, B;            // complex transform lengths: N_in/2, N_out/2
     int32_t nA, nB;          // number of passes
     int32_t radA[8], radB[8];
@@ -731,6 +732,17 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voff
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
+// Raw-buffer descriptor over [p, p + bytes) from wave-uniform values.  The words are passed through
+// readfirstlane: when scalar registers run short the compiler keeps uniform addresses in VGPRs, and a
+// descriptor in VGPRs turns every load into a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, int32_t bytes)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes < 0 ? 0 : bytes), 0x00020000);
+}
+
 template <typename Spec>
 __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 {
@@ -771,19 +783,17 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
     float *ybase = (float *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
     const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) >> 2) & 3); // LDS float index == run index + sh: 16-byte phases agree
-    auto h_load = [&](int n, int) -> cf {
+    auto h_load = [&](int n, int) -> cf { // bin n of the output grid <- bin n or n + NA - NB of the input grid, times (real) H
         const bool neg = n > NB / 2;
-        const int q = neg ? NB - n : n;
-        cf h = a.Hs[q];
-        if (neg) h.y = -h.y;
+        const int q = neg ? NB - n : n; // |frequency| in bins
+        const float h = a.Hr[q];
         if constexpr (NA >= NB) {
-            cf y = cmul(cur[neg ? n + (NA - NB) : n], h);
-            if (n == NB / 2) y = cadd(y, cmul(cur[n + (NA - NB)], cconj(h)));
-            return y;
+            const cf x = cur[neg ? n + (NA - NB) : n];
+            return make_float2(x.x * h, x.y * h); // (the Nyquist bin's alias term is dropped with Im H: stop band, < -170 dB)
         } else {
             const bool in_band = q < NA / 2;
-            const cf y = cmul(cur[in_band ? (neg ? NA - q : q) : 0], h);
-            return in_band ? y : make_float2(0.f, 0.f);
+            const cf x = cur[in_band ? (neg ? NA - q : q) : 0];
+            return in_band ? make_float2(x.x * h, x.y * h) : make_float2(0.f, 0.f);
         }
     };
     Spec::inv_staged(cur, a.WB2, h_load, [&](int n, cf w) {
@@ -896,7 +906,7 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_
     if (force_k && 2 * (int64_t)g.hop_out < g.N_out) { *out = g; return nullptr; }
 
     const int A = g.A, B = g.B;
-    std::vector<float2> tab((size_t)A + B + (A + 1) + B + (B + 1) + g.N_in + g.N_out);
+    std::vector<float2> tab((size_t)A + B + (A + 1) + B + (B + 1) + g.N_in + g.N_out + (B + 2) / 2 + 1);
     float2 *WA = tab.data(), *WB = WA + A, *P = WB + B, *Q = P + (A + 1), *Hs = Q + B;
     float2 *WA2 = Hs + (B + 1), *WB2 = WA2 + g.N_in;
     for (int m = 0; m < g.N_in; ++m) WA2[m] = make_float2((float)std::cos(6.283185307179586476925286766559 * m / g.N_in), (float)-std::sin(6.283185307179586476925286766559 * m / g.N_in));
@@ -925,6 +935,11 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_
             }
         }
         Hs[q] = make_float2((float)(hr * scale), (float)(hi * scale));
+        // The prototype is symmetric about the output instant (zero latency) and blocks are cut on period
+        // boundaries, so H is real: |Im H| <= 2e-13 |Re H| in the pass band (the one unpaired sample of the
+        // even-length support, g[-L T/2], is a window-edge value ~1e-11).  The newer paired kernels use
+        // Re H alone: half the table reads and a real x complex product per bin.
+        reinterpret_cast<float *>(WB2 + g.N_out)[q] = (float)(hr * scale);
     }
     HIP_TRY(hipMalloc((void **)&g.dev, tab.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(g.dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
@@ -1011,6 +1026,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.in = j.in; a.out = j.out;
                 a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
                 a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
+                a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out);
                 a.A = g.A; a.B = g.B; a.nA = a.nB = 0;
                 for (int i = 0; i < 8; ++i) a.radA[i] = a.radB[i] = 1;
                 a.L = p->L; a.M = p->M;
@@ -1069,6 +1085,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.in = j.in; a.out = j.out;
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
+    a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out);
     a.A = g.A; a.B = g.B; a.nA = (int32_t)g.radA.size(); a.nB = (int32_t)g.radB.size();
     for (int i = 0; i < 8; ++i) { a.radA[i] = i < a.nA ? g.radA[i] : 1; a.radB[i] = i < a.nB ? g.radB[i] : 1; }
     a.L = p->L; a.M = p->M;
