@@ -70,9 +70,29 @@ def broadcast_bank(plan, rank, world, device):
         plan.set_bank(bank.cpu().numpy())
 
 
-def time_workload(plan, x, steps, warmup, world, device, kernel=0):
+def gather_rank_info(plan, rank, world, device, backend):
+    """What the job really ran on: per rank the device index, its name and the SHA-256 of the bank it holds
+    after the broadcast (all equal, or the broadcast failed) — rank 0 reports the list."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    mine = {"rank": rank, "device": device.index, "name": torch.cuda.get_device_name(device),
+            "bank_sha256": hashlib.sha256(plan.bank().tobytes()).hexdigest()[:16]}
+    if world == 1:
+        return {"ranks_seen": 1, "backend": None, "ranks": [mine], "devices_visible": torch.cuda.device_count()}
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return {"ranks_seen": len(got), "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "ranks": got,
+            "devices_visible": torch.cuda.device_count(),
+            "banks_identical": len({g["bank_sha256"] for g in got}) == 1}
+
+
+def time_workload(plan, x, steps, warmup, world, device, kernel=0, windows=50):
     """W warm-up launches, then exactly K timed launches bracketed by barrier + synchronize.
-    Returns (wall seconds for K steps [max over ranks], mean launch duration from HIP events [s])."""
+    Returns (wall seconds for K steps [max over ranks], launch duration from HIP events [s], output).
+    The launch duration is the MEDIAN over `windows` further windows of K launches each (HIP events on
+    the launch stream): at the driver's K = 20 the contract region of the 60 s clip lasts 0.3 ms, too
+    short for one window to be a measurement.  A step is the same thing in every window."""
     import torch
     import torch.distributed as dist
     from soxr_amd import device as dev
@@ -96,6 +116,18 @@ def time_workload(plan, x, steps, warmup, world, device, kernel=0):
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
     kern = ev0.elapsed_time(ev1) * 1e-3 / steps
+    if windows:
+        per = []
+        for _ in range(windows):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                job.launch()
+            e1.record()
+            e1.synchronize()
+            per.append(e0.elapsed_time(e1) * 1e-3 / steps)
+        per.sort()
+        kern = per[len(per) // 2]
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -124,7 +156,13 @@ def cpu_baseline(seconds_in=60, budget_s=10.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = (time.perf_counter() - t0) / n
-    out = {"value": len(x) / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+    live = live_libsoxr_timing(x)
+    if live is not None:  # a real libsoxr on this box: it is the baseline (kind "reference"), the oracle rides along
+        live["port"] = {"value": len(x) / dt / 1e6, "unit": "Msamples/s", "cores": 1,
+                        "sample": f"oracle/soxr_oracle.c, {seconds_in} s mono x{n} passes"}
+        live["host_cpus"] = os.cpu_count()
+        return live
+    out = {"value": len(x) / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port", "libsoxr": "absent",
            "sample": f"{seconds_in} s mono float32 48k->44.1k VHQ x{n} passes, float64 accumulate, "
                      f"oracle/soxr_oracle.c (libsoxr itself is absent from this image)",
            "host_cpus": os.cpu_count()}
@@ -156,6 +194,82 @@ def cpu_baseline(seconds_in=60, budget_s=10.0):
                                       "sample": "10 s mono float64, same prototype (scipy.signal.upfirdn)"}
     except Exception as e:
         out["scipy_resample_poly"] = {"error": str(e)}
+    return out
+
+
+def live_libsoxr_timing(x):
+    """If a real libsoxr is importable / loadable at run time: time it the way the
+    reference's own harness does (tests/bench.py:42-53: timeit, best of N) on the 60 s mono VHQ clip, and
+    report the GPU path's parity against it.  None when absent (this image: always)."""
+    try:
+        from oracle import live_libsoxr
+        live = live_libsoxr.probe()
+    except Exception:
+        return None
+    if live is None:
+        return None
+    import timeit
+    import numpy as np
+    live.resample(x[:48000], IN_RATE, OUT_RATE, QUALITY)
+    best = min(timeit.repeat(lambda: live.resample(x, IN_RATE, OUT_RATE, QUALITY), number=1, repeat=10))
+    out = {"value": len(x) / best / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+           "libsoxr": live.version, "how": live.how,
+           "sample": "60 s mono float32 48k->44.1k VHQ, timeit best of 10 (tests/bench.py:42-53 method)"}
+    try:
+        import soxr_amd
+        ref = np.asarray(live.resample(x, IN_RATE, OUT_RATE, QUALITY), np.float64)
+        got = soxr_amd.resample(x, IN_RATE, OUT_RATE, quality=QUALITY).astype(np.float64)
+        n = min(len(ref), len(got))
+        out["parity_rel_rms_white_noise"] = float(np.sqrt(np.mean((got[:n] - ref[:n]) ** 2)) / np.sqrt(np.mean(ref[:n] ** 2)))
+        out["parity_len_equal"] = len(ref) == len(got)
+    except Exception as e:
+        out["parity_error"] = str(e)
+    return out
+
+
+def configs4_stream(seconds=20):
+    """BASELINE configs[4]: ResampleStream 44100->16000 int16, chunked input, state carried across
+    launches (host-pointer surface: every call is H2D + kernel + D2H).  us per resample_chunk call and
+    Msamples/s for the chunk sizes SURVEY.md §8d names, constant rate and variable rate."""
+    import numpy as np
+    import soxr_amd as soxr
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(44100 * seconds) * 5000).astype(np.int16)
+    out = {"workload": f"BASELINE configs[4]: ResampleStream 44100->16000 int16 VHQ mono, {seconds} s, chunked "
+                       f"(host numpy in/out per call, state on device)"}
+    for vr in (False, True):
+        for chunk in (441, 4410, 96000):
+            rs = soxr.ResampleStream(44100, 16000, 1, dtype="int16", quality="VHQ", vr=vr)
+            rs.resample_chunk(x[:chunk])  # warm up: buffers, plan tables
+            rs.clear()
+            n_calls = 0
+            t0 = time.perf_counter()
+            for a in range(0, len(x), chunk):
+                if vr and n_calls == 8:
+                    rs.set_io_ratio(44100, 22050, 1000)  # one ratio change with a slew, mid-stream
+                rs.resample_chunk(x[a:a + chunk], last=(a + chunk >= len(x)))
+                n_calls += 1
+            dt = time.perf_counter() - t0
+            out[f"{'vr' if vr else 'cr'}_chunk{chunk}"] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls,
+                                                            "Msamples_per_s": len(x) / dt / 1e6}
+    return out
+
+
+def dtype_matrix(plan, device, seconds, steps):
+    """The other three I/O dtypes as device-resident jobs on the configs[1] shape (60 s mono): float64 and
+    int32 run the f64 engine, int16 the f32 engine (exact engine for all; AUTO = what a caller gets)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(77)
+    n_in = IN_RATE * seconds
+    base = torch.randn(n_in, device=device, dtype=torch.float64, generator=g) * 0.25
+    out = {}
+    for name, x in (("float64", base), ("int32", (base * 2 ** 30).to(torch.int32)), ("int16", (base * 2 ** 14).to(torch.int16))):
+        _, k, y = time_workload(plan, x, max(5, steps // 4), 3, 1, device, kernel=0, windows=10)
+        nbytes = x.element_size() * (x.numel() + y.numel())
+        out[name] = {"launch_us": k * 1e6, "Msamples_per_s": n_in / k / 1e6,
+                     "hbm_frac": nbytes / k / 1e9 / HBM_PEAK_GBS, "direct_form_equiv_tflops": 2.0 * plan.taps * y.numel() / k / 1e12}
+        del x, y
     return out
 
 
@@ -223,6 +337,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-batch", action="store_true")
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--strong", action="store_true", help="also time the whole 1024-clip batch on this job's ranks")
+    ap.add_argument("--windows", type=int, default=50, help="extra timing windows of K launches (median -> launch_us)")
     args = ap.parse_args()
 
     import torch
@@ -249,13 +365,14 @@ def main():
 
     plan = dev.Plan(IN_RATE, OUT_RATE, QUALITY)
     broadcast_bank(plan, rank, world, device)
+    rank_info = gather_rank_info(plan, rank, world, device, backend)
 
     # ---- configs[1]: 60 s mono float32, one clip per GPU ------------------------------------
     g = torch.Generator(device=device)
     g.manual_seed(1000 + rank)
     n_in = IN_RATE * args.seconds
     x = torch.randn(n_in, device=device, dtype=torch.float32, generator=g) * 0.25
-    wall, kern, y = time_workload(plan, x, args.steps, args.warmup, world, device, args.kernel)
+    wall, kern, y = time_workload(plan, x, args.steps, args.warmup, world, device, args.kernel, windows=args.windows)
     n_out = y.shape[0]
     algo_bytes = 4.0 * (n_in + n_out)
     flops = 2.0 * plan.taps * n_out
@@ -288,7 +405,7 @@ def main():
         xb = torch.randn((clips, IN_RATE * 10, 1), device=device, dtype=torch.float32, generator=g) * 0.25
         bsteps = max(5, args.steps // 10)
         bwall, bkern, yb = time_workload(plan, xb, bsteps, max(2, args.warmup // 10), world, device,
-                                         args.kernel)
+                                         args.kernel, windows=max(5, args.windows // 2))
         b_in, b_out = clips * IN_RATE * 10, clips * yb.shape[1]
         bbytes = 4.0 * (b_in + b_out)
         bflops = 2.0 * plan.taps * b_out
@@ -302,15 +419,28 @@ def main():
                          "traffic": TRAFFIC_BYTES.get(("batch_shard", args.kernel)) if clips == 128 else None,
                          "valu_issue_frac": (VALU_INSTS[("batch_shard", args.kernel)] / (VALU_SLOTS_PER_S * bkern)
                                              if ("batch_shard", args.kernel) in VALU_INSTS and clips == 128 else None),
+                         "read_frac": 4.0 * b_in / bkern / 1e9 / HBM_PEAK_GBS,
                          "launch_us": bkern * 1e6, "direct_form_equiv_tflops": bflops / bkern / 1e12}}
         del xb, yb
+        # the same batch partitioned over THIS job's ranks (strong scaling: 1024 clips in total whatever N is)
+        if world > 1 or args.strong:
+            slo, shi = shard(args.batch_clips, world, rank)
+            xs = torch.randn((shi - slo, IN_RATE * 10, 1), device=device, dtype=torch.float32, generator=g) * 0.25
+            swall, skern, ys = time_workload(plan, xs, bsteps, 2, world, device, args.kernel, windows=5)
+            result["batch_strong"] = {
+                "workload": f"BASELINE configs[3]: {args.batch_clips} x 10 s clips partitioned over {world} rank(s) "
+                            f"(shard(n, world, rank): rank 0 holds clips [{slo}, {shi}))",
+                "scaling": "strong", "value": args.batch_clips * IN_RATE * 10 * bsteps / swall / 1e6, "unit": "Msamples/s",
+                "ms_per_step": swall / bsteps * 1e3, "launch_us_rank0": skern * 1e6,
+                "hbm_frac_rank0": 4.0 * (xs.numel() + ys.numel()) / skern / 1e9 / HBM_PEAK_GBS}
+            del xs, ys
 
     # ---- configs[2] (context line, not the headline): 60 s x 8 channels interleaved, 44.1k -> 16k VHQ
     if not args.no_batch and world == 1:
         try:
             plan2 = dev.Plan(44100, 16000, QUALITY)
             x2 = torch.randn((44100 * args.seconds, 8), device=device, dtype=torch.float32, generator=g) * 0.25
-            w2, k2, y2 = time_workload(plan2, x2, max(5, args.steps // 10), 2, world, device, args.kernel)
+            w2, k2, y2 = time_workload(plan2, x2, max(5, args.steps // 10), 2, world, device, args.kernel, windows=20)
             bytes2 = 4.0 * (x2.numel() + y2.numel())
             result["configs2"] = {"workload": f"BASELINE configs[2]: VHQ 44100->16000 float32, {args.seconds} s x 8 ch "
                                               f"interleaved [frames, 8], device-resident",
@@ -323,7 +453,7 @@ def main():
 
     # the canonical-order (bit-exact) engine on the same workloads, for reference
     if args.kernel == 0 and world == 1:
-        ew, ek, _ = time_workload(plan, x, max(10, args.steps // 4), 5, world, device, kernel=6)
+        ew, ek, _ = time_workload(plan, x, max(10, args.steps // 4), 5, world, device, kernel=6, windows=20)
         result["exact_engine"] = {"kernel": KERNEL_NAMES[6], "launch_us": ek * 1e6,
                                   "value": n_in / ek / 1e6, "unit": "Msamples/s",
                                   "hbm_frac": algo_bytes / ek / 1e9 / HBM_PEAK_GBS,
@@ -338,6 +468,16 @@ def main():
         if "batch_shard" in result:
             result["batch_shard"]["roofline"]["frac_of_measured_copy"] = \
                 result["batch_shard"]["roofline"]["achieved"] / ceil["best_copy_GBs"]
+    if rank == 0:
+        result["ranks"] = rank_info
+        if "batch_shard" in result:  # the line that is real HBM traffic (the 22 MB clip lives in the Infinity Cache)
+            br = result["batch_shard"]["roofline"]
+            result["throughput_roofline"] = {"workload": "batch_shard (configs[3] per-GPU shard)", "frac": br["frac"],
+                                             "read_frac": br["read_frac"], "achieved_GBs": br["achieved"],
+                                             "traffic": br["traffic"], "launch_us": br["launch_us"]}
+    if rank == 0 and world == 1 and not args.no_batch:
+        result["dtype_matrix"] = dtype_matrix(plan, device, args.seconds, args.steps)
+        result["configs4"] = configs4_stream()
     if rank == 0 and world == 1:
         result["host_api"] = host_api_timings()
     if rank == 0 and world == 1 and not args.no_cpu:

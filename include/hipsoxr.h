@@ -175,6 +175,12 @@ HIPSOXR_API const char *hipsoxr_stream_engine(hipsoxr_stream_t *);
 HIPSOXR_API hipsoxr_error_t hipsoxr_stream_set_io_ratio(hipsoxr_stream_t *, double io_ratio,
                                                         size_t slew_len);
 HIPSOXR_API hipsoxr_plan_t *hipsoxr_stream_plan(hipsoxr_stream_t *);
+/* int16 output is TPDF-dithered with a counter-based hash of (seed, channel, absolute output index):
+ * deterministic and chunk-invariant.  libsoxr seeds its dither randomly per handle (the reference xfails
+ * exact equality of int16 results for that reason, tests/test_resample.py:208-211); here the seed is 0
+ * unless set, so equal inputs give equal outputs — and two streams with the same seed dither alike.
+ * Give concurrent streams distinct seeds to decorrelate them. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_stream_set_dither_seed(hipsoxr_stream_t *, uint32_t seed);
 
 /* ---- measurement helper (no counterpart in the reference) -------------------------------- */
 /* Plain streaming kernels over device buffers, for the "achievable HBM rate" that bench.py

@@ -13,7 +13,7 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/csrc"
 OUT="$HERE/soxr_amd/libhipsoxr.so"
-OBJ="$HERE/build"
+OBJ="$HERE/_obj"   # (not build/: that name belongs to setuptools when a wheel is built from this directory)
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -I$HERE/../include"
 mkdir -p "$OBJ"

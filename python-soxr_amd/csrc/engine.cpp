@@ -89,7 +89,22 @@ struct hipsoxr_stream {
     void *h_in = nullptr, *h_out = nullptr;
     size_t h_in_bytes = 0, h_out_bytes = 0;
     hipEvent_t ev = nullptr; // completion of a call's last operation (see stream_wait)
+    int device = -1;         // the device the HIP stream and every buffer above live on
+    uint32_t dither_seed = 0; // int16 TPDF dither: hash(seed, channel, absolute output index); see hipsoxr_stream_set_dither_seed
     char engine_name[32] = {0};
+};
+
+// Entry points that touch a stream's resources run with the stream's own device current, whatever
+// device the calling thread has selected since (Python finalisers run at arbitrary times; a process
+// may drive several GPUs): resources are never used, pooled or freed under another device's context.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int want)
+    {
+        if (want >= 0 && hipGetDevice(&prev) == hipSuccess && prev != want) switched = hipSetDevice(want) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
 // Wait for everything queued on the stream.  A chunked call is a 20-30 us round trip on the GPU;
@@ -139,21 +154,33 @@ static std::vector<hipsoxr_plan *> g_cache;
 static uint64_t g_cache_clock = 0;
 static const size_t kCacheMax = 32;
 
-static const char *plan_acquire(double in_rate, double out_rate, unsigned long recipe, bool vr, hipsoxr_plan **out)
+static hipsoxr_plan *cache_find(double in_rate, double out_rate, unsigned long recipe, bool vr, int dev)
 {
-    int dev = -1;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(g_cache_mu);
     for (hipsoxr_plan *h : g_cache)
         if (h->key_in == in_rate && h->key_out == out_rate && h->key_recipe == recipe && h->key_vr == vr &&
             h->key_device == dev) {
             ++h->users; h->last_use = ++g_cache_clock;
-            *out = h;
-            return nullptr;
+            return h;
         }
+    return nullptr;
+}
+
+static const char *plan_acquire(double in_rate, double out_rate, unsigned long recipe, bool vr, hipsoxr_plan **out)
+{
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if ((*out = cache_find(in_rate, out_rate, recipe, vr, dev))) return nullptr;
+    }
+    // The design (up to 4M bank entries with a Bessel series each) runs OUTSIDE the cache lock: other
+    // threads keep creating and releasing streams meanwhile.  Two threads may design the same plan
+    // concurrently; the second to finish finds the first one's entry and drops its own.
     hipsoxr_plan *h = new (std::nothrow) hipsoxr_plan();
     if (!h) return "out of memory";
     if (const char *e = plan_design(in_rate, out_rate, recipe, &h->p, vr)) { delete h; return e; }
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if ((*out = cache_find(in_rate, out_rate, recipe, vr, dev))) { delete h; return nullptr; }
     h->cached = true; h->key_in = in_rate; h->key_out = out_rate; h->key_recipe = recipe; h->key_vr = vr;
     h->key_device = dev; h->users = 1; h->last_use = ++g_cache_clock;
     if (g_cache.size() >= kCacheMax) { // evict the least recently used idle plan
@@ -494,7 +521,7 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     j.out_k0 = (int64_t)s->k_done; j.out_frames = (int64_t)n;
     j.clip_counter = s->d_clips;
     j.dither = (s->elem == HIPSOXR_I16 && !(s->flags & HIPSOXR_NO_DITHER)) ? 1u : 0u;
-    j.dither_seed = 0;
+    j.dither_seed = s->dither_seed;
     if (s->in_fill == 0) { // nothing staged yet (e.g. flush of an empty stream): any valid pointer
         j.in = s->d_out;
     }
@@ -548,6 +575,7 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
     do {
         int dev = -1;
         (void)hipGetDevice(&dev);
+        s->device = dev;
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
             for (size_t i = 0; i < g_pool.size(); ++i)
@@ -619,9 +647,10 @@ hipsoxr_error_t hipsoxr_stream_create_with_plan(hipsoxr_plan_t *plan, unsigned n
 void hipsoxr_stream_delete(hipsoxr_stream_t *s)
 {
     if (!s) return;
+    DeviceGuard guard(s->device);
     if (s->st) (void)hipStreamSynchronize(s->st);
     StreamShell sh;
-    (void)hipGetDevice(&sh.device);
+    sh.device = s->device; // where the resources were created, not whatever device is current now
     const size_t frame = (size_t)s->ch * esz(s);
     sh.st = s->st; sh.d_clips = s->d_clips; sh.ev = s->ev;
     sh.h_in = s->h_in; sh.h_in_bytes = s->h_in_bytes; sh.h_out = s->h_out; sh.h_out_bytes = s->h_out_bytes;
@@ -644,6 +673,7 @@ hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size
                                        size_t olen, size_t *odone)
 {
     if (!s || !odone) return "null argument";
+    DeviceGuard guard(s->device);
     *odone = 0;
     if (in == nullptr) {
         s->ended = true; // end of input: flush
@@ -658,9 +688,17 @@ hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size
     return stream_emit(s, out, olen, odone);
 }
 
+hipsoxr_error_t hipsoxr_stream_set_dither_seed(hipsoxr_stream_t *s, uint32_t seed)
+{
+    if (!s) return "null argument";
+    s->dither_seed = seed;
+    return nullptr;
+}
+
 hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
 {
     if (!s) return "null argument";
+    DeviceGuard guard(s->device);
     s->ended = false; s->n_in_total = 0; s->k_done = 0; s->in_base = 0; s->in_fill = 0;
     if (s->vr.on) { // fresh signal at the ratio last requested
         s->vr.k_s = 0; s->vr.t_s = 0; s->vr.s0 = s->vr.s1; s->vr.delta = 0; s->vr.n_slew = 0;
@@ -687,6 +725,7 @@ double hipsoxr_stream_delay(hipsoxr_stream_t *s)
 size_t hipsoxr_stream_num_clips(hipsoxr_stream_t *s)
 {
     if (!s) return 0;
+    DeviceGuard guard(s->device);
     uint64_t v = 0;
     if (hipMemcpyAsync(&v, s->d_clips, sizeof v, hipMemcpyDeviceToHost, s->st) != hipSuccess) return 0;
     (void)hipStreamSynchronize(s->st);

@@ -82,7 +82,11 @@ __device__ __forceinline__ float dither_tpdf(uint32_t seed, uint32_t ch, int64_t
 struct OutCtx {
     uint64_t *clip_counter;
     uint32_t dither, seed;
+    uint32_t ch0; // channel index of the job's channel 0 in the caller's signal (jobs folded over channel ranges)
 };
+// set by launch_job while it issues the parts of a job folded over channel ranges: the dither of a
+// channel is keyed by its index in the WHOLE signal
+static thread_local uint32_t t_ch_base = 0;
 
 template <typename Real>
 __device__ __forceinline__ void store_out(float *p, Real v, const OutCtx &, uint32_t, int64_t)
@@ -98,7 +102,7 @@ template <typename Real>
 __device__ __forceinline__ void store_out(int16_t *p, Real v, const OutCtx &c, uint32_t ch, int64_t k)
 {
     float a = (float)v;
-    if (c.dither) a = a + dither_tpdf(c.seed, ch, k);
+    if (c.dither) a = a + dither_tpdf(c.seed, ch + c.ch0, k);
     float r = __builtin_rintf(a);
     bool clip = false;
     if (r > 32767.f) { r = 32767.f; clip = true; }
@@ -1497,8 +1501,12 @@ const char *device_bank_ensure(Plan *p, int prec)
 {
     std::lock_guard<std::mutex> lk(p->mu);
     DeviceBank &d = p->dev[prec];
+    int cur = -1;
+    if (p->device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != p->device)
+        return "this plan's device tables live on another device (one plan per device)";
     if (d.ready) return nullptr;
     if (device_count() <= 0) return "no HIP device available (hipsoxr has no CPU fallback)";
+    if (p->device < 0 && hipGetDevice(&cur) == hipSuccess) p->device = cur; // tables are built on first use, here
     TileGeom g, gm;
     const char *e = prec == 0 ? bank_upload<float>(p, d, &g, &gm) : bank_upload<double>(p, d, &g, nullptr);
     if (e) return e;
@@ -1553,7 +1561,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
         a.out_k0 = k0; a.out_frames = nf;
         __int128 kM = (__int128)k0 * p->M;
         a.d0 = (int64_t)(kM / p->L); a.p0 = (int64_t)(kM % p->L);
-        a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed;
+        a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed; a.oc.ch0 = t_ch_base;
         a.ch_fast = (j.n_channels > 1 && j.in_chan_stride == 1) ? 1 : 0;
         dim3 grid, block(256);
         if (a.ch_fast) {
@@ -1709,7 +1717,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
     a.in_abs0 = j.in_abs0; a.in_frames = j.in_frames;
     a.out_k0 = j.out_k0; a.out_frames = j.out_frames;
-    a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed;
+    a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed; a.oc.ch0 = t_ch_base;
     // periods touched: floor(k0/Lc) .. floor((k0+n-1)/Lc)
     const int64_t b_lo = j.out_k0 / g.Lc, b_hi = (j.out_k0 + j.out_frames - 1) / g.Lc;
     a.b_first = b_lo;
@@ -1809,7 +1817,7 @@ static const char *launch_wave_dot(Plan *p, const hipsoxr_job_t &j, hipStream_t 
     a.in_abs0 = j.in_abs0; a.in_frames = j.in_frames; a.out_k0 = j.out_k0; a.out_frames = j.out_frames;
     __int128 kM = (__int128)j.out_k0 * p->M;
     a.d0 = (int64_t)(kM / p->L); a.p0 = (int64_t)(kM % p->L);
-    a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed;
+    a.oc.clip_counter = j.clip_counter; a.oc.dither = j.dither; a.oc.seed = j.dither_seed; a.oc.ch0 = t_ch_base;
     a.ch_fast = 0;
     const int32_t per_wave = 16;
     const int64_t waves = (j.out_frames + per_wave - 1) / per_wave;
@@ -1885,6 +1893,46 @@ const char *stream_kernel(void *dst, const void *src, size_t bytes, int mode, vo
 const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr)
 {
     if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return nullptr;
+    // Kernels index (clip, channel) columns through grid.y (<= 65535).  Wider jobs — the Python surface
+    // admits 65536 channels like the reference, src/soxr/__init__.py:22 — are folded into several
+    // launches over channel (or clip) ranges; columns are independent, so the result is the same.
+    if ((uint64_t)j.n_clips * j.n_channels > 65535) {
+        const size_t es = elem_size(j.elem);
+        hipsoxr_job_t part = j;
+        if (j.n_channels > 1) {
+            const uint32_t step = j.n_clips > 65535 ? 1 : 65535 / j.n_clips;
+            if (j.n_clips > 65535) { // both wide: one clip range at a time, channels folded below it
+                for (uint32_t c0 = 0; c0 < j.n_clips; c0 += 65535) {
+                    part = j;
+                    part.n_clips = std::min<uint32_t>(65535, j.n_clips - c0);
+                    part.in = (const char *)j.in + (int64_t)c0 * j.in_clip_stride * (int64_t)es;
+                    part.out = (char *)j.out + (int64_t)c0 * j.out_clip_stride * (int64_t)es;
+                    if (const char *e = launch_job(p, part, stream, vr)) return e;
+                }
+                return nullptr;
+            }
+            for (uint32_t h0 = 0; h0 < j.n_channels; h0 += step) {
+                part = j;
+                part.n_channels = std::min<uint32_t>(step, j.n_channels - h0);
+                part.in = (const char *)j.in + (int64_t)h0 * j.in_chan_stride * (int64_t)es;
+                part.out = (char *)j.out + (int64_t)h0 * j.out_chan_stride * (int64_t)es;
+                const uint32_t saved = t_ch_base;
+                t_ch_base = saved + h0;
+                const char *e = launch_job(p, part, stream, vr);
+                t_ch_base = saved;
+                if (e) return e;
+            }
+            return nullptr;
+        }
+        for (uint32_t c0 = 0; c0 < j.n_clips; c0 += 65535) {
+            part = j;
+            part.n_clips = std::min<uint32_t>(65535, j.n_clips - c0);
+            part.in = (const char *)j.in + (int64_t)c0 * j.in_clip_stride * (int64_t)es;
+            part.out = (char *)j.out + (int64_t)c0 * j.out_clip_stride * (int64_t)es;
+            if (const char *e = launch_job(p, part, stream, vr)) return e;
+        }
+        return nullptr;
+    }
     const int prec = engine_prec(j.elem);
     if (const char *e = device_bank_ensure(p, prec)) return e;
     // Frequency-domain engine: explicit request, or AUTO for large whole-signal float32 jobs.

@@ -23,6 +23,7 @@ struct soxr {
     size_t max_ilen = 0;
     unsigned channels = 0;
     int dtype = 0;                 // soxr_datatype_t
+    double io_ratio = 1.;          // input frames per output frame (pull mode: how much input an output request needs)
     bool input_ended = false;
 };
 
@@ -139,6 +140,7 @@ soxr_t soxr_create(double input_rate, double output_rate, unsigned num_channels,
     if (!e) {
         p->channels = num_channels;
         p->dtype = dtype;
+        p->io_ratio = input_rate / output_rate;
         e = hipsoxr_stream_create(input_rate, output_rate, num_channels, (hipsoxr_datatype_t)dtype, recipe, flags,
                                   &p->h);
         if (e) { delete p; p = nullptr; }
@@ -152,11 +154,22 @@ soxr_error_t soxr_process(soxr_t p, soxr_in_t in, size_t ilen, size_t *idone, so
                           size_t *odone)
 {
     if (!p) return "null pointer";
+    // libsoxr's end-of-input convention for callers that pass a length with the flush: ilen = ~ilen
+    // (a "negative" size_t) means "these are the last ilen frames"
+    bool last = false;
+    if ((ptrdiff_t)ilen < 0) { ilen = ~ilen; last = true; }
     size_t od = 0;
     soxr_error_t e = hipsoxr_stream_process(p->h, in, ilen, out, olen, &od);
+    if (!e && last && in) { // input consumed: now flush into what is left of the output buffer
+        size_t od2 = 0;
+        Cursor cur;
+        e = hipsoxr_stream_process(p->h, nullptr, 0, cur.at(p, out, od), olen - od, &od2);
+        od += od2;
+    }
     if (idone) *idone = e ? 0 : ilen; // everything handed over is consumed (the stream keeps it on the device)
     if (odone) *odone = od;
-    if (!e) p->clips = hipsoxr_stream_num_clips(p->h);
+    // (the clip counter lives on the device: it is fetched when soxr_num_clips() asks for it, not after
+    // every chunk — that would be a device-to-host copy and a stream synchronise per call)
     p->err = e;
     return e;
 }
@@ -185,14 +198,16 @@ size_t soxr_output(soxr_t p, soxr_out_t out, size_t olen)
         if (od || total == olen) continue;
         if (p->input_ended) break; // flushed dry
         soxr_in_t in = nullptr;
-        const size_t want = p->max_ilen;
+        // ask for what the missing output needs, as libsoxr does (never an unbounded request: callbacks
+        // that fill a fixed buffer rely on it), capped by max_ilen
+        size_t want = (size_t)((double)(olen - total) * p->io_ratio) + 2;
+        if (want > p->max_ilen) want = p->max_ilen;
         const size_t ilen = p->fn(p->fn_state, &in, want);
         if (!in) { p->err = "input function reported failure"; break; }
         if (ilen == 0) { p->input_ended = true; continue; }
         p->err = hipsoxr_stream_process(p->h, in, ilen, o, olen - total, &od);
         total += od;
     }
-    p->clips = hipsoxr_stream_num_clips(p->h);
     return total;
 }
 
@@ -234,7 +249,9 @@ void soxr_delete(soxr_t p)
 // reference: src/soxr_ext.cpp:201
 soxr_error_t soxr_set_io_ratio(soxr_t p, double io_ratio, size_t slew_len)
 {
-    return p ? hipsoxr_stream_set_io_ratio(p->h, io_ratio, slew_len) : "null pointer";
+    if (!p) return "null pointer";
+    if (io_ratio > p->io_ratio) p->io_ratio = io_ratio; // (pull-mode requests are sized for the largest ratio seen)
+    return hipsoxr_stream_set_io_ratio(p->h, io_ratio, slew_len);
 }
 
 // reference: src/soxr_ext.cpp:385-389

@@ -16,8 +16,19 @@ import numpy as np
 from . import _native as _n
 from ._native import QQ, LQ, MQ, HQ, VHQ
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 __libsoxr_version__ = _n.version()  # reference: soxr_ext.libsoxr_version(), src/soxr/__init__.py:18
+
+
+
+def prefix():
+    """Install prefix of the libsoxr-named ABI (lib/libsoxr.so, include/soxr.h, lib/pkgconfig/soxr.pc):
+    what a libsoxr client's CMAKE_PREFIX_PATH should point at, e.g. the reference's own
+    `-DUSE_SYSTEM_LIBSOXR=ON` build (CMakeLists.txt:29,83-93).  Present in an installed wheel; in a
+    source checkout the header lives in include/ and the library beside this file."""
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefix")
+
 
 # same limit as the reference (src/soxr/__init__.py:22)
 _CH_LIMIT = 65536
@@ -84,9 +95,13 @@ class ResampleStream:
     quality : 'QQ' | 'LQ' | 'MQ' | 'HQ' | 'VHQ' (or the soxr.* constants)
     vr : bool                       (experimental in the reference) variable-rate mode: in_rate/out_rate
                                     must be the LARGEST io ratio that will be used; see set_io_ratio
+    dither_seed : int               (extension) seed of the int16 TPDF dither.  libsoxr seeds randomly per
+                                    handle; here dither is a deterministic function of (seed, channel,
+                                    output index), default seed 0 — pass distinct seeds to decorrelate
+                                    concurrent streams
     """
 
-    def __init__(self, in_rate, out_rate, num_channels, dtype="float32", quality="HQ", vr=False):
+    def __init__(self, in_rate, out_rate, num_channels, dtype="float32", quality="HQ", vr=False, dither_seed=0):
         _check_rates(in_rate, out_rate)
         _check_channels(num_channels)
         self._type = np.dtype(dtype)
@@ -98,6 +113,8 @@ class ResampleStream:
         flags = _n.VR if vr else 0
         _n.check(_n.lib.hipsoxr_stream_create(float(in_rate), float(out_rate), self._channels,
                                               elem, recipe, flags, _C.byref(self._h)))
+        if dither_seed:
+            _n.check(_n.lib.hipsoxr_stream_set_dither_seed(self._h, int(dither_seed) & 0xFFFFFFFF))
         self._ended = False
 
     def __del__(self, _delete=_n.lib.hipsoxr_stream_delete):  # bound early: globals may be gone at exit
@@ -167,8 +184,14 @@ class ResampleStream:
     def set_io_ratio(self, in_rate, out_rate, slew_len=0):
         """(Experimental in the reference, src/soxr/__init__.py:162-179.)  New rate ratio for the
         output that follows; needs vr=True.  slew_len > 0: the ratio moves linearly to the new value
-        over that many output frames; 0: at once.  in_rate/out_rate may not exceed the ratio given
-        to the constructor."""
+        over that many OUTPUT frames; 0: at once.  in_rate/out_rate may not exceed the ratio given
+        to the constructor.
+
+        Unit of slew_len: the reference's docstring says "length of smooth transition in input samples"
+        (src/soxr/__init__.py:174-177) but passes the number straight to soxr_set_io_ratio
+        (src/soxr_ext.cpp:200-204), whose variable-rate stage advances its step once per OUTPUT sample;
+        nothing in the reference tests it.  This implementation counts output frames (the engine's
+        clock ticks per output, which keeps the position law an exact quadratic: DESIGN.md §3)."""
         if in_rate <= 0 or out_rate <= 0:
             raise ValueError("Sample rate should be over 0")
         _n.check(_n.lib.hipsoxr_stream_set_io_ratio(self._h, float(in_rate) / float(out_rate),

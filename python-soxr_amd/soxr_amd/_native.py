@@ -9,6 +9,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhipsoxr.so")
+if not os.path.exists(LIB_PATH):
+    # installed wheel: the one copy of the engine is the libsoxr-named object (it exports both ABIs)
+    _alt = os.path.join(_HERE, "prefix", "lib", "libsoxr.so.0")
+    if os.path.exists(_alt):
+        LIB_PATH = _alt
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -96,6 +101,7 @@ SIGNATURES = {
     "hipsoxr_stream_engine": (C.c_char_p, [C.c_void_p]),
     "hipsoxr_stream_set_io_ratio": (_err, [C.c_void_p, C.c_double, C.c_size_t]),
     "hipsoxr_stream_plan": (C.c_void_p, [C.c_void_p]),
+    "hipsoxr_stream_set_dither_seed": (_err, [C.c_void_p, C.c_uint32]),
     "hipsoxr_bench_stream": (_err, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "hipsoxr_oneshot": (_err, [C.c_double, C.c_double, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p,
                                C.c_size_t, _P(C.c_size_t), C.c_int, C.c_ulong, C.c_ulong]),

@@ -165,3 +165,24 @@ def test_product_reproduces_committed_golden_vectors(soxr, case):
     assert np.array_equal(y[:16].astype(np.float64), np.asarray(case["head"]))
     assert np.array_equal(y[-16:].astype(np.float64), np.asarray(case["tail"]))
     assert hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest() == case["sha256"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int16])
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_channel_limit_65536(soxr, oracle, dtype, order):
+    """The reference admits up to 65536 channels (src/soxr/__init__.py:22); kernels index columns through
+    grid.y (<= 65535), so the widest signal is folded over two launches — same results, including the
+    int16 dither, which is keyed by the channel's index in the whole signal."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((40, 65536))
+    x = (x * 5000).astype(dtype) if np.issubdtype(dtype, np.integer) else (x * 0.25).astype(dtype)
+    xin = np.asfortranarray(x) if order == "F" else x
+    y = soxr.resample(xin, 16000, 24000, quality="MQ")
+    assert y.shape == (60, 65536) and y.dtype == x.dtype
+    for c in (0, 1, 32767, 65534, 65535):        # both sides of the fold, both ends
+        want = oracle.resample(x[:, c:c + 1], 16000, 24000, "MQ", mode="port")
+        if dtype == np.int16:                    # the oracle keys dither by channel index: compute it for channel c
+            pl = oracle.plan(16000, 24000, "MQ")
+            v = oracle.resample_channel(pl, x[:, c].astype(np.float32), "port_f32")
+            want = oracle.quantize(v, np.int16, channel=c)[0][:, None]
+        assert np.array_equal(y[:, c:c + 1], want), c
