@@ -125,6 +125,14 @@ HIPSOXR_API hipsoxr_error_t hipsoxr_plan_info(const hipsoxr_plan_t *, hipsoxr_pl
 HIPSOXR_API hipsoxr_error_t hipsoxr_plan_get_bank(const hipsoxr_plan_t *, double *dst, size_t n);
 /* Replace the bank (e.g. with the one RCCL-broadcast from rank 0); device tables are rebuilt. */
 HIPSOXR_API hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *, const double *src, size_t n);
+/* Multi-GPU: broadcast the bank from rank `root` to every rank of an RCCL communicator (`nccl_comm` is an
+ * ncclComm_t; one process per GPU, each calls this with its own plan created from the same arguments;
+ * `my_rank` is the caller's rank in the communicator).  Ranks other than root install what they receive
+ * (device tables rebuild on next use).  This is the only collective of the path: clips shard across
+ * ranks with no data-path exchange (BASELINE.json north_star: "RCCL broadcast of the shared filter bank
+ * over xGMI").  RCCL is looked up in the running process (e.g. PyTorch's copy), else dlopen'ed. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_plan_broadcast(hipsoxr_plan_t *, void *nccl_comm, int root, int my_rank,
+                                                   void *hip_stream);
 /* Total output frames for `in_len` input frames: floor(in_len*L/M + 1/2). */
 HIPSOXR_API uint64_t hipsoxr_plan_out_len(const hipsoxr_plan_t *, uint64_t in_len);
 

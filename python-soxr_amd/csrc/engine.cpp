@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -307,6 +308,52 @@ hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *h, const double *src, size
     fft_release(&h->p);
     std::memcpy(h->p.bank.data(), src, n * sizeof(double));
     return nullptr;
+}
+
+// The one collective of the multi-GPU path: the shared bank, from `root` to every rank
+// of the communicator.  RCCL is resolved at run time from whatever copy the process already holds
+// (PyTorch bundles its own librccl: a communicator is only valid inside the library that made it),
+// falling back to the system's librccl.so; libhipsoxr.so itself does not link against it.
+hipsoxr_error_t hipsoxr_plan_broadcast(hipsoxr_plan_t *h, void *nccl_comm, int root, int my_rank, void *hip_stream)
+{
+    if (!h || !nccl_comm) return "null argument";
+    if (h->cached) return "this plan is shared through the plan cache (it belongs to a stream); create one with hipsoxr_plan_create";
+    typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    static bcast_fn bcast = nullptr;
+    if (!bcast) {
+        void *sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");
+        if (!sym) {
+            void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) sym = dlsym(lib, "ncclBroadcast");
+        }
+        if (!sym) return "RCCL not found (no ncclBroadcast in this process and no librccl.so to load)";
+        bcast = (bcast_fn)sym;
+    }
+    if (device_count() <= 0) return kNoDevice;
+    const size_t n = h->p.bank.size();
+    hipStream_t st = (hipStream_t)hip_stream;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, n * sizeof(double)));
+    const char *err = nullptr;
+    do {
+        if (my_rank == root && hipMemcpyAsync(d, h->p.bank.data(), n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+            err = "hipMemcpy failed"; break;
+        }
+        if (bcast(d, d, n, /*ncclFloat64*/ 8, root, nccl_comm, st) != 0) { err = "ncclBroadcast failed"; break; }
+        if (my_rank != root) {
+            std::vector<double> got(n);
+            if (hipMemcpyAsync(got.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { err = "hipMemcpy failed"; break; }
+            device_bank_release(&h->p);
+            fft_release(&h->p);
+            h->p.bank.swap(got);
+        } else if (hipStreamSynchronize(st) != hipSuccess) {
+            err = "hip sync failed";
+        }
+    } while (0);
+    (void)hipFree(d);
+    return err;
 }
 
 uint64_t hipsoxr_plan_out_len(const hipsoxr_plan_t *h, uint64_t in_len)

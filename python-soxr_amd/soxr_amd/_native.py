@@ -87,6 +87,7 @@ SIGNATURES = {
     "hipsoxr_plan_info": (_err, [C.c_void_p, _P(PlanInfo)]),
     "hipsoxr_plan_get_bank": (_err, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "hipsoxr_plan_set_bank": (_err, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hipsoxr_plan_broadcast": (_err, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hipsoxr_plan_out_len": (C.c_uint64, [C.c_void_p, C.c_uint64]),
     "hipsoxr_run_device": (_err, [C.c_void_p, _P(Job), C.c_void_p]),
     "hipsoxr_stream_create": (_err, [C.c_double, C.c_double, C.c_uint, C.c_int, C.c_ulong, C.c_ulong,
