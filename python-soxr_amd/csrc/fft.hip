@@ -34,6 +34,10 @@
 
 #include "device.h"
 
+#if defined(FFT2_ABL) && (FFT2_ABL & 1) // timing ablation (tools/abl_pair2.sh): no workgroup barriers — results are wrong
+#define __syncthreads() ((void)0)
+#endif
+
 namespace hipsoxr {
 
 #define HIP_TRY(expr)                                       \
@@ -254,7 +258,11 @@ __device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store,
                 if constexpr (std::is_invocable_v<Load, int, int>) u[i][t] = load(j + t * nb, t); // t: input slot
                 else u[i][t] = load(j + t * nb);
             }
+#if defined(FFT2_ABL) && (FFT2_ABL & 32)
+            if (false) {
+#else
             if (Ns > 1) {
+#endif
                 // Powers w^t of the butterfly's twiddle.  Any power formed from ONE rounded table
                 // entry inherits t times its phase error ((w(1+e))^t ~ w^t (1+te)), so for the large
                 // radices a second entry, w^4, is read and w^(4a+b) = (w^4)^a w^b: the error factor
@@ -277,7 +285,9 @@ __device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store,
 #pragma unroll
                 for (int t = 1; t < R; ++t) u[i][t] = cmul(u[i][t], pw[t]);
             }
+#if !(defined(FFT2_ABL) && (FFT2_ABL & 16))
             dft_r<R, SIGN>(u[i]);
+#endif
         }
     }
     if (SYNC_BEFORE_STORE) __syncthreads(); // in-place: every input of the pass is in registers
@@ -339,8 +349,17 @@ __device__ __forceinline__ void fft_ct_pre(cf *buf, const cf *W, Load first_load
 // conflict.  An odd-ish R0 (5, 21: stride 40 / 168 bytes) is conflict-free as it is; for R0 = 16
 // (stride 128 bytes = every lane on the same two banks, a 16-way conflict) the buffer between pass
 // 1 and pass 2 is kept in a swizzled layout  n -> n ^ ((n >> 4) & 15)  (SWZ).
+#ifdef FFT2_TRACE
+#define FFT_STAMP() do { if (g_tr && (threadIdx.x & 63) == 0 && g_tri < 16) g_tr[g_tri] = __builtin_amdgcn_s_memtime(); ++g_tri; } while (0)
+#define FFT_STAMP_DECL unsigned long long *g_tr, int &g_tri,
+#define FFT_STAMP_ARGS g_tr, g_tri,
+#else
+#define FFT_STAMP() ((void)0)
+#define FFT_STAMP_DECL
+#define FFT_STAMP_ARGS
+#endif
 template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, bool LASTSYNC = false, typename Load, typename Store>
-__device__ __forceinline__ void fft_ct3(cf *buf, const cf *W, Load first_load, Store last_store, bool first_in_lds)
+__device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL cf *buf, const cf *W, Load first_load, Store last_store, bool first_in_lds)
 {
     static_assert(R0 * R1 * R2 == N, "radix schedule");
     auto lds_load = [&](int n) -> cf { return buf[n]; };
@@ -349,10 +368,15 @@ __device__ __forceinline__ void fft_ct3(cf *buf, const cf *W, Load first_load, S
     auto swz_store = [&](int n, cf v) { buf[SWZ ? n ^ ((n >> 4) & 15) : n] = v; };
     if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, swz_store);
     else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, swz_store);
+    FFT_STAMP();
     __syncthreads();
+    FFT_STAMP();
     fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, swz_load, lds_store);
+    FFT_STAMP();
     __syncthreads();
+    FFT_STAMP();
     fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load, last_store);
+    FFT_STAMP();
 }
 
 struct FftArgs {
@@ -360,7 +384,8 @@ struct FftArgs {
     void *out;
     const float2 *WA, *WB, *P, *Q, *Hs; // twiddles of both transforms, (un)tangling twiddles, filter
     const float2 *WA2, *WB2;            // paired-block kernel: twiddles of the full-length transforms
-    const float *Hr;                    // paired-block kernels, 2nd/3rd generation: the filter as REAL values (see fft_build)
+    const float *Hr;                    // k_fft_pair2: the filter as REAL values (see fft_build)
+    unsigned long long *trace;          // HIPSOXR_DEBUG_TRACE (builds with -DFFT2_TRACE only): per-wave s_memtime stamps [wg][wave][16]
     int32_t A, B;            // complex transform lengths: N_in/2, N_out/2
     int32_t nA, nB;          // number of passes
     int32_t radA[8], radB[8];
@@ -537,13 +562,13 @@ struct PairSpec {
     static constexpr bool prefetch = false;
     static constexpr int RB0 = B0, RA0 = A0;
     struct Tw {};
-    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
-    { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ>(b, W, ld, st, in_lds); }
-    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
-    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ>(b, W, ld, st, in_lds); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
+    { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ>(FFT_STAMP_ARGS b, W, ld, st, in_lds); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv(FFT_STAMP_DECL cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
+    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ>(FFT_STAMP_ARGS b, W, ld, st, in_lds); }
     // last pass stores into LDS in another layout (output staging): all its inputs must be in registers first
-    template <typename Ld, typename St> static __device__ __forceinline__ void inv_staged(cf *b, const cf *W, Ld ld, St st)
-    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, true>(b, W, ld, st, true); }
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv_staged(FFT_STAMP_DECL cf *b, const cf *W, Ld ld, St st)
+    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, true>(FFT_STAMP_ARGS b, W, ld, st, true); }
 };
 // Four-pass variant (radices <= 8): more barriers but much shorter butterfly chains per pass —
 // the better trade for SMALL jobs, whose cost is the latency of one workgroup, not throughput.
@@ -562,9 +587,9 @@ struct PairSpec4 {
         t.b3 = pass_twiddle<NB, B0 * B1 * B2, B3, NT>(WB);
         return t;
     }
-    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &t)
+    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &t)
     { fft_ct_pre<NA, -1, NT, A0, A1, A2, A3>(b, W, ld, st, in_lds, t.a1, t.a2, t.a3); }
-    template <typename Ld, typename St> static __device__ __forceinline__ void inv(cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &t)
+    template <typename Ld, typename St> static __device__ __forceinline__ void inv(FFT_STAMP_DECL cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &t)
     { fft_ct_pre<NB, +1, NT, B0, B1, B2, B3>(b, W, ld, st, in_lds, t.b1, t.b2, t.b3); }
 };
 typedef PairSpec4<2560, 2352, 512, 5, 8, 8, 8, 6, 7, 7, 8> Pair2560x2352L; // low-latency schedule
@@ -599,6 +624,10 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *cur = reinterpret_cast<cf *>(smem_raw);
     constexpr int NA = Spec::NA, NB = Spec::NB;
+#ifdef FFT2_TRACE
+    unsigned long long *g_tr = nullptr;
+    int g_tri = 0;
+#endif
 
     // What is paired: two consecutive blocks of one column (planar / mono data), or — for
     // interleaved data with an even channel count (a.chpair) — the same block of two neighbouring
@@ -649,7 +678,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     const int32_t ifs32 = (int32_t)a.ifs;
     const bool unit = a.ifs == 1 && !cp;
     const float *xa = xin + ina * a.ifs, *xb = xin + inb * a.ifs;
-    Spec::fwd(cur, a.WA2, [&](int n) -> cf {
+    Spec::fwd(FFT_STAMP_ARGS cur, a.WA2, [&](int n) -> cf {
 #if defined(FFT_ABL) && (FFT_ABL & 2) // timing ablation (tools/fft_ablate.sh): no input loads
         if (interior) return make_float2((float)n * 1e-3f, (float)(n ^ 5) * 1e-3f);
 #endif
@@ -710,7 +739,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
             }
         }
     };
-    Spec::inv(cur, a.WB2, h_load, out_store, true, tw);
+    Spec::inv(FFT_STAMP_ARGS cur, a.WB2, h_load, out_store, true, tw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -750,6 +779,11 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     cf *cur = reinterpret_cast<cf *>(smem_raw);
     float *stage = reinterpret_cast<float *>(smem_raw);
     constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0;
+#ifdef FFT2_TRACE
+    unsigned long long *g_tr = a.trace ? a.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + threadIdx.x / 64) * 16 : nullptr;
+    int g_tri = 0;
+    FFT_STAMP();
+#endif
 
     const uint32_t ch = __builtin_amdgcn_readfirstlane(blockIdx.y % a.n_channels);
     const uint32_t clip = __builtin_amdgcn_readfirstlane(blockIdx.y / a.n_channels);
@@ -758,7 +792,11 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     const int64_t ina = pa * a.M, outa = pa * a.L;
     const int32_t hop_in = (int32_t)(a.hop_periods * a.M);
     const float *xin = (const float *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+#if defined(FFT2_ABL) && (FFT2_ABL & 8)
+    auto lds_store = [&](int n, cf v) { if (v.x == 1234.5f) cur[n] = v; };
+#else
     auto lds_store = [&](int n, cf v) { cur[n] = v; };
+#endif
     typename Spec::Tw tw;
 
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
@@ -766,18 +804,22 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
         const int64_t left = (a.in_frames - ina) * 4; // bytes from block a's first sample to the end of the column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(xin + ina), 0, (int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left), 0x00020000);
-        Spec::fwd(cur, a.WA2, [&](int n, int t) -> cf {
+        Spec::fwd(FFT_STAMP_ARGS cur, a.WA2, [&](int n, int t) -> cf {
             const int j4 = (n - t * nbA) * 4; // the butterfly's own offset (one VGPR for all t)
+#if defined(FFT2_ABL) && (FFT2_ABL & 2)
+            return make_float2((float)(j4 + t) * 1e-4f, (float)(j4 ^ t) * 1e-4f);
+#endif
             return make_float2(buf_load_f32(rs, j4, t * nbA * 4), buf_load_f32(rs, j4, (t * nbA + hop_in) * 4));
         }, lds_store, false, tw);
     } else { // the first pair of a column reaches before its start: explicit zero-extension
         const int64_t inb = ina + hop_in;
-        Spec::fwd(cur, a.WA2, [&](int n, int) -> cf {
+        Spec::fwd(FFT_STAMP_ARGS cur, a.WA2, [&](int n, int) -> cf {
             const int64_t la = ina + n, lb = inb + n;
             return make_float2((la >= 0 && la < a.in_frames) ? xin[la] : 0.f, (lb >= 0 && lb < a.in_frames) ? xin[lb] : 0.f);
         }, lds_store, false, tw);
     }
     __syncthreads();
+    FFT_STAMP();
 
     // ---- inverse (see k_fft_pair), last pass into the staging layout -------------------------------
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
@@ -796,13 +838,14 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
             return in_band ? make_float2(x.x * h, x.y * h) : make_float2(0.f, 0.f);
         }
     };
-    Spec::inv_staged(cur, a.WB2, h_load, [&](int n, cf w) {
+    Spec::inv_staged(FFT_STAMP_ARGS cur, a.WB2, h_load, [&](int n, cf w) {
         if (n >= v0 && n < v1) {
             stage[n - v0 + sh] = w.x;
             stage[n - v0 + sh + hop_out] = w.y;
         }
     });
     __syncthreads();
+    FFT_STAMP();
 
     // ---- store the run: floats [0, valid) of it exist in the column -----------------------------------
     const int64_t remain = a.out_frames - (outa + v0);
@@ -811,6 +854,9 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     for (int32_t q = threadIdx.x; q < nq; q += NT) {
         const float4 v = *reinterpret_cast<const float4 *>(stage + 4 * q);
         const int32_t i0 = 4 * q - sh;
+#if defined(FFT2_ABL) && (FFT2_ABL & 4)
+        if (v.x != 1234.5f) continue;
+#endif
         if (i0 >= 0 && i0 + 3 < valid) {
 #ifdef FFT2_NT_STORE
             __builtin_nontemporal_store(v, reinterpret_cast<float4 *>(ybase + i0));
@@ -824,6 +870,10 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
             if (i0 + 3 >= 0 && i0 + 3 < valid) ybase[i0 + 3] = v.w;
         }
     }
+#ifdef FFT2_TRACE
+    g_tri = 15;
+    FFT_STAMP();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1026,7 +1076,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.in = j.in; a.out = j.out;
                 a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
                 a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
-                a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out);
+                a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
                 a.A = g.A; a.B = g.B; a.nA = a.nB = 0;
                 for (int i = 0; i < 8; ++i) a.radA[i] = a.radB[i] = 1;
                 a.L = p->L; a.M = p->M;
@@ -1062,8 +1112,25 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }
+#ifdef FFT2_TRACE
+                size_t trace_n = 0;
+                if (switches().dbg_trace && kern == use->kern2) {
+                    trace_n = (size_t)grid.x * grid.y * (use->nt / 64) * 16;
+                    HIP_TRY(hipMalloc((void **)&a.trace, trace_n * 8));
+                    HIP_TRY(hipMemset(a.trace, 0, trace_n * 8));
+                }
+#endif
                 hipLaunchKernelGGL(kern, grid, dim3(use->nt), lds, (hipStream_t)stream, a);
                 HIP_TRY(hipGetLastError());
+#ifdef FFT2_TRACE
+                if (a.trace) { // debugging aid only: synchronous dump of the per-wave time stamps
+                    std::vector<unsigned long long> h(trace_n);
+                    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+                    HIP_TRY(hipMemcpy(h.data(), a.trace, trace_n * 8, hipMemcpyDeviceToHost));
+                    if (FILE *f = fopen(switches().dbg_trace, "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
+                    (void)hipFree(a.trace);
+                }
+#endif
                 *handled = true;
                 return nullptr;
             }
@@ -1085,7 +1152,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.in = j.in; a.out = j.out;
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
-    a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out);
+    a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
     a.A = g.A; a.B = g.B; a.nA = (int32_t)g.radA.size(); a.nB = (int32_t)g.radB.size();
     for (int i = 0; i < 8; ++i) { a.radA[i] = i < a.nA ? g.radA[i] : 1; a.radB[i] = i < a.nB ? g.radB[i] : 1; }
     a.L = p->L; a.M = p->M;
