@@ -50,98 +50,105 @@ namespace hipsoxr {
 // device: complex helpers and small DFTs (SIGN = -1 forward, +1 inverse, unnormalised)
 // ---------------------------------------------------------------------------------------------
 typedef float2 cf;
-__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
+typedef double2 cd;
+// The complex helpers and butterflies are templates over the complex type C (float2 or double2): the
+// float64 instance of the paired kernel (float64 device jobs) shares every line of them.
+template <typename C> using real_of = decltype(C().x);
+template <typename C> __device__ __forceinline__ C cadd(C a, C b) { return C(a.x + b.x, a.y + b.y); }
+template <typename C> __device__ __forceinline__ C csub(C a, C b) { return C(a.x - b.x, a.y - b.y); }
+template <typename C> __device__ __forceinline__ C cmul(C a, C b) { return C(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <typename C> __device__ __forceinline__ C cconj(C a) { return C(a.x, -a.y); }
 // multiply by SIGN * i
-template <int SIGN> __device__ __forceinline__ cf cmuli(cf a)
+template <int SIGN, typename C> __device__ __forceinline__ C cmuli(C a)
 {
-    return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+    return SIGN > 0 ? C(-a.y, a.x) : C(a.y, -a.x);
 }
 
-template <int SIGN> __device__ __forceinline__ void dft2(cf &a, cf &b)
+template <int SIGN, typename C> __device__ __forceinline__ void dft2(C &a, C &b)
 {
-    cf t = a; a = cadd(t, b); b = csub(t, b);
+    C t = a; a = cadd(t, b); b = csub(t, b);
 }
-template <int SIGN> __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
+template <int SIGN, typename C> __device__ __forceinline__ void dft4(C &a0, C &a1, C &a2, C &a3)
 {
-    cf s0 = cadd(a0, a2), d0 = csub(a0, a2), s1 = cadd(a1, a3), d1 = cmuli<SIGN>(csub(a1, a3));
+    C s0 = cadd(a0, a2), d0 = csub(a0, a2), s1 = cadd(a1, a3), d1 = cmuli<SIGN>(csub(a1, a3));
     a0 = cadd(s0, s1); a2 = csub(s0, s1); a1 = cadd(d0, d1); a3 = csub(d0, d1);
 }
-template <int SIGN> __device__ __forceinline__ void dft8(cf *u)
+template <int SIGN, typename C> __device__ __forceinline__ void dft8(C *u)
 {
-    const float h = 0.70710678118654752440f;
+    typedef real_of<C> T;
+    const T h = (T)0.70710678118654752440, sg = (T)SIGN;
     // two radix-4 on even/odd, then combine
-    cf e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
+    C e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
     dft4<SIGN>(e0, e1, e2, e3);
     dft4<SIGN>(o0, o1, o2, o3);
     // twiddles w8^m, m = 0..3 : 1, (1 + SIGN i)/sqrt2, SIGN i, (-1 + SIGN i)/sqrt2
-    cf t1 = make_float2(h * (o1.x - SIGN * o1.y), h * (o1.y + SIGN * o1.x));
-    cf t2 = cmuli<SIGN>(o2);
-    cf t3 = make_float2(h * (-o3.x - SIGN * o3.y), h * (-o3.y + SIGN * o3.x));
+    C t1 = C(h * (o1.x - sg * o1.y), h * (o1.y + sg * o1.x));
+    C t2 = cmuli<SIGN>(o2);
+    C t3 = C(h * (-o3.x - sg * o3.y), h * (-o3.y + sg * o3.x));
     u[0] = cadd(e0, o0); u[4] = csub(e0, o0);
     u[1] = cadd(e1, t1); u[5] = csub(e1, t1);
     u[2] = cadd(e2, t2); u[6] = csub(e2, t2);
     u[3] = cadd(e3, t3); u[7] = csub(e3, t3);
 }
-template <int SIGN> __device__ __forceinline__ void dft16(cf *u)
+template <int SIGN, typename C> __device__ __forceinline__ void dft16(C *u)
 {
+    typedef real_of<C> T;
     // 4 x 4 decomposition: columns (stride 4), twiddle w16^(a*b), rows
-    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
-    cf x[4][4];
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, h = (T)0.70710678118654752440, sg = (T)SIGN;
+    C x[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        cf v0 = u[a], v1 = u[a + 4], v2 = u[a + 8], v3 = u[a + 12];
+        C v0 = u[a], v1 = u[a + 4], v2 = u[a + 8], v3 = u[a + 12];
         dft4<SIGN>(v0, v1, v2, v3);
         x[a][0] = v0; x[a][1] = v1; x[a][2] = v2; x[a][3] = v3;
     }
     // twiddle x[a][b] *= w16^(a*b), w16 = exp(SIGN * 2 pi i / 16)
-    const cf w1 = make_float2(c1, SIGN * s1), w2 = make_float2(h, SIGN * h), w3 = make_float2(s1, SIGN * c1);
-    const cf w4 = make_float2(0.f, (float)SIGN), w6 = make_float2(-h, SIGN * h), w9 = make_float2(-c1, -SIGN * s1);
+    const C w1 = C(c1, sg * s1), w2 = C(h, sg * h), w3 = C(s1, sg * c1);
+    const C w4 = C((T)0, sg), w6 = C(-h, sg * h), w9 = C(-c1, -sg * s1);
     x[1][1] = cmul(x[1][1], w1); x[1][2] = cmul(x[1][2], w2); x[1][3] = cmul(x[1][3], w3);
     x[2][1] = cmul(x[2][1], w2); x[2][2] = cmul(x[2][2], w4); x[2][3] = cmul(x[2][3], w6);
     x[3][1] = cmul(x[3][1], w3); x[3][2] = cmul(x[3][2], w6); x[3][3] = cmul(x[3][3], w9);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        cf v0 = x[0][b], v1 = x[1][b], v2 = x[2][b], v3 = x[3][b];
+        C v0 = x[0][b], v1 = x[1][b], v2 = x[2][b], v3 = x[3][b];
         dft4<SIGN>(v0, v1, v2, v3);
         u[b] = v0; u[b + 4] = v1; u[b + 8] = v2; u[b + 12] = v3;
     }
 }
 // odd prime radix via the conjugate-pair form: X[m], X[R-m] = A_m +- SIGN*i*B_m
-template <int R, int SIGN> __device__ __forceinline__ void dft_odd(cf *u)
+template <int R, int SIGN, typename C> __device__ __forceinline__ void dft_odd(C *u)
 {
+    typedef real_of<C> T;
     constexpr int Hh = (R - 1) / 2;
     constexpr double PI2 = 6.283185307179586476925286766559;
-    cf s[Hh], d[Hh];
+    C s[Hh], d[Hh];
 #pragma unroll
     for (int t = 0; t < Hh; ++t) { s[t] = cadd(u[t + 1], u[R - 1 - t]); d[t] = csub(u[t + 1], u[R - 1 - t]); }
-    cf x0 = u[0];
-    cf sum = x0;
+    C x0 = u[0];
+    C sum = x0;
 #pragma unroll
     for (int t = 0; t < Hh; ++t) sum = cadd(sum, s[t]);
-    cf out[R];
+    C out[R];
     out[0] = sum;
 #pragma unroll
     for (int m = 1; m <= Hh; ++m) {
-        cf A = x0, B = make_float2(0.f, 0.f);
+        C A = x0, B = C((T)0, (T)0);
 #pragma unroll
         for (int t = 1; t <= Hh; ++t) {
-            const float c = (float)__builtin_cos(PI2 * (double)((m * t) % R) / R);
-            const float sn = (float)__builtin_sin(PI2 * (double)((m * t) % R) / R);
+            const T c = (T)__builtin_cos(PI2 * (double)((m * t) % R) / R);
+            const T sn = (T)__builtin_sin(PI2 * (double)((m * t) % R) / R);
             A.x += c * s[t - 1].x; A.y += c * s[t - 1].y;
             B.x += sn * d[t - 1].x; B.y += sn * d[t - 1].y;
         }
         // SIGN*i*B
-        cf iB = cmuli<SIGN>(B);
+        C iB = cmuli<SIGN>(B);
         out[m] = cadd(A, iB);
         out[R - m] = csub(A, iB);
     }
 #pragma unroll
     for (int m = 0; m < R; ++m) u[m] = out[m];
 }
-template <int R, int SIGN> __device__ __forceinline__ void dft_r(cf *u);
+template <int R, int SIGN, typename C> __device__ __forceinline__ void dft_r(C *u);
 
 // Composite radix R1*R2 with coprime factors by the prime-factor (Good-Thomas) index maps: a
 // plain R1 x R2 two-dimensional DFT, no internal twiddles; the maps are compile-time constants, so
@@ -152,10 +159,10 @@ constexpr int inv_mod(int a, int m)
         if ((a * x) % m == 1) return x;
     return 1;
 }
-template <int R1, int R2, int SIGN> __device__ __forceinline__ void dft_pfa(cf *u)
+template <int R1, int R2, int SIGN, typename C> __device__ __forceinline__ void dft_pfa(C *u)
 {
     constexpr int N = R1 * R2, e1 = R2 * inv_mod(R2 % R1, R1), e2 = R1 * inv_mod(R1 % R2, R2);
-    cf x[R2][R1]; // x[n2][n1] = u[(R2 n1 + R1 n2) mod N]
+    C x[R2][R1]; // x[n2][n1] = u[(R2 n1 + R1 n2) mod N]
 #pragma unroll
     for (int n2 = 0; n2 < R2; ++n2)
 #pragma unroll
@@ -164,7 +171,7 @@ template <int R1, int R2, int SIGN> __device__ __forceinline__ void dft_pfa(cf *
     for (int n2 = 0; n2 < R2; ++n2) dft_r<R1, SIGN>(x[n2]);
 #pragma unroll
     for (int k1 = 0; k1 < R1; ++k1) {
-        cf c[R2];
+        C c[R2];
 #pragma unroll
         for (int n2 = 0; n2 < R2; ++n2) c[n2] = x[n2][k1];
         dft_r<R2, SIGN>(c);
@@ -172,7 +179,7 @@ template <int R1, int R2, int SIGN> __device__ __forceinline__ void dft_pfa(cf *
         for (int k2 = 0; k2 < R2; ++k2) u[(e1 * k1 + e2 * k2) % N] = c[k2]; // CRT output map
     }
 }
-template <int R, int SIGN> __device__ __forceinline__ void dft_r(cf *u)
+template <int R, int SIGN, typename C> __device__ __forceinline__ void dft_r(C *u)
 {
     if constexpr (R == 2) dft2<SIGN>(u[0], u[1]);
     else if constexpr (R == 4) dft4<SIGN>(u[0], u[1], u[2], u[3]);
@@ -240,18 +247,19 @@ __device__ __forceinline__ void fft_pass(cf *buf, int N, int Ns, const cf *W)
 // PRE: the butterfly's twiddle was fetched earlier (pre_w1, one butterfly per thread) — for small
 // jobs, whose cost is the latency of a single workgroup, every table read that follows a barrier
 // is an exposed L2 round trip; fetched at kernel start they all overlap with the input loads.
-template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, bool PRE = false, typename Load, typename Store>
-__device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store, cf pre_w1 = cf())
+template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, bool PRE = false, typename C, typename Load, typename Store>
+__device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, C pre_w1 = C())
 {
     constexpr int nb = N / R, wstep = N / (Ns * R), NB = (nb + NT - 1) / NT;
     static_assert(!PRE || (NB == 1 && R < 10), "prefetched twiddles: one butterfly per thread, radix < 10");
-    cf u[NB][R];
+    typedef real_of<C> T;
+    C u[NB][R];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int j = threadIdx.x + i * NT;
         if (NB * NT == nb || j < nb) {
             const int k = j % Ns;
-            cf w1 = make_float2(1.f, 0.f);
+            C w1 = C((T)1, (T)0);
             if (Ns > 1) w1 = PRE ? pre_w1 : W[k * wstep]; // issued before the data reads: the latencies overlap
 #pragma unroll
             for (int t = 0; t < R; ++t) {
@@ -267,10 +275,10 @@ __device__ __forceinline__ void fft_pass_ct(const cf *W, Load load, Store store,
                 // entry inherits t times its phase error ((w(1+e))^t ~ w^t (1+te)), so for the large
                 // radices a second entry, w^4, is read and w^(4a+b) = (w^4)^a w^b: the error factor
                 // drops from R-1 to <= a+b, for the same number of complex products.
-                cf pw[R];
+                C pw[R];
                 pw[1] = w1;
                 if constexpr (R >= 10) {
-                    const cf w4 = W[4 * k * wstep]; // 4*k*wstep < 4N/R <= N
+                    const C w4 = W[4 * k * wstep]; // 4*k*wstep < 4N/R <= N
 #pragma unroll
                     for (int t = 2; t < R; ++t) {
                         const int a4 = t / 4, b4 = t % 4;
@@ -358,14 +366,14 @@ __device__ __forceinline__ void fft_ct_pre(cf *buf, const cf *W, Load first_load
 #define FFT_STAMP_DECL
 #define FFT_STAMP_ARGS
 #endif
-template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, bool LASTSYNC = false, typename Load, typename Store>
-__device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL cf *buf, const cf *W, Load first_load, Store last_store, bool first_in_lds)
+template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, bool LASTSYNC = false, typename C, typename Load, typename Store>
+__device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL C *buf, const C *W, Load first_load, Store last_store, bool first_in_lds)
 {
     static_assert(R0 * R1 * R2 == N, "radix schedule");
-    auto lds_load = [&](int n) -> cf { return buf[n]; };
-    auto lds_store = [&](int n, cf v) { buf[n] = v; };
-    auto swz_load = [&](int n) -> cf { return buf[SWZ ? n ^ ((n >> 4) & 15) : n]; };
-    auto swz_store = [&](int n, cf v) { buf[SWZ ? n ^ ((n >> 4) & 15) : n] = v; };
+    auto lds_load = [&](int n) -> C { return buf[n]; };
+    auto lds_store = [&](int n, C v) { buf[n] = v; };
+    auto swz_load = [&](int n) -> C { return buf[SWZ ? n ^ ((n >> 4) & 15) : n]; };
+    auto swz_store = [&](int n, C v) { buf[SWZ ? n ^ ((n >> 4) & 15) : n] = v; };
     if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, swz_store);
     else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, swz_store);
     FFT_STAMP();
@@ -385,6 +393,8 @@ struct FftArgs {
     const float2 *WA, *WB, *P, *Q, *Hs; // twiddles of both transforms, (un)tangling twiddles, filter
     const float2 *WA2, *WB2;            // paired-block kernel: twiddles of the full-length transforms
     const float *Hr;                    // k_fft_pair2: the filter as REAL values (see fft_build)
+    const double2 *WA2d, *WB2d;         // k_fft_pair2<double>: the same tables in float64
+    const double *Hrd;
     unsigned long long *trace;          // HIPSOXR_DEBUG_TRACE (builds with -DFFT2_TRACE only): per-wave s_memtime stamps [wg][wave][16]
     int32_t A, B;            // complex transform lengths: N_in/2, N_out/2
     int32_t nA, nB;          // number of passes
@@ -562,12 +572,12 @@ struct PairSpec {
     static constexpr bool prefetch = false;
     static constexpr int RB0 = B0, RA0 = A0;
     struct Tw {};
-    template <typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
+    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st, bool in_lds, const Tw &)
     { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ>(FFT_STAMP_ARGS b, W, ld, st, in_lds); }
-    template <typename Ld, typename St> static __device__ __forceinline__ void inv(FFT_STAMP_DECL cf *b, const cf *W, Ld ld, St st, bool in_lds, const Tw &)
+    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void inv(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st, bool in_lds, const Tw &)
     { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ>(FFT_STAMP_ARGS b, W, ld, st, in_lds); }
     // last pass stores into LDS in another layout (output staging): all its inputs must be in registers first
-    template <typename Ld, typename St> static __device__ __forceinline__ void inv_staged(FFT_STAMP_DECL cf *b, const cf *W, Ld ld, St st)
+    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void inv_staged(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st)
     { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, true>(FFT_STAMP_ARGS b, W, ld, st, true); }
 };
 // Four-pass variant (radices <= 8): more barriers but much shorter butterfly chains per pass —
@@ -756,28 +766,43 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
 //     1.17x the algorithmic bytes with streaming stores).
 // ---------------------------------------------------------------------------------------------
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+template <typename Real> __device__ __forceinline__ Real buf_load_real(__amdgpu_buffer_rsrc_t r, int voff, int soff);
+template <> __device__ __forceinline__ float buf_load_real<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-
-// Raw-buffer descriptor over [p, p + bytes) from wave-uniform values.  The words are passed through
-// readfirstlane: when scalar registers run short the compiler keeps uniform addresses in VGPRs, and a
-// descriptor in VGPRs turns every load into a waterfall loop.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, int32_t bytes)
+template <> __device__ __forceinline__ double buf_load_real<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    const uint64_t u = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane(bytes < 0 ? 0 : bytes), 0x00020000);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+// per-precision views of the kernel arguments
+template <typename Real> struct PairTabs;
+template <> struct PairTabs<float> {
+    typedef float2 C; typedef float4 V16;
+    static __device__ __forceinline__ const C *wa(const FftArgs &a) { return a.WA2; }
+    static __device__ __forceinline__ const C *wb(const FftArgs &a) { return a.WB2; }
+    static __device__ __forceinline__ const float *hr(const FftArgs &a) { return a.Hr; }
+};
+template <> struct PairTabs<double> {
+    typedef double2 C; typedef double2 V16;
+    static __device__ __forceinline__ const C *wa(const FftArgs &a) { return a.WA2d; }
+    static __device__ __forceinline__ const C *wb(const FftArgs &a) { return a.WB2d; }
+    static __device__ __forceinline__ const double *hr(const FftArgs &a) { return a.Hrd; }
+};
 
-template <typename Spec>
+// Real = float: float32 device jobs.  Real = double: float64 device jobs — libsoxr's own VHQ engine is a
+// float64 one; the same chain in double2 (LDS 16 bytes per point), results within the
+// method's own floor of the float64 direct form (the neglected stop-band aliasing, ~3e-10 for VHQ).
+template <typename Spec, typename Real>
 __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 {
+    typedef typename PairTabs<Real>::C C;
+    typedef typename PairTabs<Real>::V16 V16;
+    constexpr int ES = (int)sizeof(Real), EPS = 16 / ES; // element size, elements per 16-byte store
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *cur = reinterpret_cast<cf *>(smem_raw);
-    float *stage = reinterpret_cast<float *>(smem_raw);
+    C *cur = reinterpret_cast<C *>(smem_raw);
+    Real *stage = reinterpret_cast<Real *>(smem_raw);
     constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0;
 #ifdef FFT2_TRACE
     unsigned long long *g_tr = a.trace ? a.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + threadIdx.x / 64) * 16 : nullptr;
@@ -791,31 +816,31 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     const int64_t pa = 2 * bx * a.hop_periods - a.lead_periods; // first period of block a; block b starts hop_periods later
     const int64_t ina = pa * a.M, outa = pa * a.L;
     const int32_t hop_in = (int32_t)(a.hop_periods * a.M);
-    const float *xin = (const float *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    const Real *xin = (const Real *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
 #if defined(FFT2_ABL) && (FFT2_ABL & 8)
-    auto lds_store = [&](int n, cf v) { if (v.x == 1234.5f) cur[n] = v; };
+    auto lds_store = [&](int n, C v) { if (v.x == (Real)1234.5) cur[n] = v; };
 #else
-    auto lds_store = [&](int n, cf v) { cur[n] = v; };
+    auto lds_store = [&](int n, C v) { cur[n] = v; };
 #endif
     typename Spec::Tw tw;
 
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
     if (ina >= 0) {
-        const int64_t left = (a.in_frames - ina) * 4; // bytes from block a's first sample to the end of the column
+        const int64_t left = (a.in_frames - ina) * ES; // bytes from block a's first sample to the end of the column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(xin + ina), 0, (int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left), 0x00020000);
-        Spec::fwd(FFT_STAMP_ARGS cur, a.WA2, [&](int n, int t) -> cf {
-            const int j4 = (n - t * nbA) * 4; // the butterfly's own offset (one VGPR for all t)
+        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int t) -> C {
+            const int j4 = (n - t * nbA) * ES; // the butterfly's own offset (one VGPR for all t)
 #if defined(FFT2_ABL) && (FFT2_ABL & 2)
-            return make_float2((float)(j4 + t) * 1e-4f, (float)(j4 ^ t) * 1e-4f);
+            return C((Real)(j4 + t) * (Real)1e-4, (Real)(j4 ^ t) * (Real)1e-4);
 #endif
-            return make_float2(buf_load_f32(rs, j4, t * nbA * 4), buf_load_f32(rs, j4, (t * nbA + hop_in) * 4));
+            return C(buf_load_real<Real>(rs, j4, t * nbA * ES), buf_load_real<Real>(rs, j4, (t * nbA + hop_in) * ES));
         }, lds_store, false, tw);
     } else { // the first pair of a column reaches before its start: explicit zero-extension
         const int64_t inb = ina + hop_in;
-        Spec::fwd(FFT_STAMP_ARGS cur, a.WA2, [&](int n, int) -> cf {
+        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int) -> C {
             const int64_t la = ina + n, lb = inb + n;
-            return make_float2((la >= 0 && la < a.in_frames) ? xin[la] : 0.f, (lb >= 0 && lb < a.in_frames) ? xin[lb] : 0.f);
+            return C((la >= 0 && la < a.in_frames) ? xin[la] : (Real)0, (lb >= 0 && lb < a.in_frames) ? xin[lb] : (Real)0);
         }, lds_store, false, tw);
     }
     __syncthreads();
@@ -823,22 +848,24 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 
     // ---- inverse (see k_fft_pair), last pass into the staging layout -------------------------------
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
-    float *ybase = (float *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
-    const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) >> 2) & 3); // LDS float index == run index + sh: 16-byte phases agree
-    auto h_load = [&](int n, int) -> cf { // bin n of the output grid <- bin n or n + NA - NB of the input grid, times (real) H
+    Real *ybase = (Real *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
+    // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
+    const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
+    const Real *Hr = PairTabs<Real>::hr(a);
+    auto h_load = [&](int n, int) -> C { // bin n of the output grid <- bin n or n + NA - NB of the input grid, times (real) H
         const bool neg = n > NB / 2;
         const int q = neg ? NB - n : n; // |frequency| in bins
-        const float h = a.Hr[q];
+        const Real h = Hr[q];
         if constexpr (NA >= NB) {
-            const cf x = cur[neg ? n + (NA - NB) : n];
-            return make_float2(x.x * h, x.y * h); // (the Nyquist bin's alias term is dropped with Im H: stop band, < -170 dB)
+            const C x = cur[neg ? n + (NA - NB) : n];
+            return C(x.x * h, x.y * h); // (the Nyquist bin's alias term is dropped with Im H: stop band, < -170 dB)
         } else {
             const bool in_band = q < NA / 2;
-            const cf x = cur[in_band ? (neg ? NA - q : q) : 0];
-            return in_band ? make_float2(x.x * h, x.y * h) : make_float2(0.f, 0.f);
+            const C x = cur[in_band ? (neg ? NA - q : q) : 0];
+            return in_band ? C(x.x * h, x.y * h) : C((Real)0, (Real)0);
         }
     };
-    Spec::inv_staged(FFT_STAMP_ARGS cur, a.WB2, h_load, [&](int n, cf w) {
+    Spec::inv_staged(FFT_STAMP_ARGS cur, PairTabs<Real>::wb(a), h_load, [&](int n, C w) {
         if (n >= v0 && n < v1) {
             stage[n - v0 + sh] = w.x;
             stage[n - v0 + sh + hop_out] = w.y;
@@ -847,27 +874,23 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     __syncthreads();
     FFT_STAMP();
 
-    // ---- store the run: floats [0, valid) of it exist in the column -----------------------------------
+    // ---- store the run: elements [0, valid) of it exist in the column ----------------------------------
     const int64_t remain = a.out_frames - (outa + v0);
     const int32_t valid = (int32_t)(remain < 0 ? 0 : remain > 2 * (int64_t)hop_out ? 2 * (int64_t)hop_out : remain);
-    const int32_t nq = (valid + sh + 3) >> 2;
+    const int32_t nq = (valid + sh + EPS - 1) / EPS;
     for (int32_t q = threadIdx.x; q < nq; q += NT) {
-        const float4 v = *reinterpret_cast<const float4 *>(stage + 4 * q);
-        const int32_t i0 = 4 * q - sh;
+        const V16 v = *reinterpret_cast<const V16 *>(stage + EPS * q);
+        const int32_t i0 = EPS * q - sh;
 #if defined(FFT2_ABL) && (FFT2_ABL & 4)
-        if (v.x != 1234.5f) continue;
+        if (v.x != (Real)1234.5) continue;
 #endif
-        if (i0 >= 0 && i0 + 3 < valid) {
-#ifdef FFT2_NT_STORE
-            __builtin_nontemporal_store(v, reinterpret_cast<float4 *>(ybase + i0));
-#else
-            *reinterpret_cast<float4 *>(ybase + i0) = v;
-#endif
+        if (i0 >= 0 && i0 + EPS - 1 < valid) {
+            *reinterpret_cast<V16 *>(ybase + i0) = v;
         } else {
-            if (i0 >= 0 && i0 < valid) ybase[i0] = v.x;
-            if (i0 + 1 >= 0 && i0 + 1 < valid) ybase[i0 + 1] = v.y;
-            if (i0 + 2 >= 0 && i0 + 2 < valid) ybase[i0 + 2] = v.z;
-            if (i0 + 3 >= 0 && i0 + 3 < valid) ybase[i0 + 3] = v.w;
+            const Real *e = reinterpret_cast<const Real *>(&v);
+#pragma unroll
+            for (int c = 0; c < EPS; ++c)
+                if (i0 + c >= 0 && i0 + c < valid) ybase[i0 + c] = e[c];
         }
     }
 #ifdef FFT2_TRACE
@@ -886,7 +909,8 @@ struct FftGeom {
     std::vector<int> radA, radB;
     int32_t lead_periods = 0, hop_periods = 0, v0 = 0, hop_out = 0;
     size_t lds_bytes = 0;
-    float2 *dev = nullptr; // [WA: A][WB: B][P: A+1][Q: B][Hs: B+1][WA2: N_in][WB2: N_out]
+    float2 *dev = nullptr; // [WA: A][WB: B][P: A+1][Q: B][Hs: B+1][WA2: N_in][WB2: N_out][Hr: B+1 floats]
+    double2 *devd = nullptr; // float64 instance of the paired kernel: [WA2d: N_in][WB2d: N_out][Hrd: B+1 doubles]
 };
 
 static bool factor_radices(int n, std::vector<int> &rad)
@@ -915,6 +939,7 @@ void fft_release(const Plan *p)
     for (size_t i = 0; i < g_fft.size();)
         if (g_fft[i].first.first == p) {
             if (g_fft[i].second.dev) (void)hipFree(g_fft[i].second.dev);
+            if (g_fft[i].second.devd) (void)hipFree(g_fft[i].second.devd);
             g_fft.erase(g_fft.begin() + i);
         } else ++i;
 }
@@ -969,6 +994,7 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_
     // H[q] = sum_p sum_j bank[p][j] exp(-2 pi i q (L*(T/2-1-j) + p) / (L*N_in)), scaled by 1/(N_in*L)
     const double scale = 1.0 / ((double)g.N_in * (double)L);
     const int qmax = std::min(A, B);
+    std::vector<double> hr64((size_t)B + 1, 0.); // Re H in float64 (float64 instance of the paired kernel)
     for (int q = 0; q <= B; ++q) {
         if (q > qmax) { Hs[q] = make_float2(0.f, 0.f); continue; }
         double hr = 0., hi = 0.;
@@ -990,9 +1016,19 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_
         // even-length support, g[-L T/2], is a window-edge value ~1e-11).  The newer paired kernels use
         // Re H alone: half the table reads and a real x complex product per bin.
         reinterpret_cast<float *>(WB2 + g.N_out)[q] = (float)(hr * scale);
+        hr64[q] = hr * scale;
     }
     HIP_TRY(hipMalloc((void **)&g.dev, tab.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(g.dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    { // the float64 instance's tables (small: N_in + N_out + B/2 double2)
+        std::vector<double2> td((size_t)g.N_in + g.N_out + (B + 2) / 2 + 1);
+        for (int m = 0; m < g.N_in; ++m) td[m] = make_double2(std::cos(PI2 * m / g.N_in), -std::sin(PI2 * m / g.N_in));
+        for (int m = 0; m < g.N_out; ++m) td[(size_t)g.N_in + m] = make_double2(std::cos(PI2 * m / g.N_out), std::sin(PI2 * m / g.N_out));
+        double *hrd = reinterpret_cast<double *>(td.data() + g.N_in + g.N_out);
+        for (int q = 0; q <= B; ++q) hrd[q] = q < (int)hr64.size() ? hr64[q] : 0.;
+        HIP_TRY(hipMalloc((void **)&g.devd, td.size() * sizeof(double2)));
+        HIP_TRY(hipMemcpy(g.devd, td.data(), td.size() * sizeof(double2), hipMemcpyHostToDevice));
+    }
     g.ok = true;
     *out = g;
     return nullptr;
@@ -1003,8 +1039,9 @@ bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &j)
 {
     // what the method neglects is the aliasing of the filter's stop band: only recipes whose stop band
     // is far below the 1e-6 bar qualify (HQ 128 dB, VHQ 177 dB; MQ/LQ at 104 dB do not)
-    return p.phases == 0 && p.att_db >= 120. && j.elem == HIPSOXR_F32 && j.in_abs0 == 0 && j.out_k0 == 0 &&
-           (uint64_t)j.out_frames <= plan_out_len(p, (uint64_t)j.in_frames);
+    // float64 jobs: the paired kernel has a float64 instance (unit-stride columns, the ratio table below)
+    return p.phases == 0 && p.att_db >= 120. && (j.elem == HIPSOXR_F32 || j.elem == HIPSOXR_F64) && j.in_abs0 == 0 &&
+           j.out_k0 == 0 && (uint64_t)j.out_frames <= plan_out_len(p, (uint64_t)j.in_frames);
 }
 
 const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *handled)
@@ -1021,8 +1058,9 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         return nullptr;
     };
     // ---- paired-block kernels: compile-time schedules for the common ratios -------------------
-    struct PairEntry { int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); };
-#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT, k_fft_pair2<PairOf<NA, NB, NT>>}
+    struct PairEntry { int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); void (*kern2d)(FftArgs); };
+#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) \
+    {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>}
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
         HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
@@ -1042,6 +1080,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
 #undef HIPSOXR_PAIR
     const bool no_pair = switches().fft_no_pair;
     const uint64_t cols_p = (uint64_t)j.n_clips * j.n_channels;
+    const bool f64 = j.elem == HIPSOXR_F64;
+    if (f64 && (no_pair || cols_p > 65535 || j.in_frame_stride != 1 || j.out_frame_stride != 1)) return nullptr; // exact engine
     if (!no_pair && cols_p <= 65535) {
         const PairEntry *big = nullptr, *sml = nullptr;
         int big_i = 0, sml_i = 0;
@@ -1057,7 +1097,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 // few work items (one 60 s clip = 300 pairs): half-size blocks give twice as many,
                 // shorter workgroups, at the price of more overlap
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
-                if ((wgs < 480 && !switches().fft_large_only) || switches().fft_small_only) { // measured crossover: ~470 pairs of large blocks
+                // (float64: LDS is 16 bytes per point — the half-size blocks keep four workgroups per CU)
+                if ((wgs < 480 && !switches().fft_large_only) || switches().fft_small_only || f64) { // measured crossover: ~470 pairs of large blocks
                     FftGeom gs;
                     if (const char *err = get(2 + sml_i, sml->k, &gs)) return err;
                     if (gs.ok) { g = gs; use = sml; }
@@ -1066,10 +1107,10 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             // Latency-bound jobs (everything resident at once, about one workgroup per CU slot):
             // the four-pass schedule with prefetched tables has the shorter critical path (7.1 vs
             // 9.0 us for one workgroup); from ~400 workgroups on, the three-pass one wins on work.
-            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr};
+            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr};
             if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && !switches().fft_small_3pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
-                if (wgs < 400) use = &low_latency;
+                if (wgs < 400 && !f64) use = &low_latency;
             }
             if (use) {
                 FftArgs a;
@@ -1077,6 +1118,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
                 a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
                 a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
+                a.WA2d = g.devd; a.WB2d = g.devd + g.N_in; a.Hrd = reinterpret_cast<const double *>(g.devd + g.N_in + g.N_out);
                 a.A = g.A; a.B = g.B; a.nA = a.nB = 0;
                 for (int i = 0; i < 8; ++i) a.radA[i] = a.radB[i] = 1;
                 a.L = p->L; a.M = p->M;
@@ -1091,30 +1133,34 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.chpair = (j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1 &&
                             j.in_frame_stride % 2 == 0 && j.out_frame_stride % 2 == 0 && j.in_clip_stride % 2 == 0 &&
                             j.out_clip_stride % 2 == 0 && ((uintptr_t)j.in & 7) == 0 && ((uintptr_t)j.out & 7) == 0 &&
-                            !switches().fft_no_chpair) ? 1 : 0;
-                const size_t lds = std::max((size_t)std::max(g.N_in, g.N_out) * sizeof(float2), switches().dbg_fft_lds);
+                            !switches().fft_no_chpair && !f64) ? 1 : 0;
+                const size_t lds = std::max((size_t)std::max(g.N_in, g.N_out) * (f64 ? sizeof(double2) : sizeof(float2)), switches().dbg_fft_lds);
+                if (f64 && lds > 160 * 1024) return nullptr;
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)use->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 // work items per channel unit: blocks (channel pairs) or pairs of blocks (single channels)
                 const int64_t items = a.chpair ? n_blocks : (n_blocks + 1) / 2, items8 = (items + 7) / 8 * 8;
                 const int64_t units = a.chpair ? j.n_channels / 2 : j.n_channels;
                 a.xcd_map = (j.n_channels > 1 && j.in_chan_stride == 1 && j.out_chan_stride == 1 && j.n_clips <= 65535 &&
-                             items8 * units <= 2147483647LL && !switches().fft_no_xcd_map) ? 1 : 0;
+                             items8 * units <= 2147483647LL && !switches().fft_no_xcd_map && !f64) ? 1 : 0;
                 if (a.chpair && !a.xcd_map) a.chpair = 0; // (channel pairing is only laid out through the XCD map)
                 a.pairs_per_col = items;
                 const dim3 grid = a.xcd_map ? dim3((unsigned)(items8 * units), j.n_clips, 1)
                                             : dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols_p, 1);
                 // unit-stride columns (mono / planar): the second-generation kernel (buffer loads, staged aligned stores)
                 void (*kern)(FftArgs) = use->kern;
-                if (use->kern2 && !a.xcd_map && !a.chpair && j.in_frame_stride == 1 && j.out_frame_stride == 1 &&
-                    2 * (size_t)g.hop_out * sizeof(float) + 16 <= lds && !switches().fft_pair_v1) {
-                    kern = use->kern2;
+                const size_t esz = f64 ? sizeof(double) : sizeof(float);
+                const bool v2ok = use->kern2 && !a.xcd_map && !a.chpair && j.in_frame_stride == 1 && j.out_frame_stride == 1 &&
+                                  2 * (size_t)g.hop_out * esz + 16 <= lds;
+                if (f64 && !v2ok) return nullptr; // (no float64 instance of the first-generation kernel: exact engine)
+                if (v2ok && (f64 || !switches().fft_pair_v1)) {
+                    kern = f64 ? use->kern2d : use->kern2;
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }
 #ifdef FFT2_TRACE
                 size_t trace_n = 0;
-                if (switches().dbg_trace && kern == use->kern2) {
+                if (switches().dbg_trace && (kern == use->kern2 || kern == use->kern2d)) {
                     trace_n = (size_t)grid.x * grid.y * (use->nt / 64) * 16;
                     HIP_TRY(hipMalloc((void **)&a.trace, trace_n * 8));
                     HIP_TRY(hipMemset(a.trace, 0, trace_n * 8));
@@ -1137,6 +1183,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         }
     }
     // ---- general path: one block per workgroup ---------------------------------------------------
+    if (f64) return nullptr; // float32 only
     FftGeom g;
     if (const char *err = get(0, 0, &g)) return err;
     if (g.ok) {
@@ -1153,6 +1200,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
     a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
+    a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr;
     a.A = g.A; a.B = g.B; a.nA = (int32_t)g.radA.size(); a.nB = (int32_t)g.radB.size();
     for (int i = 0; i < 8; ++i) { a.radA[i] = i < a.nA ? g.radA[i] : 1; a.radB[i] = i < a.nB ? g.radB[i] : 1; }
     a.L = p->L; a.M = p->M;

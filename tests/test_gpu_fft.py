@@ -137,3 +137,46 @@ def test_host_surface_never_uses_the_fft_engine(soxr, oracle):
     for k0 in (0, 250000, len(y) - 500):
         want = oracle.resample_channel(pl, x, "port_f32", k0=k0, n_out=500)
         assert np.array_equal(y[k0:k0 + 500], want)
+
+
+@pytest.mark.parametrize("in_rate,out_rate,quality,tol", [(48000, 44100, "VHQ", 2e-9), (44100, 48000, "VHQ", 2e-9),
+                                                          (44100, 16000, "VHQ", 2e-9), (48000, 44100, "HQ", 1e-6),
+                                                          (96000, 48000, "VHQ", 2e-9), (16000, 48000, "VHQ", 2e-9)])
+def test_fft_engine_float64_instance(oracle, in_rate, out_rate, quality, tol):
+    """float64 device jobs: the paired kernel in double2 (libsoxr's own VHQ engine is a float64 one, SURVEY.md
+    §0.3).  Against the oracle's float64 direct form what is left is the method's own floor — the neglected
+    aliasing of the stop band: ~3e-10 relative RMS for VHQ (-177 dB), ~4e-7 for HQ (-128 dB) — not rounding."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(17)
+    plan = dev.Plan(in_rate, out_rate, quality)
+    for shape in ((50000,), (3, 20001, 1), (7, 1)):            # mono, a batch of planar columns, a tiny job
+        x = rng.standard_normal(shape) * 0.25
+        xt = torch.from_numpy(x).cuda()
+        y = dev.resample_tensor(plan, xt, kernel=FFT)
+        assert y.dtype == torch.float64
+        y = y.cpu().numpy()
+        cols = x.reshape(-1, x.shape[-2] if x.ndim == 3 else x.shape[0]) if x.ndim != 2 else x.T
+        if x.ndim == 1:
+            ref = oracle.resample(x, in_rate, out_rate, quality, mode="ref")
+        elif x.ndim == 3:
+            ref = np.stack([oracle.resample(x[c, :, 0], in_rate, out_rate, quality, mode="ref") for c in range(x.shape[0])])[:, :, None]
+        else:
+            ref = oracle.resample(x, in_rate, out_rate, quality, mode="ref")
+        assert y.shape == ref.shape
+        assert _rms(y - ref) <= tol * max(_rms(ref), 1e-3), (shape, _rms(y - ref) / max(_rms(ref), 1e-3))
+
+
+def test_auto_engine_float64_large_job_is_frequency_domain_and_close(oracle):
+    """AUTO on a large float64 device job now takes the frequency-domain engine: not bit-identical to the
+    canonical order any more (the host surface still is: it passes KERNEL_EXACT), within 2e-9 of it."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(18)
+    x = rng.standard_normal(200000) * 0.25
+    plan = dev.Plan(48000, 44100, "VHQ")
+    xt = torch.from_numpy(x).cuda()
+    auto = dev.resample_tensor(plan, xt).cpu().numpy()
+    exact = dev.resample_tensor(plan, xt, kernel=EXACT).cpu().numpy()
+    assert np.array_equal(exact, oracle.resample(x, 48000, 44100, "VHQ", mode="port"))
+    assert 0 < _rms(auto - exact) <= 2e-9 * _rms(exact)
