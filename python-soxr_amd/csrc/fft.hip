@@ -189,6 +189,7 @@ template <int R, int SIGN, typename C> __device__ __forceinline__ void dft_r(C *
     else if constexpr (R == 10) dft_pfa<2, 5, SIGN>(u);
     else if constexpr (R == 12) dft_pfa<4, 3, SIGN>(u);
     else if constexpr (R == 14) dft_pfa<2, 7, SIGN>(u);
+    else if constexpr (R == 15) dft_pfa<3, 5, SIGN>(u);
     else if constexpr (R == 20) dft_pfa<4, 5, SIGN>(u);
     else if constexpr (R == 21) dft_pfa<3, 7, SIGN>(u);
     else dft_odd<R, SIGN>(u);
@@ -613,12 +614,14 @@ HIPSOXR_SCHED(7056, 21, 16, 21, false);
 HIPSOXR_SCHED(5376, 21, 16, 16, false);
 HIPSOXR_SCHED(5120, 16, 16, 20, true);
 HIPSOXR_SCHED(4704, 21, 16, 14, false);
+HIPSOXR_SCHED(4410, 21, 14, 15, false);
 HIPSOXR_SCHED(4096, 16, 16, 16, true);
 HIPSOXR_SCHED(3584, 14, 16, 16, false);
 HIPSOXR_SCHED(2560, 16, 16, 10, true);
 HIPSOXR_SCHED(2352, 21, 16, 7, false);
 HIPSOXR_SCHED(2048, 16, 16, 8, true);
 HIPSOXR_SCHED(1792, 7, 16, 16, false);
+HIPSOXR_SCHED(1600, 16, 10, 10, true);
 HIPSOXR_SCHED(1280, 5, 16, 16, false);
 HIPSOXR_SCHED(1176, 21, 8, 7, false);
 HIPSOXR_SCHED(896, 7, 16, 8, false);
@@ -713,21 +716,27 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
     auto h_load = [&](int n, int t) -> cf { // t: which of the butterfly's inputs (selects the prefetched H)
         const bool neg = n > NB / 2;
         const int q = neg ? NB - n : n; // |frequency| in bins
-        cf h;
-        if constexpr (Spec::prefetch) {
-            h = hpre[t];
+        if constexpr (!Spec::prefetch) { // H is real (see fft_build): one table word and a real x complex product per bin
+            const float h = a.Hr[q];
+            if constexpr (NA >= NB) {
+                const cf x = cur[neg ? n + (NA - NB) : n];
+                return make_float2(x.x * h, x.y * h);
+            } else {
+                const bool in_band = q < NA / 2; // the input Nyquist bin itself carries only stop-band energy
+                const cf x = cur[in_band ? (neg ? NA - q : q) : 0];
+                return in_band ? make_float2(x.x * h, x.y * h) : make_float2(0.f, 0.f);
+            }
         } else {
-            h = a.Hs[q];
-            if (neg) h.y = -h.y;
-        }
-        if constexpr (NA >= NB) { // down-sampling: the spectrum is truncated
-            cf y = cmul(cur[neg ? n + (NA - NB) : n], h);
-            if (n == NB / 2) y = cadd(y, cmul(cur[n + (NA - NB)], cconj(h)));
-            return y;
-        } else {                  // up-sampling: the spectrum is zero-extended
-            const bool in_band = q < NA / 2; // the input Nyquist bin itself carries only stop-band energy
-            const cf y = cmul(cur[in_band ? (neg ? NA - q : q) : 0], h);
-            return in_band ? y : make_float2(0.f, 0.f);
+            const cf h = hpre[t];
+            if constexpr (NA >= NB) { // down-sampling: the spectrum is truncated
+                cf y = cmul(cur[neg ? n + (NA - NB) : n], h);
+                if (n == NB / 2) y = cadd(y, cmul(cur[n + (NA - NB)], cconj(h)));
+                return y;
+            } else {                  // up-sampling: the spectrum is zero-extended
+                const bool in_band = q < NA / 2;
+                const cf y = cmul(cur[in_band ? (neg ? NA - q : q) : 0], h);
+                return in_band ? y : make_float2(0.f, 0.f);
+            }
         }
     };
     auto out_store = [&](int n, cf w) {
@@ -906,7 +915,7 @@ struct FftGeom {
     bool ok = false;
     int k = 0;
     int32_t N_in = 0, N_out = 0, A = 0, B = 0;
-    std::vector<int> radA, radB;
+    int32_t radA[8] = {1, 1, 1, 1, 1, 1, 1, 1}, radB[8] = {1, 1, 1, 1, 1, 1, 1, 1}, nA = 0, nB = 0; // (plain arrays: the cached geometry is copied per launch)
     int32_t lead_periods = 0, hop_periods = 0, v0 = 0, hop_out = 0;
     size_t lds_bytes = 0;
     float2 *dev = nullptr; // [WA: A][WB: B][P: A+1][Q: B][Hs: B+1][WA2: N_in][WB2: N_out][Hr: B+1 floats]
@@ -964,7 +973,8 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_
         if (!factor_radices((int)(Nin / 2), ra) || !factor_radices((int)(Nout / 2), rb)) continue;
         if (!force_k && g.k && (small || std::max(Nin, Nout) / 2 > 2600)) break;
         g.k = k; g.N_in = (int32_t)Nin; g.N_out = (int32_t)Nout; g.A = g.N_in / 2; g.B = g.N_out / 2;
-        g.radA = ra; g.radB = rb;
+        g.nA = (int32_t)ra.size(); g.nB = (int32_t)rb.size();
+        for (int i = 0; i < 8; ++i) { g.radA[i] = i < g.nA ? ra[i] : 1; g.radB[i] = i < g.nB ? rb[i] : 1; }
     }
     if (!g.k) { *out = g; return nullptr; }
     // outputs whose filter support [n_k, n_k + T) lies inside the block: discard ceil((T/2+2)*L/M)
@@ -1066,6 +1076,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
         HIPSOXR_PAIR(160, 147, 32, false, 4704, 5120, 384), HIPSOXR_PAIR(160, 147, 16, true, 2352, 2560, 384),   // 44.1k -> 48k
         HIPSOXR_PAIR(160, 441, 16, false, 7056, 2560, 448), HIPSOXR_PAIR(441, 160, 16, false, 2560, 7056, 448),  // 44.1k <-> 16k
+        HIPSOXR_PAIR(160, 441, 10, true, 4410, 1600, 320), HIPSOXR_PAIR(441, 160, 10, true, 1600, 4410, 320),    // ... 35 KB blocks: 4 workgroups per CU
         HIPSOXR_PAIR(1, 2, 2048, false, 4096, 2048, 256), HIPSOXR_PAIR(2, 1, 2048, false, 2048, 4096, 256),      // 2:1, 1:2
         HIPSOXR_PAIR(1, 3, 1792, false, 5376, 1792, 384), HIPSOXR_PAIR(3, 1, 1792, false, 1792, 5376, 384),      // 48k <-> 16k
         HIPSOXR_PAIR(2, 3, 1792, false, 5376, 3584, 384), HIPSOXR_PAIR(3, 2, 1792, false, 3584, 5376, 384),      // 48k <-> 32k
@@ -1201,8 +1212,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
     a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
     a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr;
-    a.A = g.A; a.B = g.B; a.nA = (int32_t)g.radA.size(); a.nB = (int32_t)g.radB.size();
-    for (int i = 0; i < 8; ++i) { a.radA[i] = i < a.nA ? g.radA[i] : 1; a.radB[i] = i < a.nB ? g.radB[i] : 1; }
+    a.A = g.A; a.B = g.B; a.nA = g.nA; a.nB = g.nB;
+    for (int i = 0; i < 8; ++i) { a.radA[i] = g.radA[i]; a.radB[i] = g.radB[i]; }
     a.L = p->L; a.M = p->M;
     a.lead_periods = g.lead_periods; a.hop_periods = g.hop_periods; a.v0 = g.v0; a.hop_out = g.hop_out;
     a.n_clips = j.n_clips; a.n_channels = j.n_channels;
