@@ -6,6 +6,12 @@ import sqlite3
 import sys
 
 
+def short(name):
+    """Kernel name without the hipsoxr:: noise but WITH its template arguments (float and double instances
+    of one kernel share grid and block sizes: a 48-character prefix would merge their counters)."""
+    return name.replace("hipsoxr::", "").replace("void ", "")[:150]
+
+
 def main(paths):
     for db in paths:
         c = sqlite3.connect(db)
@@ -20,14 +26,14 @@ def main(paths):
                  "max(end-start) from kernels group by name, grid_x, grid_y, grid_z")
             for r in c.execute(q):
                 if "hipsoxr" in r[0]:
-                    print("  per-grid: %-44s grid (%d,%d,%d) block %d  n=%d  avg %.2f us  min %.2f  max %.2f" % (
-                        r[0][:44], r[1], r[2], r[3], r[4], r[5], r[6] / 1e3, r[7] / 1e3, r[8] / 1e3))
+                    print("  per-grid: %-100s grid (%d,%d,%d) block %d  n=%d  avg %.2f us  min %.2f  max %.2f" % (
+                        short(r[0])[:100], r[1], r[2], r[3], r[4], r[5], r[6] / 1e3, r[7] / 1e3, r[8] / 1e3))
         except sqlite3.Error:
             pass
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         try:
             for r in c.execute("select kernel_name, counter_name, value, grid_size, workgroup_size from counters_collection"):
-                agg[(r[0][:48], r[3], r[4])][r[1]].append(r[2])
+                agg[(short(r[0]), r[3], r[4])][r[1]].append(r[2])
         except sqlite3.Error:
             pass
         for k, v in agg.items():
