@@ -230,16 +230,17 @@ def live_libsoxr_timing(x):
 def configs4_stream(seconds=20):
     """BASELINE configs[4]: ResampleStream 44100->16000 int16, chunked input, state carried across
     launches (host-pointer surface: every call is H2D + kernel + D2H).  us per resample_chunk call and
-    Msamples/s for the chunk sizes SURVEY.md §8d names, constant rate and variable rate."""
+    Msamples/s for the chunk sizes SURVEY.md §8d names: constant rate (synchronous calls, and with deferred
+    output — each call returns the previous call's frames, no GPU round trip inside the call) and variable rate."""
     import numpy as np
     import soxr_amd as soxr
     rng = np.random.default_rng(5)
     x = (rng.standard_normal(44100 * seconds) * 5000).astype(np.int16)
     out = {"workload": f"BASELINE configs[4]: ResampleStream 44100->16000 int16 VHQ mono, {seconds} s, chunked "
                        f"(host numpy in/out per call, state on device)"}
-    for vr in (False, True):
+    for vr, deferred in ((False, False), (False, True), (True, False)):
         for chunk in (441, 4410, 96000):
-            rs = soxr.ResampleStream(44100, 16000, 1, dtype="int16", quality="VHQ", vr=vr)
+            rs = soxr.ResampleStream(44100, 16000, 1, dtype="int16", quality="VHQ", vr=vr, deferred=deferred)
             rs.resample_chunk(x[:chunk])  # warm up: buffers, plan tables
             rs.clear()
             n_calls = 0
@@ -250,7 +251,7 @@ def configs4_stream(seconds=20):
                 rs.resample_chunk(x[a:a + chunk], last=(a + chunk >= len(x)))
                 n_calls += 1
             dt = time.perf_counter() - t0
-            out[f"{'vr' if vr else 'cr'}_chunk{chunk}"] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls,
+            out[f"{'vr' if vr else 'cr_deferred' if deferred else 'cr'}_chunk{chunk}"] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls,
                                                             "Msamples_per_s": len(x) / dt / 1e6}
     return out
 

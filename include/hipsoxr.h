@@ -70,6 +70,10 @@ typedef enum {
 /* Stream flags. */
 #define HIPSOXR_VR 32UL        /* quality-spec flag: variable rate (reference: src/soxr_ext.cpp:74) */
 #define HIPSOXR_NO_DITHER 8UL  /* io-spec flag: disable int16 TPDF dither */
+#define HIPSOXR_DEFER 64UL     /* (extension) deferred output: a process call enqueues its work and returns the
+                                  PREVIOUS call's frames — no GPU round trip inside the call.  Same concatenated
+                                  output; frames surface one call later (the reference's contract allows any
+                                  per-call count, README.md:77-78).  Constant-rate interleaved streams. */
 
 /* Element types used by device jobs (layout is given by strides, not by the type). */
 typedef enum { HIPSOXR_F32 = 0, HIPSOXR_F64 = 1, HIPSOXR_I32 = 2, HIPSOXR_I16 = 3 } hipsoxr_elem_t;

@@ -42,6 +42,7 @@ struct Switches {
     bool fft_small_3pass = false; // HIPSOXR_FFT_SMALL_3PASS  small 147/160 blocks on the 3-pass (radix 16/21) schedule
     bool fft_pair_v1 = false;     // HIPSOXR_FFT_PAIR_V1      unit-stride jobs on k_fft_pair instead of k_fft_pair2
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
+    bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids
     bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp

@@ -80,6 +80,10 @@ struct hipsoxr_stream {
     size_t in_cap = 0, alt_cap = 0; // frames
     int64_t in_base = 0;
     size_t in_fill = 0;
+    // Small-chunk streams keep the ring in pinned, device-mapped HOST memory: appending is a memcpy (no
+    // copy call on the HIP stream at all) and the kernel reads its few hundred window samples over PCIe in
+    // the one round trip it makes anyway.  A chunk above kHostRingChunk moves the ring to device memory for good.
+    bool ring_on_host = false;
     void *d_out = nullptr;
     size_t out_cap = 0; // frames
     uint64_t *d_clips = nullptr;
@@ -90,6 +94,15 @@ struct hipsoxr_stream {
     void *h_in = nullptr, *h_out = nullptr;
     size_t h_in_bytes = 0, h_out_bytes = 0;
     hipEvent_t ev = nullptr; // completion of a call's last operation (see stream_wait)
+    // Deferred output (HIPSOXR_DEFER): a call enqueues its copy and launch and returns the PREVIOUS call's
+    // result, which finished long ago — no GPU round trip inside the call (see stream_process_deferred)
+    bool defer = false;
+    size_t pend_n = 0, pend_off = 0; // frames produced by the launch in flight / already handed out of them
+    int pend_slot = 0;
+    void *h_res[2] = {nullptr, nullptr}, *h_src[2] = {nullptr, nullptr}; // pinned result / input bounce buffers, alternating
+    size_t h_res_bytes[2] = {0, 0}, h_src_bytes[2] = {0, 0};
+    hipEvent_t ev_res[2] = {nullptr, nullptr}, ev_src[2] = {nullptr, nullptr};
+    unsigned calls = 0;
     int device = -1;         // the device the HIP stream and every buffer above live on
     uint32_t dither_seed = 0; // int16 TPDF dither: hash(seed, channel, absolute output index); see hipsoxr_stream_set_dither_seed
     char engine_name[32] = {0};
@@ -123,6 +136,7 @@ static hipError_t stream_wait(hipsoxr_stream *s)
     return hipStreamSynchronize(s->st);
 }
 static const size_t kPinnedMax = (size_t)1 << 20; // chunks up to 1 MiB go through the bounce buffers
+static const size_t kHostRingChunk = (size_t)64 << 10; // chunks up to 64 KiB: ring in pinned host memory (see hipsoxr_stream)
 
 static const char *pinned_ensure(void **buf, size_t *cap, size_t bytes)
 {
@@ -203,6 +217,7 @@ static const char *plan_acquire(double in_rate, double out_rate, unsigned long r
 // ------------------------------------------------------------------------------------------------
 struct StreamShell {
     int device = -1;
+    bool ring_on_host = false; // d_in / d_in_alt are pinned host memory (small-chunk streams), not device memory
     hipStream_t st = nullptr;
     void *d_in = nullptr, *d_in_alt = nullptr, *d_out = nullptr;
     size_t in_bytes = 0, alt_bytes = 0, out_bytes = 0;
@@ -217,8 +232,8 @@ static const size_t kPoolMax = 8, kPoolBytes = (size_t)1 << 30;
 
 static void shell_free(StreamShell &sh)
 {
-    if (sh.d_in) (void)hipFree(sh.d_in);
-    if (sh.d_in_alt) (void)hipFree(sh.d_in_alt);
+    if (sh.d_in) (void)(sh.ring_on_host ? hipHostFree(sh.d_in) : hipFree(sh.d_in));
+    if (sh.d_in_alt) (void)(sh.ring_on_host ? hipHostFree(sh.d_in_alt) : hipFree(sh.d_in_alt));
     if (sh.d_out) (void)hipFree(sh.d_out);
     if (sh.d_clips) (void)hipFree(sh.d_clips);
     if (sh.h_in) (void)hipHostFree(sh.h_in);
@@ -424,6 +439,56 @@ static uint64_t vr_k_limit(const hipsoxr_stream *s, bool ended)
 }
 
 // Move the still-needed tail of the staged input to the front of the alternate buffer.
+static void ring_free(hipsoxr_stream *s, void *p)
+{
+    if (!p) return;
+    if (s->ring_on_host) (void)hipHostFree(p); else (void)hipFree(p);
+}
+
+// Host ring: make room for `ilen` more frames (drop what no output needs any more, grow by powers of two).
+// Nothing may be reading the ring meanwhile: the stream is drained first (it is idle in synchronous mode).
+static const char *host_ring_reserve(hipsoxr_stream *s, size_t ilen)
+{
+    const size_t frame = (size_t)s->ch * esz(s);
+    if (s->d_in && s->in_fill + ilen <= s->in_cap) return nullptr;
+    HIP_TRY(stream_wait(s));
+    const int64_t n0 = first_needed(s);
+    const int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base), s->in_base + (int64_t)s->in_fill);
+    const size_t drop = (size_t)(keep_from - s->in_base), keep = s->in_fill - drop;
+    size_t cap = std::max<size_t>(s->in_cap, 1024);
+    while (cap < keep + 8 * ilen) cap <<= 1; // compaction every eighth call
+    if (cap != s->in_cap || !s->d_in) {
+        void *nb = nullptr;
+        if (hipHostMalloc(&nb, cap * frame, hipHostMallocDefault) != hipSuccess) return "hipHostMalloc failed";
+        if (keep) std::memcpy(nb, (char *)s->d_in + drop * frame, keep * frame);
+        if (s->d_in) (void)hipHostFree(s->d_in);
+        s->d_in = nb; s->in_cap = cap;
+    } else if (keep && drop) {
+        std::memmove(s->d_in, (char *)s->d_in + drop * frame, keep * frame);
+    }
+    s->in_base = keep_from;
+    s->in_fill = keep;
+    return nullptr;
+}
+
+// A large chunk arrives on a host-ring stream: move what is pending to device memory and stay there.
+static const char *host_ring_to_device(hipsoxr_stream *s)
+{
+    const size_t frame = (size_t)s->ch * esz(s);
+    HIP_TRY(stream_wait(s));
+    void *host = s->d_in;
+    const size_t fill = s->in_fill, cap = std::max<size_t>(s->in_cap, 1024);
+    void *dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, cap * frame));
+    if (fill) HIP_TRY(hipMemcpy(dev, host, fill * frame, hipMemcpyHostToDevice));
+    if (host) (void)hipHostFree(host);
+    if (s->d_in_alt) (void)hipHostFree(s->d_in_alt);
+    s->ring_on_host = false;
+    s->d_in = dev; s->in_cap = cap;
+    s->d_in_alt = nullptr; s->alt_cap = 0;
+    return nullptr;
+}
+
 static const char *stream_compact(hipsoxr_stream *s, size_t want_cap)
 {
     const int64_t n0 = first_needed(s);
@@ -457,6 +522,25 @@ static const char *stream_compact(hipsoxr_stream *s, size_t want_cap)
 
 static const char *stream_append(hipsoxr_stream *s, const void *in, size_t ilen)
 {
+    const size_t bytes_in = ilen * s->ch * esz(s);
+    if (!s->split && !s->ring_on_host && !s->d_in && s->n_in_total == 0 && bytes_in <= kHostRingChunk &&
+        !switches().no_host_ring) {
+        // first chunk of a stream that owns no device ring yet, and a small one: ring in pinned host memory
+        // (a stream that inherited a device ring from the pool keeps it; finished streams hand their ring,
+        // of either kind, back to the pool)
+        s->ring_on_host = true;
+    }
+    if (s->ring_on_host) {
+        if (bytes_in > kHostRingChunk) {
+            if (const char *e = host_ring_to_device(s)) return e;
+        } else {
+            if (const char *e = host_ring_reserve(s, ilen)) return e;
+            std::memcpy((char *)s->d_in + s->in_fill * s->ch * esz(s), in, bytes_in);
+            s->in_fill += ilen;
+            s->n_in_total += ilen;
+            return nullptr;
+        }
+    }
     if (s->in_fill + ilen > s->in_cap) {
         // retire consumed input first; grow (power of two) only if that is not enough
         const int64_t n0 = first_needed(s);
@@ -601,6 +685,95 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     return nullptr;
 }
 
+// Deferred output.  The reference's contract lets a call return any number of frames, including none
+// (README.md:77-78: "[0, 0, 0, 186, 186, 166, ...]"; CSoxr::process returns whatever soxr_process produced,
+// src/soxr_ext.cpp:162-187): libsoxr itself buffers internally.  With HIPSOXR_DEFER a call
+//   1. hands out what the PREVIOUS call's launch produced (complete by now: one event query),
+//   2. copies its input to the device ring (pinned bounce buffer, asynchronous copy),
+//   3. launches the kernel for everything computable now, writing into the other pinned result buffer,
+// and returns without waiting for 2 and 3.  The concatenated output is bit-identical to the synchronous
+// mode; only the call on which a frame appears moves (one call later), and delay() counts it as pending.
+// Constant-rate interleaved streams with small chunks (results <= 1 MiB); anything else runs synchronously.
+static const char *stream_process_deferred(hipsoxr_stream *s, const void *in, size_t ilen, void *out, size_t olen,
+                                           size_t *odone)
+{
+    const Plan &p = s->plan->p;
+    const size_t frame = (size_t)s->ch * esz(s);
+    size_t got = 0;
+    // 1. the previous launch's result
+    if (s->pend_off < s->pend_n) {
+        if (s->ev_res[s->pend_slot]) HIP_TRY(hipEventSynchronize(s->ev_res[s->pend_slot]));
+        else HIP_TRY(hipStreamSynchronize(s->st));
+        const size_t take = std::min(s->pend_n - s->pend_off, olen);
+        std::memcpy(out, (char *)s->h_res[s->pend_slot] + s->pend_off * frame, take * frame);
+        s->pend_off += take;
+        got = take;
+    }
+    // 2. this call's input.  Device ring: through one of two pinned bounce buffers, alternating; the copy
+    //    issued from this one two calls ago may still sit in the stream behind a long kernel (no launch, hence
+    //    no completion observed, while the caller drains a backlog): its own event says when it is free.
+    if (in && ilen) {
+        if (s->ended) return "Input after last input";
+        const int b = (int)(s->calls & 1);
+        const size_t bytes = ilen * frame;
+        if (s->ring_on_host || (!s->d_in && s->n_in_total == 0 && bytes <= kHostRingChunk && !switches().no_host_ring)) {
+            if (const char *e = stream_append(s, in, ilen)) return e; // host ring: a memcpy, nothing in flight to protect
+        } else if (bytes <= kPinnedMax && (!s->ev_src[b] || hipEventSynchronize(s->ev_src[b]) == hipSuccess) &&
+                   !pinned_ensure(&s->h_src[b], &s->h_src_bytes[b], bytes)) {
+            if (s->in_fill + ilen > s->in_cap) { // retire / grow the ring exactly as stream_append does
+                void *keep_h = s->h_in; size_t keep_b = s->h_in_bytes;
+                s->h_in = s->h_src[b]; s->h_in_bytes = s->h_src_bytes[b];
+                const char *e = stream_append(s, in, ilen);
+                s->h_src[b] = s->h_in; s->h_src_bytes[b] = s->h_in_bytes;
+                s->h_in = keep_h; s->h_in_bytes = keep_b;
+                if (e) return e;
+            } else {
+                std::memcpy(s->h_src[b], in, bytes);
+                HIP_TRY(hipMemcpyAsync((char *)s->d_in + s->in_fill * frame, s->h_src[b], bytes, hipMemcpyHostToDevice, s->st));
+                s->in_fill += ilen;
+                s->n_in_total += ilen;
+            }
+            if (!s->ev_src[b] && hipEventCreateWithFlags(&s->ev_src[b], hipEventDisableTiming) != hipSuccess) s->ev_src[b] = nullptr;
+            if (s->ev_src[b]) HIP_TRY(hipEventRecord(s->ev_src[b], s->st));
+            else HIP_TRY(hipStreamSynchronize(s->st));
+        } else {
+            if (const char *e = stream_append(s, in, ilen)) return e;
+            HIP_TRY(stream_wait(s)); // large chunk straight from the caller's (borrowed) buffer
+        }
+        ++s->calls;
+    }
+    // 3. launch for what is computable now, once the previous result is fully handed out
+    if (s->pend_off == s->pend_n) {
+        s->pend_n = s->pend_off = 0;
+        const uint64_t k_end = k_avail(p, s->n_in_total);
+        size_t n = k_end > s->k_done ? (size_t)(k_end - s->k_done) : 0;
+        if (n * frame > kPinnedMax) n = kPinnedMax / frame;
+        const int slot = s->pend_slot ^ 1;
+        if (n && !pinned_ensure(&s->h_res[slot], &s->h_res_bytes[slot], n * frame)) {
+            if (!s->ev_res[slot] && hipEventCreateWithFlags(&s->ev_res[slot], hipEventDisableTiming) != hipSuccess)
+                s->ev_res[slot] = nullptr;
+            hipsoxr_job_t j;
+            std::memset(&j, 0, sizeof j);
+            j.in = s->d_in; j.out = s->h_res[slot]; j.elem = s->elem;
+            j.kernel = HIPSOXR_KERNEL_EXACT;
+            j.n_clips = 1; j.n_channels = s->ch;
+            j.in_frame_stride = s->ch; j.in_chan_stride = 1;
+            j.out_frame_stride = s->ch; j.out_chan_stride = 1;
+            j.in_abs0 = s->in_base; j.in_frames = (int64_t)s->in_fill;
+            j.out_k0 = (int64_t)s->k_done; j.out_frames = (int64_t)n;
+            j.clip_counter = s->d_clips;
+            j.dither = (s->elem == HIPSOXR_I16 && !(s->flags & HIPSOXR_NO_DITHER)) ? 1u : 0u;
+            j.dither_seed = s->dither_seed;
+            if (const char *e = launch_job(&s->plan->p, j, s->st)) return e;
+            if (s->ev_res[slot]) HIP_TRY(hipEventRecord(s->ev_res[slot], s->st));
+            s->k_done += n;
+            s->pend_n = n; s->pend_off = 0; s->pend_slot = slot;
+        }
+    }
+    *odone = got;
+    return nullptr;
+}
+
 static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr_datatype_t io,
                               unsigned long flags, hipsoxr_stream **out)
 {
@@ -612,6 +785,7 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
     if (!s) return "out of memory";
     s->plan = plan; s->own_plan = own; s->ch = ch;
     s->elem = (int)io & 3; s->split = ((int)io & 4) != 0; s->flags = flags;
+    s->defer = (flags & HIPSOXR_DEFER) && !(flags & HIPSOXR_VR) && !s->split;
     if (flags & HIPSOXR_VR) {
         const double io0 = plan->p.in_rate / plan->p.out_rate;
         if (!(io0 > 9.5367431640625e-07) || !(io0 < 1048576.)) { delete s; return "io ratio out of range for variable rate"; }
@@ -632,11 +806,17 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
                     const size_t frame = (size_t)ch * esz(s);
                     s->st = sh.st; s->d_clips = sh.d_clips; s->ev = sh.ev;
                     s->h_in = sh.h_in; s->h_in_bytes = sh.h_in_bytes; s->h_out = sh.h_out; s->h_out_bytes = sh.h_out_bytes;
+                    s->ring_on_host = sh.ring_on_host && !s->split;
+                    if (sh.ring_on_host && s->split) { // (split layouts keep the ring on the device)
+                        if (sh.d_in) (void)hipHostFree(sh.d_in);
+                        if (sh.d_in_alt) (void)hipHostFree(sh.d_in_alt);
+                        sh.d_in = sh.d_in_alt = nullptr; sh.in_bytes = sh.alt_bytes = 0;
+                    }
                     s->d_in = sh.d_in; s->in_cap = sh.in_bytes / frame;
                     s->d_in_alt = sh.d_in_alt; s->alt_cap = sh.alt_bytes / frame;
                     s->d_out = sh.d_out; s->out_cap = sh.out_bytes / frame;
-                    if (!s->in_cap && s->d_in) { (void)hipFree(s->d_in); s->d_in = nullptr; }
-                    if (!s->alt_cap && s->d_in_alt) { (void)hipFree(s->d_in_alt); s->d_in_alt = nullptr; }
+                    if (!s->in_cap && s->d_in) { ring_free(s, s->d_in); s->d_in = nullptr; }
+                    if (!s->alt_cap && s->d_in_alt) { ring_free(s, s->d_in_alt); s->d_in_alt = nullptr; }
                     if (!s->out_cap && s->d_out) { (void)hipFree(s->d_out); s->d_out = nullptr; }
                     break;
                 }
@@ -696,8 +876,15 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
     if (!s) return;
     DeviceGuard guard(s->device);
     if (s->st) (void)hipStreamSynchronize(s->st);
+    for (int i = 0; i < 2; ++i) {
+        if (s->h_res[i]) (void)hipHostFree(s->h_res[i]);
+        if (s->h_src[i]) (void)hipHostFree(s->h_src[i]);
+        if (s->ev_res[i]) (void)hipEventDestroy(s->ev_res[i]);
+        if (s->ev_src[i]) (void)hipEventDestroy(s->ev_src[i]);
+    }
     StreamShell sh;
     sh.device = s->device; // where the resources were created, not whatever device is current now
+    sh.ring_on_host = s->ring_on_host;
     const size_t frame = (size_t)s->ch * esz(s);
     sh.st = s->st; sh.d_clips = s->d_clips; sh.ev = s->ev;
     sh.h_in = s->h_in; sh.h_in_bytes = s->h_in_bytes; sh.h_out = s->h_out; sh.h_out_bytes = s->h_out_bytes;
@@ -722,6 +909,23 @@ hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size
     if (!s || !odone) return "null argument";
     DeviceGuard guard(s->device);
     *odone = 0;
+    if (s->defer && out && olen) {
+        if (in != nullptr) return stream_process_deferred(s, in, ilen, out, olen, odone);
+        // end of input: what is still pending first, then the synchronous flush for the rest
+        size_t got = 0;
+        if (const char *e = stream_process_deferred(s, s /* non-null, no input */, 0, out, olen, &got)) return e;
+        if (s->pend_off < s->pend_n || got == olen) { *odone = got; return nullptr; }
+        // (the deferred step may have launched once more: hand that out too before flushing)
+        size_t got2 = 0;
+        if (const char *e = stream_process_deferred(s, s, 0, (char *)out + got * s->ch * esz(s), olen - got, &got2)) return e;
+        got += got2;
+        if (s->pend_off < s->pend_n || got == olen) { *odone = got; return nullptr; }
+        s->ended = true;
+        size_t tail = 0;
+        if (const char *e = stream_emit(s, (char *)out + got * s->ch * esz(s), olen - got, &tail)) return e;
+        *odone = got + tail;
+        return nullptr;
+    }
     if (in == nullptr) {
         s->ended = true; // end of input: flush
     } else if (ilen > 0) {
@@ -746,7 +950,9 @@ hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
 {
     if (!s) return "null argument";
     DeviceGuard guard(s->device);
+    if (s->st) (void)hipStreamSynchronize(s->st);
     s->ended = false; s->n_in_total = 0; s->k_done = 0; s->in_base = 0; s->in_fill = 0;
+    s->pend_n = s->pend_off = 0;
     if (s->vr.on) { // fresh signal at the ratio last requested
         s->vr.k_s = 0; s->vr.t_s = 0; s->vr.s0 = s->vr.s1; s->vr.delta = 0; s->vr.n_slew = 0;
     }
@@ -764,7 +970,7 @@ double hipsoxr_stream_delay(hipsoxr_stream_t *s)
         const double two64 = 18446744073709551616.;
         d = ((double)s->n_in_total - (double)s->vr.pos(s->k_done) / two64) / ((double)s->vr.step(s->k_done) / two64);
     } else {
-        d = (double)s->n_in_total * (double)p.L / (double)p.M - (double)s->k_done;
+        d = (double)s->n_in_total * (double)p.L / (double)p.M - (double)(s->k_done - (uint64_t)(s->pend_n - s->pend_off));
     }
     return d > 0. ? d : 0.;
 }

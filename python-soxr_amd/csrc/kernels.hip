@@ -52,7 +52,7 @@ const Switches &switches()
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_small_3pass = on("HIPSOXR_FFT_SMALL_3PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
         w.no_planes = on("HIPSOXR_NO_PLANES");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
         w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
@@ -238,6 +238,9 @@ __global__ void __launch_bounds__(256) k_wave_dot(GatherArgs a, const Real *__re
 // per tap.  Interval and residual come from exact integer arithmetic on (k*M) mod L, so the result
 // is again a pure function of the absolute output index (chunk / launch invariant) and equals
 // oracle_interp_port_* bit for bit.
+template <typename Real, int N> struct VecN;
+template <> struct VecN<float, 4> { typedef float4 type; };
+template <> struct VecN<double, 2> { typedef double2 type; };
 template <typename Real> struct Vec4;
 template <> struct Vec4<float> { typedef float4 type; };
 template <> struct Vec4<double> { typedef double4 type; };
@@ -545,16 +548,21 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
 // ---------------------------------------------------------------------------------------------
 // k_gather's cost on a small launch is pure latency: every lane walks T taps, each a pair of L2 loads
 // feeding a dependent FMA (81 us for T = 736, whatever the chunk size).  Here a workgroup of 256
-// threads takes NO consecutive outputs: ALL threads first stage the NO coefficient rows and input
-// windows into LDS (every load of the workgroup in flight at once: one round trip, not T), then
-// 2*NO lanes run the canonical half-chains out of LDS (lane o: left half of output o, lane NO+o:
-// right half), and the two halves are added.  Same arithmetic, bit for bit.
+// threads takes NO consecutive outputs: ALL threads first stage the operands into LDS — the NO
+// coefficient rows, and ONCE the input span the NO windows share (consecutive windows are shifted by
+// M/L samples: 8 windows of 736 taps are 756 distinct samples, not 5888) — with every load of the
+// workgroup in flight at once (one round trip for T <= 768, not T); then 2*NO lanes run the canonical
+// half-chains out of LDS (lane o: left half of output o, lane NO+o: right half), four taps per
+// 16-byte coefficient read, and the two halves are added.  Same arithmetic, bit for bit.
+// The input may be pinned host memory (small-chunk streams keep their ring there, engine.cpp): the span
+// is then the only thing that crosses PCIe, once.
 // MODE 0: exact bank (phase-major [L][T]); 1: interpolated-phase plan; 2: variable rate.  In the
 // interpolated modes the staging thread evaluates the tap's cubic (the canonical Horner FMAs).
 struct ChainArgs {
     InterpArgs ia;           // .g: job geometry; .tab/.P/...: interpolated plans
     const void *phase_major; // exact plans: [L][T] Real
     int32_t NO;              // outputs per workgroup (power of two, <= 32)
+    int32_t span_cap;        // LDS room for the shared input span, in samples
 };
 
 template <typename IO, typename Real, int MODE>
@@ -564,11 +572,12 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
     const InterpArgs &ia = ca.ia;
     const GatherArgs &a = ia.g;
     constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
-    const int32_t T = a.T, H = T / 2, NO = ca.NO, S = NO + 1; // S: row stride (odd: conflict-free transposes)
-    Real *cs = reinterpret_cast<Real *>(smem_raw); // [T][S] coefficients
-    Real *xs = cs + (size_t)T * S;                 // [T][S] samples
-    int64_t *n0s = reinterpret_cast<int64_t *>(xs + (size_t)T * S); // [NO] first-tap input index (relative to in[0])
-    uint64_t *aux = reinterpret_cast<uint64_t *>(n0s + NO);         // [NO] phase (MODE 0) or iv<<32 | xq (MODE 1, 2)
+    constexpr int V = 16 / (int)sizeof(Real);      // taps per 16-byte coefficient read: 4 (f32) or 2 (f64)
+    const int32_t T = a.T, H = T / 2, NO = ca.NO, RS = T + V; // RS: row stride (rows 16-byte aligned, banks rotate by V per row)
+    Real *cs = reinterpret_cast<Real *>(smem_raw); // [NO][RS] coefficients, row-major
+    Real *xs = cs + (size_t)NO * RS;               // [span_cap] the input span shared by the NO windows
+    int64_t *n0s = reinterpret_cast<int64_t *>(xs + ((ca.span_cap + 3) & ~3)); // [NO] first-tap input index (relative to in[0])
+    uint64_t *aux = reinterpret_cast<uint64_t *>(n0s + NO);                    // [NO] phase (MODE 0) or iv<<32 | xq (MODE 1, 2)
 
     const uint32_t ch = blockIdx.y % a.n_channels, clip = blockIdx.y / a.n_channels;
     const int64_t o_base = (int64_t)blockIdx.x * NO;
@@ -588,35 +597,44 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
         }
     }
     __syncthreads();
-    // stage: element e = (output o, tap j); a wave covers 64 consecutive taps of one output.
-    // Eight elements per trip, loads first: 16 global loads in flight per thread.
-    const int n_el = NO * T;
-    for (int e0 = threadIdx.x; e0 < n_el; e0 += 256 * 8) {
-        Real xv[8], cv[8];
-        V4 pv[8];
+    // ---- stage.  The input span first (its loads are the slow ones when the ring lives in host memory) ...
+    const int64_t nfirst = n0s[0];
+    const int32_t span = (int32_t)(n0s[NO - 1] - nfirst) + T; // windows are ordered: n0 is non-decreasing in o
+    for (int sidx = threadIdx.x; sidx < span; sidx += 256) {
+        const int64_t l = nfirst + sidx;
+        xs[sidx] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+    }
+    // ... then the coefficient rows.  Wave w takes rows w, w+4, ...; a lane takes taps lane, lane+64, ... of a
+    // row (no run-time division in the index arithmetic: that alone was a quarter of this kernel).  EPT taps
+    // per trip, loads first: for T <= 768 that is ONE round trip per row, two rows per wave at NO = 8.
+    constexpr int EPT = MODE == 0 ? 12 : 8;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int o = wave; o < NO; o += 4) {
+        const uint64_t au = aux[o];
+        const Real *crow = MODE == 0 ? (const Real *)ca.phase_major + au * (uint64_t)T : nullptr;
+        const V4 *prow = MODE == 0 ? nullptr : (const V4 *)ia.tab + (size_t)(au >> 32) * T;
+        for (int j0 = lane; j0 < T; j0 += 64 * EPT) {
+            Real cv[EPT];
+            V4 pv[MODE == 0 ? 1 : EPT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 256;
-            xv[u] = 0; cv[u] = 0;
-            if (e < n_el) {
-                const int o = e / T, j = e - o * T;
-                const int64_t l = n0s[o] + j;
-                if (l >= 0 && l < a.in_frames) xv[u] = (Real)xin[l * a.ifs];
-                if (MODE == 0) cv[u] = ((const Real *)ca.phase_major)[aux[o] * (uint64_t)T + j];
-                else pv[u] = ((const V4 *)ia.tab)[(size_t)(aux[o] >> 32) * T + j];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 256;
-            if (e < n_el) {
-                const int o = e / T, j = e - o * T;
-                if (MODE != 0) {
-                    const Real xx = (Real)(uint32_t)aux[o] * (Real)(1. / (double)(1ULL << SH));
-                    cv[u] = fma_r(fma_r(fma_r(pv[u].w, xx, pv[u].z), xx, pv[u].y), xx, pv[u].x);
+            for (int u = 0; u < EPT; ++u) {
+                const int j = j0 + u * 64;
+                cv[u] = 0;
+                if (j < T) {
+                    if (MODE == 0) cv[u] = crow[j];
+                    else pv[u] = prow[j];
                 }
-                xs[(size_t)j * S + o] = xv[u];
-                cs[(size_t)j * S + o] = cv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int j = j0 + u * 64;
+                if (j < T) {
+                    if (MODE != 0) {
+                        const Real xx = (Real)(uint32_t)au * (Real)(1. / (double)(1ULL << SH));
+                        cv[u] = fma_r(fma_r(fma_r(pv[u].w, xx, pv[u].z), xx, pv[u].y), xx, pv[u].x);
+                    }
+                    cs[(size_t)o * RS + j] = cv[u];
+                }
             }
         }
     }
@@ -624,11 +642,26 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
     if ((int)threadIdx.x < 2 * NO) { // first wave: the half-chains
         const int o = threadIdx.x < NO ? threadIdx.x : threadIdx.x - NO;
         const bool right = (int)threadIdx.x >= NO;
-        const Real *cp = cs + (right ? (size_t)(T - 1) * S : 0) + o, *xp = xs + (right ? (size_t)(T - 1) * S : 0) + o;
-        const int step = right ? -S : S;
+        const Real *row = cs + (size_t)o * RS;
+        const Real *xw = xs + (n0s[o] - nfirst); // this output's window inside the shared span
         Real acc = 0;
-#pragma unroll 8
-        for (int i = 0; i < H; ++i) acc = fma_r(cp[i * step], xp[i * step], acc);
+        if (!right) {
+#pragma unroll 2
+            for (int i = 0; i < H; i += V) { // taps i .. i+V-1, ascending
+                Real c[V];
+                *reinterpret_cast<typename VecN<Real, V>::type *>(c) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i);
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc = fma_r(c[v], xw[i + v], acc);
+            }
+        } else {
+#pragma unroll 2
+            for (int i = T - V; i >= H; i -= V) { // taps i+V-1 .. i, descending
+                Real c[V];
+                *reinterpret_cast<typename VecN<Real, V>::type *>(c) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i);
+#pragma unroll
+                for (int v = V - 1; v >= 0; --v) acc = fma_r(c[v], xw[i + v], acc);
+            }
+        }
         const Real accR = __shfl(acc, (int)threadIdx.x + NO, 64); // NO <= 32: partner in the same wave
         const int64_t idx = o_base + o;
         if (!right && idx < a.out_frames) {
@@ -1582,12 +1615,21 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             // few outputs per workgroup: the staging loop is then two or three trips of 16 loads per
             // thread (its latency is the kernel's latency), and there are enough workgroups anyway
             int NO = nf <= 2048 ? 8 : 32;
-            while (NO > 2 && (size_t)2 * p->T * (NO + 1) * sizeof(Real) + (size_t)NO * 16 > 150 * 1024) NO /= 2;
-            const size_t lds = (size_t)2 * p->T * (NO + 1) * sizeof(Real) + (size_t)NO * 16;
-            if (lds <= 150 * 1024) {
+            // LDS: NO coefficient rows of T + V words, the shared input span (T + what NO-1 window shifts of at
+            // most ceil(M/L) + 1 samples add; variable rate: the plan's ratio is the largest step), bookkeeping
+            const int64_t shift = (p->M + p->L - 1) / p->L + 2;
+            auto chain_lds = [&](int no, int32_t *span_cap) {
+                const int64_t sc = (int64_t)p->T + (int64_t)no * shift + 4;
+                *span_cap = (int32_t)sc;
+                return (size_t)no * (p->T + 16 / sizeof(Real)) * sizeof(Real) + (size_t)((sc + 3) & ~3) * sizeof(Real) + (size_t)no * 16;
+            };
+            int32_t span_cap = 0;
+            while (NO > 2 && chain_lds(NO, &span_cap) > 150 * 1024) NO /= 2;
+            const size_t lds = chain_lds(NO, &span_cap);
+            if (lds <= 150 * 1024 && shift < (1 << 20)) {
                 ChainArgs ca;
                 std::memset(&ca, 0, sizeof ca);
-                ca.ia.g = a; ca.NO = NO;
+                ca.ia.g = a; ca.NO = NO; ca.span_cap = span_cap;
                 const char *err = nullptr;
                 void (*ck)(ChainArgs) = nullptr;
                 if (p->phases) {

@@ -153,3 +153,54 @@ def test_stream_protocol(soxr):
     assert np.array_equal(full, soxr.resample(x, 44100, 16000, quality="VHQ"))
     with pytest.raises(RuntimeError):
         rs.set_io_ratio(44100, 22050)                           # needs vr=True (tests/test_gpu_vr.py)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16, np.int32])
+@pytest.mark.parametrize("chunk", [17, 441, 4410, 50000])
+def test_deferred_stream_equals_oneshot(soxr, dtype, chunk):
+    """Deferred output (extension): every call returns the previous call's frames; the concatenation is
+    bit-identical to the one-shot result and to the synchronous stream, delay() accounts for what is
+    pending, and clear() starts over."""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((44100, 2))
+    x = (x * 5000).astype(dtype) if np.issubdtype(dtype, np.integer) else (x * 0.25).astype(dtype)
+    want = soxr.resample(x, 44100, 16000, quality="HQ")
+    rs = soxr.ResampleStream(44100, 16000, 2, dtype=dtype, quality="HQ", deferred=True)
+    for rep in range(2):
+        parts, fed, got = [], 0, 0
+        for a in range(0, len(x), chunk):
+            y = rs.resample_chunk(x[a:a + chunk], last=(a + chunk >= len(x)))
+            fed += len(x[a:a + chunk]); got += len(y)
+            parts.append(y)
+            if a + chunk < len(x):
+                assert abs(rs.delay() - (fed * 16000 / 44100 - got)) < 1e-6
+        out = np.concatenate(parts)
+        assert out.shape == want.shape and np.array_equal(out, want)
+        if chunk <= 4410:
+            assert len(parts[0]) == 0      # nothing can come back from the first call
+        rs.clear()
+
+
+def test_deferred_stream_small_output_buffer(soxr):
+    """The C entry with an output buffer smaller than what is pending: frames are handed out over several
+    calls, nothing is lost or reordered."""
+    import ctypes as C
+    from soxr_amd import _native as nat
+    rng = np.random.default_rng(32)
+    x = (rng.standard_normal(20000) * 0.25).astype(np.float32)
+    want = soxr.resample(x, 48000, 44100, quality="HQ")
+    h = C.c_void_p()
+    nat.check(nat.lib.hipsoxr_stream_create(48000.0, 44100.0, 1, nat.FLOAT32_I, nat.HQ, nat.DEFER, C.byref(h)))
+    out, done = np.zeros(len(want) + 100, np.float32), C.c_size_t()
+    pos = 0
+    for a in range(0, len(x), 1000):
+        c = np.ascontiguousarray(x[a:a + 1000])
+        nat.check(nat.lib.hipsoxr_stream_process(h, c.ctypes.data, len(c), out.ctypes.data + 4 * pos, 300, C.byref(done)))
+        pos += done.value
+    while True:
+        nat.check(nat.lib.hipsoxr_stream_process(h, None, 0, out.ctypes.data + 4 * pos, 300, C.byref(done)))
+        if done.value == 0:
+            break
+        pos += done.value
+    nat.lib.hipsoxr_stream_delete(h)
+    assert pos == len(want) and np.array_equal(out[:pos], want)
