@@ -33,17 +33,17 @@ for p in (ROOT, os.path.join(ROOT, "python-soxr_amd")):
         sys.path.insert(0, p)
 
 IN_RATE, OUT_RATE, QUALITY = 48000, 44100, "VHQ"
-KERNEL_NAMES = {0: "k_fft_pair (AUTO: frequency-domain engine, paired-block kernel, for large float32 device jobs)",
+KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, second-generation paired-block kernel, for large float32 device jobs)",
                 1: "k_gather<float,float>", 2: "k_tile_mfma_p<float>", 3: "k_tile<float,float,16,true>",
-                4: "k_tile_mfma_p<float>", 5: "k_fft_pair", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
+                4: "k_tile_mfma_p<float>", 5: "k_fft_pair2<.., float>", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
 # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 +
-# WRITE_SIZE, see profiles/r01f_traffic.json); bench.py cannot collect counters itself.
-TRAFFIC_BYTES = {("configs1", 0): 25155379, ("configs1", 5): 25155379,
-                 ("batch_shard", 0): 518675865, ("batch_shard", 5): 518675865}  # profiles/r01f_traffic.json
-# VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/r01f_rocprofv3_summary.txt): the other
+# WRITE_SIZE, see profiles/r02_traffic.json); bench.py cannot collect counters itself.
+TRAFFIC_BYTES = {("configs1", 0): 23304192, ("configs1", 5): 23304192,
+                 ("batch_shard", 0): 480613990, ("batch_shard", 5): 480613990}  # profiles/r02_traffic.json
+# VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/r02_rocprofv3_summary.txt): the other
 # resource the frequency-domain kernel is limited by.  An fp32 wave-instruction occupies a SIMD for
 # 2 cycles (SIMD-32, wave64); 256 CUs x 4 SIMDs at 2.4 GHz.
-VALU_INSTS = {("configs1", 0): 3820144, ("configs1", 5): 3820144, ("batch_shard", 0): 69569280, ("batch_shard", 5): 69569280}
+VALU_INSTS = {("configs1", 0): 3272674, ("configs1", 5): 3272674, ("batch_shard", 0): 61341184, ("batch_shard", 5): 61341184}
 VALU_SLOTS_PER_S = 256 * 4 * 2.4e9 / 2
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
@@ -251,8 +251,21 @@ def configs4_stream(seconds=20):
                 rs.resample_chunk(x[a:a + chunk], last=(a + chunk >= len(x)))
                 n_calls += 1
             dt = time.perf_counter() - t0
-            out[f"{'vr' if vr else 'cr_deferred' if deferred else 'cr'}_chunk{chunk}"] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls,
-                                                            "Msamples_per_s": len(x) / dt / 1e6}
+            key = f"{'vr' if vr else 'cr_deferred' if deferred else 'cr'}_chunk{chunk}"
+            out[key] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls, "Msamples_per_s": len(x) / dt / 1e6}
+            if chunk == 441 and not vr:
+                # a real-time caller feeds a chunk every 10 ms: time spent INSIDE the call when calls are spaced
+                # (here 300 us apart), i.e. the latency the caller sees rather than the back-to-back rate
+                rs.clear()
+                inside = 0.0
+                for a in range(0, 441 * 300, chunk):
+                    t1 = time.perf_counter()
+                    rs.resample_chunk(x[a:a + chunk])
+                    t2 = time.perf_counter()
+                    inside += t2 - t1
+                    while time.perf_counter() - t2 < 300e-6:
+                        pass
+                out[key]["us_in_call_when_spaced"] = inside / 300 * 1e6
     return out
 
 

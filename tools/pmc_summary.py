@@ -33,12 +33,11 @@ def main(paths):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         try:
             for r in c.execute("select kernel_name, counter_name, value, grid_size, workgroup_size from counters_collection"):
-                agg[(short(r[0]), r[3], r[4])][r[1]].append(r[2])
+                if "hipsoxr" in r[0]:
+                    agg[(short(r[0]), r[3], r[4])][r[1]].append(r[2])
         except sqlite3.Error:
             pass
         for k, v in agg.items():
-            if "hipsoxr" not in k[0]:
-                continue
             print("  ", k)
             for n, x in sorted(v.items()):
                 print("      %-28s %16.1f  (n=%d)" % (n, sum(x) / len(x), len(x)))
