@@ -1,4 +1,5 @@
-// kernels.hip — the soxr_process hot path on CDNA4 (gfx950).  Hand-written HIP, no MFMA.
+// kernels.hip — the soxr_process hot path on CDNA4 (gfx950): the EXACT (canonical-order) engine.
+// Hand-written HIP; the f32 throughput kernels run the canonical fma chains on the f32-input matrix pipe.
 //
 // Replaces the inner product libsoxr runs inside soxr_process (reference call sites
 // src/soxr_ext.cpp:163-166, :245-248, :328-331):
@@ -16,22 +17,28 @@
 // reference tests test_divide_match / test_stream_length).  Zero-padded table entries contribute
 // fma(0, x, acc) == acc exactly for finite x.
 //
-// Two kernels:
-//   k_gather  one lane per output sample; coefficients gathered from the tap-major bank
-//             [T][Lpad] (lanes of a wave read neighbouring phases of one tap row), input read
-//             straight from global memory (a wave touches ~64*M/L consecutive samples per tap).
-//             Handles every ratio / layout / length; used for small jobs (streaming chunks).
-//   k_tile    throughput kernel.  A workgroup stages the input of 64 consecutive periods
-//             (period = L outputs <- M inputs) of one channel in LDS (coalesced read, row stride
-//             padded so that lane-per-period reads are bank-conflict free).  Each wavefront owns a
-//             tile of RT consecutive output phases; ALL 64 LANES SHARE THE TILE'S COEFFICIENTS,
-//             which therefore travel on the scalar path (s_load from the constant address space
-//             into SGPRs, used directly as v_fmac operands) — the inner loop is one ds_read_b128
-//             per 4*RT FMAs and no cross-lane reduction at all.
-//
-// Why not the "one wavefront per output + __shfl reduction" shape: 6 DPP/shuffle steps plus two
-// LDS reads per ~4.6 FMAs caps VALU utilisation near 30 %; a 1-D FIR at 296 taps/output is
-// VALU-bound on MI355X (592 flop per 8.35 B), so FMA issue rate is what matters.
+// Kernels (all bit-identical to each other and to the oracle; DESIGN.md §5.1 has the table):
+//   k_gather        one lane per output sample; coefficients gathered from the tap-major bank
+//                   [T][Lpad], input read straight from global memory.  Universal fallback: every
+//                   ratio / layout / length.
+//   k_chain         small launches (streaming chunks, < 4096 outputs): a workgroup stages the coefficient
+//                   rows and the input span its outputs share into LDS in one round trip, then
+//                   2*NO lanes run the two canonical half-chains.  Exact, interpolated and variable-rate plans.
+//   k_interp(_tile) interpolated-phase plans (arbitrary ratios) and variable rate: per tap a cubic in
+//                   the fractional position (Horner FMAs), small / large launches.
+//   k_tile          period-tiled VALU kernel: 64 periods of one column staged in LDS, a wave = 16
+//                   output phases whose coefficients travel on the scalar path (s_load -> SGPR operands
+//                   of v_pk_fma_f32).  The f64 engine (float64 / int32 I/O); f32 A/B reference.
+//   k_tile_mfma(_p) the same tiling on v_mfma_f32_16x16x4_f32 — on gfx950 the f32-input MFMA IS the
+//                   k-ordered fmaf chain of the canonical arithmetic, bit for bit, at the vector ALU's
+//                   peak rate, with both operands in VGPRs (prefetchable arbitrarily deep; SGPR-fed VALU
+//                   FMAs top out at 47-61 TF here).  _p: k-de-interleaved LDS planes, 4-wave workgroups,
+//                   software-pipelined half-chains.  The f32 engine for float32 / int16 I/O.
+//   k_wave_dot      reference point only: the shape BASELINE.json's north star describes (one wavefront
+//                   per output sample + shuffle reduction): 587 us where k_tile_mfma_p takes 32 —
+//                   6 cross-lane steps and two LDS reads per ~4.6 FMAs.  Never chosen automatically.
+// The frequency-domain engine (1e-6-class, not bit-identical: whole-signal float32/float64 device jobs)
+// lives in fft.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
