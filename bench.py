@@ -230,17 +230,21 @@ def live_libsoxr_timing(x):
 def configs4_stream(seconds=20):
     """BASELINE configs[4]: ResampleStream 44100->16000 int16, chunked input, state carried across
     launches (host-pointer surface: every call is H2D + kernel + D2H).  us per resample_chunk call and
-    Msamples/s for the chunk sizes SURVEY.md §8d names: constant rate (synchronous calls, and with deferred
-    output — each call returns the previous call's frames, no GPU round trip inside the call) and variable rate."""
+    Msamples/s for the chunk sizes SURVEY.md §8d names: constant rate (synchronous calls; synchronous calls served
+    by the resident kernel — no HIP call per chunk; deferred output — each call returns the previous call's
+    frames, no GPU round trip inside the call) and variable rate."""
     import numpy as np
     import soxr_amd as soxr
     rng = np.random.default_rng(5)
     x = (rng.standard_normal(44100 * seconds) * 5000).astype(np.int16)
     out = {"workload": f"BASELINE configs[4]: ResampleStream 44100->16000 int16 VHQ mono, {seconds} s, chunked "
                        f"(host numpy in/out per call, state on device)"}
-    for vr, deferred in ((False, False), (False, True), (True, False)):
+    for vr, deferred, resident in ((False, False, False), (False, False, True), (False, True, False), (True, False, False)):
         for chunk in (441, 4410, 96000):
-            rs = soxr.ResampleStream(44100, 16000, 1, dtype="int16", quality="VHQ", vr=vr, deferred=deferred)
+            if resident and chunk == 96000:
+                continue  # (beyond what the resident kernel serves: same as the synchronous leg)
+            rs = soxr.ResampleStream(44100, 16000, 1, dtype="int16", quality="VHQ", vr=vr, deferred=deferred,
+                                     resident=resident)
             rs.resample_chunk(x[:chunk])  # warm up: buffers, plan tables
             rs.clear()
             n_calls = 0
@@ -251,7 +255,7 @@ def configs4_stream(seconds=20):
                 rs.resample_chunk(x[a:a + chunk], last=(a + chunk >= len(x)))
                 n_calls += 1
             dt = time.perf_counter() - t0
-            key = f"{'vr' if vr else 'cr_deferred' if deferred else 'cr'}_chunk{chunk}"
+            key = f"{'vr' if vr else 'cr_deferred' if deferred else 'cr_resident' if resident else 'cr'}_chunk{chunk}"
             out[key] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls, "Msamples_per_s": len(x) / dt / 1e6}
             if chunk == 441 and not vr:
                 # a real-time caller feeds a chunk every 10 ms: time spent INSIDE the call when calls are spaced

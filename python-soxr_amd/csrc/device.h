@@ -24,7 +24,27 @@ struct VrPos {
 
 // Enqueue one job (validated by the caller) on `stream`.  vr != nullptr: positions come from *vr
 // instead of the plan's rational ratio (interpolated-phase plans only).
-const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream, const VrPos *vr = nullptr);
+// Resident form of the small-launch kernel (kernels.hip, k_chain_resident): the mailbox in pinned host memory
+// and what a launch of an instance needs.
+struct ResidentBox {
+    uint64_t w[8];                  // line 0: host -> device (tagged words, see k_chain_resident)
+    uint32_t done, exited, pad[14]; // line 1: device -> host
+};
+struct ResidentCtl { unsigned long long dec; unsigned arrived, pad; };
+struct ResidentLaunch {
+    ResidentBox *box;      // pinned, device-mapped
+    ResidentCtl *ctl;      // device memory, zeroed, not used by an earlier instance
+    uint32_t base_seq;     // messages taken by earlier instances
+    uint32_t epoch;        // number of this instance (never 0)
+    int64_t idle_us;       // the instance leaves after this long without a message
+    uint32_t n_wgs = 0;    // out: workgroups of the instance
+    int64_t max_out = 0;   // out: outputs per column one message may ask for
+};
+// job.out_frames = the largest message the instance must serve; launches nothing but the resident kernel
+const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream, const VrPos *vr = nullptr, ResidentLaunch *res = nullptr);
+// hand message `seq` to the instance: outputs [out_k0, out_k0 + out_frames) from ring frames [in_abs0, in_abs0 + in_frames)
+bool resident_post(const Plan &p, ResidentBox *box, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames);
+void resident_leave(ResidentBox *box, uint32_t epoch);
 
 int device_count();
 
@@ -44,6 +64,8 @@ struct Switches {
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
+    bool resident = false;        // HIPSOXR_RESIDENT         small-chunk synchronous streams use the resident kernel (as the HIPSOXR_RESIDENT flag)
+    int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids
     bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp
     // timing experiments on the tile kernels (results may be wrong with dbg_flags != 0)

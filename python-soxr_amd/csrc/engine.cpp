@@ -9,7 +9,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
@@ -103,6 +105,19 @@ struct hipsoxr_stream {
     size_t h_res_bytes[2] = {0, 0}, h_src_bytes[2] = {0, 0};
     hipEvent_t ev_res[2] = {nullptr, nullptr}, ev_src[2] = {nullptr, nullptr};
     unsigned calls = 0;
+    // Resident kernel (HIPSOXR_RESIDENT): synchronous small chunks are handed to a kernel that stays on the GPU
+    // between calls, through a mailbox in pinned memory — no HIP call per chunk (see resident_emit)
+    bool resident = false;
+    struct Resident {
+        ResidentBox *box = nullptr;  // pinned
+        ResidentCtl *ctl = nullptr;  // device: kCtlSlots arbiter words, one per instance
+        size_t ctl_next = 0;
+        uint32_t seq = 0, epoch = 0;
+        bool running = false;
+        const void *in = nullptr; void *out = nullptr; // what the running instance was launched on
+        int64_t max_out = 0;
+        unsigned failed = 0;         // launches refused (job not eligible): stop trying
+    } res;
     int device = -1;         // the device the HIP stream and every buffer above live on
     uint32_t dither_seed = 0; // int16 TPDF dither: hash(seed, channel, absolute output index); see hipsoxr_stream_set_dither_seed
     char engine_name[32] = {0};
@@ -124,8 +139,19 @@ struct DeviceGuard {
 // Wait for everything queued on the stream.  A chunked call is a 20-30 us round trip on the GPU;
 // the runtime's blocking hipStreamSynchronize adds an interrupt-and-wake-up latency of the same
 // order, so the first ~100 us are spent polling an event instead.
+// Retire the stream's resident kernel, if one is running: everything else that uses the HIP stream queues
+// behind it (and would wait until it leaves by itself, HIPSOXR_RESIDENT_IDLE_US later).
+static void resident_stop(hipsoxr_stream *s)
+{
+    if (!s->res.running) return;
+    resident_leave(s->res.box, s->res.epoch);
+    (void)hipStreamSynchronize(s->st);
+    s->res.running = false;
+}
+
 static hipError_t stream_wait(hipsoxr_stream *s)
 {
+    resident_stop(s);
     if (s->ev && hipEventRecord(s->ev, s->st) == hipSuccess) {
         for (int spin = 0; spin < 20000; ++spin) {
             const hipError_t q = hipEventQuery(s->ev);
@@ -451,13 +477,14 @@ static const char *host_ring_reserve(hipsoxr_stream *s, size_t ilen)
 {
     const size_t frame = (size_t)s->ch * esz(s);
     if (s->d_in && s->in_fill + ilen <= s->in_cap) return nullptr;
-    HIP_TRY(stream_wait(s));
+    if (!s->res.running) HIP_TRY(stream_wait(s)); // (a resident kernel is idle between calls: it has answered the last one)
     const int64_t n0 = first_needed(s);
     const int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base), s->in_base + (int64_t)s->in_fill);
     const size_t drop = (size_t)(keep_from - s->in_base), keep = s->in_fill - drop;
     size_t cap = std::max<size_t>(s->in_cap, 1024);
     while (cap < keep + 8 * ilen) cap <<= 1; // compaction every eighth call
     if (cap != s->in_cap || !s->d_in) {
+        resident_stop(s); // the ring moves: the next call launches another instance on the new one
         void *nb = nullptr;
         if (hipHostMalloc(&nb, cap * frame, hipHostMallocDefault) != hipSuccess) return "hipHostMalloc failed";
         if (keep) std::memcpy(nb, (char *)s->d_in + drop * frame, keep * frame);
@@ -605,6 +632,78 @@ static const char *stream_emit(hipsoxr_stream *s, void *out, size_t olen, size_t
     return nullptr;
 }
 
+// Synchronous small chunk through the resident kernel: post the call's numbers, spin on the answer.
+// Returns nullptr with *served = false when this call has to take the ordinary path.
+static const size_t kCtlSlots = 1024;
+static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool *served)
+{
+    hipsoxr_stream::Resident &r = s->res;
+    *served = false;
+    if (r.failed >= 2) return nullptr;
+    if (!r.box) {
+        if (hipHostMalloc((void **)&r.box, sizeof(ResidentBox), hipHostMallocDefault) != hipSuccess) { r.box = nullptr; r.failed = 2; return nullptr; }
+        std::memset(r.box, 0, sizeof(ResidentBox));
+        if (hipMalloc((void **)&r.ctl, kCtlSlots * sizeof(ResidentCtl)) != hipSuccess) { r.ctl = nullptr; r.failed = 2; return nullptr; }
+        HIP_TRY(hipMemsetAsync(r.ctl, 0, kCtlSlots * sizeof(ResidentCtl), s->st));
+        r.ctl_next = 0;
+    }
+    if (r.running && (r.in != j.in || r.out != j.out || j.out_frames > r.max_out)) resident_stop(s);
+    auto launch = [&](uint32_t base_seq) -> const char * {
+        if (r.ctl_next == kCtlSlots) { // every arbiter word has been used: wipe them (ordered behind the last instance)
+            HIP_TRY(hipMemsetAsync(r.ctl, 0, kCtlSlots * sizeof(ResidentCtl), s->st));
+            r.ctl_next = 0;
+        }
+        ResidentLaunch rl;
+        rl.box = r.box; rl.ctl = r.ctl + r.ctl_next++; rl.base_seq = base_seq;
+        if (++r.epoch == 0) ++r.epoch;
+        rl.epoch = r.epoch; rl.idle_us = std::max(50, switches().resident_idle_us);
+        hipsoxr_job_t cap = j; // room for chunks a quarter longer than this one
+        cap.out_frames = std::max<int64_t>(64, j.out_frames + j.out_frames / 4 + 2);
+        if (const char *e = launch_job(&s->plan->p, cap, s->st, nullptr, &rl)) {
+            (void)e; // not a job the resident form serves: the ordinary path does
+            ++r.failed;
+            return "";
+        }
+        r.running = true; r.in = j.in; r.out = j.out; r.max_out = rl.max_out; r.failed = 0;
+        return nullptr;
+    };
+    if (!r.running) {
+        if (const char *e = launch(r.seq)) return *e ? e : nullptr;
+        if (j.out_frames > r.max_out) { resident_stop(s); ++r.failed; return nullptr; }
+    }
+    const uint32_t seq = r.seq + 1;
+    if (!resident_post(s->plan->p, r.box, seq, j.in_abs0, j.in_frames, j.out_k0, j.out_frames)) { resident_stop(s); return nullptr; }
+    r.seq = seq;
+    volatile uint32_t *done = &r.box->done, *exited = &r.box->exited;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; ++spin) {
+        if (*done == seq) break;
+        if (*exited == r.epoch) {
+            // the instance left (idle for too long) before it saw the message, which is still in the box: the next
+            // instance takes it.  (An instance answers a message completely or not at all: k_chain_resident.)
+            (void)hipStreamSynchronize(s->st);
+            r.running = false;
+            if (*done == seq) break;
+            if (const char *e = launch(seq - 1)) return *e ? e : "resident kernel: relaunch refused";
+        }
+        __builtin_ia32_pause();
+        if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+            return "resident kernel does not answer";
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+#ifdef HIPSOXR_RES_TRACE
+    if ((r.seq & 1023) == 1000) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        std::fprintf(stderr, "resident msg %u: host post->done %.2f us; last workgroup %u: CAS+decode %.2f us, body %.2f, fence %.2f, arrive %.2f\n",
+                     r.seq, us, r.box->pad[4], r.box->pad[0] * 0.01, r.box->pad[1] * 0.01, r.box->pad[2] * 0.01, r.box->pad[3] * 0.01);
+        std::fprintf(stderr, "   workgroup 0 body: positions %.2f us, (span %.2f) staged %.2f, chains %.2f, stored %.2f\n", r.box->pad[5] * 0.01, r.box->pad[9] * 0.01, r.box->pad[6] * 0.01,
+                     r.box->pad[7] * 0.01, r.box->pad[8] * 0.01);
+    }
+#endif
+    *served = true;
+    return nullptr;
+}
+
 static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, size_t *odone)
 {
     const Plan &p = s->plan->p;
@@ -621,7 +720,7 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     if (v.on && v.n_slew && s->k_done + n > v.k_s + v.n_slew) n = (size_t)(v.k_s + v.n_slew - s->k_done);
     *odone = n;
     if (n == 0) {
-        HIP_TRY(stream_wait(s)); // the caller's input buffer is borrowed only for the call
+        if (!s->res.running) HIP_TRY(stream_wait(s)); // the caller's input buffer is borrowed only for the call (host ring: copied already)
         return nullptr;
     }
     if (n > s->out_cap) {
@@ -635,6 +734,7 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     // Small results are written by the kernel straight into pinned host memory (it is mapped into
     // the device's address space): no device-to-host copy call, just the completion wait.
     const size_t out_bytes = n * s->ch * esz(s);
+    if (s->res.running && out_bytes > s->h_out_bytes) resident_stop(s); // (the result buffer is about to move)
     const bool direct = out_bytes <= kPinnedMax && !pinned_ensure(&s->h_out, &s->h_out_bytes, out_bytes);
     hipsoxr_job_t j;
     std::memset(&j, 0, sizeof j);
@@ -656,6 +756,16 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     if (s->in_fill == 0) { // nothing staged yet (e.g. flush of an empty stream): any valid pointer
         j.in = s->d_out;
     }
+    bool served = false;
+    if (s->resident && s->ring_on_host && direct && !v.on && !s->split && s->in_fill > 0 && n <= 2048) {
+        if (const char *e = resident_emit(s, j, &served)) return e;
+    }
+    if (served) {
+        std::memcpy(out, s->h_out, out_bytes);
+        s->k_done += n;
+        return nullptr;
+    }
+    resident_stop(s);
     if (v.on) {
         const i128 T0 = v.pos(s->k_done), S0 = v.step(s->k_done), D = s->k_done < v.k_s + v.n_slew ? v.delta : 0;
         VrPos vp = {(uint64_t)((u128)T0 >> 64), (uint64_t)(u128)T0, (uint64_t)((u128)S0 >> 64), (uint64_t)(u128)S0,
@@ -786,6 +896,7 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
     s->plan = plan; s->own_plan = own; s->ch = ch;
     s->elem = (int)io & 3; s->split = ((int)io & 4) != 0; s->flags = flags;
     s->defer = (flags & HIPSOXR_DEFER) && !(flags & HIPSOXR_VR) && !s->split;
+    s->resident = ((flags & HIPSOXR_RESIDENT) || switches().resident) && !s->defer && !(flags & HIPSOXR_VR) && !s->split;
     if (flags & HIPSOXR_VR) {
         const double io0 = plan->p.in_rate / plan->p.out_rate;
         if (!(io0 > 9.5367431640625e-07) || !(io0 < 1048576.)) { delete s; return "io ratio out of range for variable rate"; }
@@ -875,7 +986,10 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
 {
     if (!s) return;
     DeviceGuard guard(s->device);
+    resident_stop(s);
     if (s->st) (void)hipStreamSynchronize(s->st);
+    if (s->res.box) (void)hipHostFree(s->res.box);
+    if (s->res.ctl) (void)hipFree(s->res.ctl);
     for (int i = 0; i < 2; ++i) {
         if (s->h_res[i]) (void)hipHostFree(s->h_res[i]);
         if (s->h_src[i]) (void)hipHostFree(s->h_src[i]);
@@ -933,7 +1047,7 @@ hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size
         if (const char *e = stream_append(s, in, ilen)) return e;
     }
     if (olen == 0 || out == nullptr) {
-        if (in && ilen) HIP_TRY(stream_wait(s)); // host buffer is borrowed only for the call
+        if (in && ilen && !s->res.running) HIP_TRY(stream_wait(s)); // host buffer is borrowed only for the call
         return nullptr;
     }
     return stream_emit(s, out, olen, odone);
@@ -950,6 +1064,7 @@ hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
 {
     if (!s) return "null argument";
     DeviceGuard guard(s->device);
+    resident_stop(s);
     if (s->st) (void)hipStreamSynchronize(s->st);
     s->ended = false; s->n_in_total = 0; s->k_done = 0; s->in_base = 0; s->in_fill = 0;
     s->pend_n = s->pend_off = 0;
@@ -980,6 +1095,7 @@ size_t hipsoxr_stream_num_clips(hipsoxr_stream_t *s)
     if (!s) return 0;
     DeviceGuard guard(s->device);
     uint64_t v = 0;
+    resident_stop(s);
     if (hipMemcpyAsync(&v, s->d_clips, sizeof v, hipMemcpyDeviceToHost, s->st) != hipSuccess) return 0;
     (void)hipStreamSynchronize(s->st);
     return (size_t)v;

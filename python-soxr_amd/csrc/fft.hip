@@ -1109,7 +1109,10 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 // shorter workgroups, at the price of more overlap
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
                 // (float64: LDS is 16 bytes per point — the half-size blocks keep four workgroups per CU)
-                if ((wgs < 480 && !switches().fft_large_only) || switches().fft_small_only || f64) { // measured crossover: ~470 pairs of large blocks
+                // (7056-point blocks: 56 KB of LDS, two workgroups per CU — the 35 KB blocks of the k = 10 geometry keep
+                //  four and win at every size: 44.1k -> 16k VHQ, 8 x 60 s planar 41 vs 68 us, 80 x 60 s 427 vs 638 us)
+                const bool big_lds = big->nt > 384;
+                if (((wgs < 480 || big_lds) && !switches().fft_large_only) || switches().fft_small_only || f64) { // measured crossover: ~470 pairs of large blocks
                     FftGeom gs;
                     if (const char *err = get(2 + sml_i, sml->k, &gs)) return err;
                     if (gs.ok) { g = gs; use = sml; }

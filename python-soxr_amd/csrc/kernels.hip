@@ -59,7 +59,8 @@ const Switches &switches()
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_small_3pass = on("HIPSOXR_FFT_SMALL_3PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
         w.no_planes = on("HIPSOXR_NO_PLANES");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.resident = on("HIPSOXR_RESIDENT");
+        if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
         w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
@@ -572,12 +573,29 @@ struct ChainArgs {
     int32_t span_cap;        // LDS room for the shared input span, in samples
 };
 
-template <typename IO, typename Real, int MODE>
-__global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
+// what changes from one launch (or one message to the resident form, below) to the next
+struct ChainMsg { int64_t in_abs0, in_frames, out_k0, out_frames, d0, p0; };
+
+#ifndef HIPSOXR_RPW
+#define HIPSOXR_RPW 2
+#endif
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `pre` runs in every thread before the barrier in front of the output stores; outputs are withheld if *veto has its
+// top bit set after that barrier (the resident form's arbiter, see k_chain_resident)
+template <typename IO, typename Real, int MODE, typename Pre = NoHook>
+__device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &m, const uint32_t bx, const uint32_t by,
+                                           unsigned char *smem_raw, uint32_t *trace = nullptr, Pre pre = Pre(),
+                                           const unsigned long long *veto = nullptr)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const InterpArgs &ia = ca.ia;
-    const GatherArgs &a = ia.g;
+#ifdef HIPSOXR_RES_TRACE
+    const long long tb0 = wall_clock64();
+#define HIPSOXR_CB_STAMP(k) do { if (trace && threadIdx.x == 0) trace[k] = (uint32_t)(wall_clock64() - tb0); } while (0)
+#else
+#define HIPSOXR_CB_STAMP(k) do { } while (0)
+#endif
+    InterpArgs ia = ca.ia;
+    GatherArgs &a = ia.g;
+    a.in_abs0 = m.in_abs0; a.in_frames = m.in_frames; a.out_k0 = m.out_k0; a.out_frames = m.out_frames; a.d0 = m.d0; a.p0 = m.p0;
     constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
     constexpr int V = 16 / (int)sizeof(Real);      // taps per 16-byte coefficient read: 4 (f32) or 2 (f64)
     const int32_t T = a.T, H = T / 2, NO = ca.NO, RS = T + V; // RS: row stride (rows 16-byte aligned, banks rotate by V per row)
@@ -586,17 +604,25 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
     int64_t *n0s = reinterpret_cast<int64_t *>(xs + ((ca.span_cap + 3) & ~3)); // [NO] first-tap input index (relative to in[0])
     uint64_t *aux = reinterpret_cast<uint64_t *>(n0s + NO);                    // [NO] phase (MODE 0) or iv<<32 | xq (MODE 1, 2)
 
-    const uint32_t ch = blockIdx.y % a.n_channels, clip = blockIdx.y / a.n_channels;
-    const int64_t o_base = (int64_t)blockIdx.x * NO;
+    const uint32_t ch = by % a.n_channels, clip = by / a.n_channels;
+    const int64_t o_base = (int64_t)bx * NO;
     const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
     typedef typename Vec4<Real>::type V4;
 
     if ((int)threadIdx.x < NO) { // one thread per output: where it sits
         const int64_t idx = o_base + threadIdx.x < a.out_frames ? o_base + threadIdx.x : a.out_frames - 1;
         if (MODE == 0) {
-            const int64_t t = a.p0 + idx * a.M, q = t / a.L;
+            const int64_t t = a.p0 + idx * a.M;
+            int64_t q;
+            uint32_t rem;
+            if (a.L < (1LL << 31) && t < (1LL << 51)) { // (integer division proper: ~1 us of this kernel's latency)
+                q = (int64_t)divmod_small((uint64_t)t, (uint32_t)a.L, 1. / (double)a.L, &rem);
+            } else {
+                q = t / a.L;
+                rem = (uint32_t)(t - q * a.L); // (banks are L*T coefficients: L < 2^32)
+            }
             n0s[threadIdx.x] = a.d0 + q - (H - 1) - a.in_abs0;
-            aux[threadIdx.x] = (uint64_t)(t - q * a.L);
+            aux[threadIdx.x] = (uint64_t)rem;
         } else {
             const InterpPos<Real> r = interp_locate<Real, MODE == 2>(ia, idx);
             n0s[threadIdx.x] = r.n0 - a.in_abs0;
@@ -604,78 +630,303 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
         }
     }
     __syncthreads();
-    // ---- stage.  The input span first (its loads are the slow ones when the ring lives in host memory) ...
+    HIPSOXR_CB_STAMP(0);
+    // ---- stage.  Wave w takes coefficient rows w, w+4, ...; a lane takes taps lane, lane+64, ... of a row (no
+    //      run-time division in the index arithmetic: that alone was a quarter of this kernel), EPT taps per
+    //      trip, loads first, RPW rows at a time.  The input span (SPT samples per thread) is requested AFTER the
+    //      first trip's coefficients and stored after them: when the ring lives in host memory its loads are a
+    //      PCIe round trip (2-3.5 us), and loads return in order — requested first, they held every coefficient
+    //      behind them (5.0-5.7 us for the whole staging; this way 3.4-4.8 us).
     const int64_t nfirst = n0s[0];
     const int32_t span = (int32_t)(n0s[NO - 1] - nfirst) + T; // windows are ordered: n0 is non-decreasing in o
-    for (int sidx = threadIdx.x; sidx < span; sidx += 256) {
-        const int64_t l = nfirst + sidx;
-        xs[sidx] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-    }
-    // ... then the coefficient rows.  Wave w takes rows w, w+4, ...; a lane takes taps lane, lane+64, ... of a
-    // row (no run-time division in the index arithmetic: that alone was a quarter of this kernel).  EPT taps
-    // per trip, loads first: for T <= 768 that is ONE round trip per row, two rows per wave at NO = 8.
-    constexpr int EPT = MODE == 0 ? 12 : 8;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int o = wave; o < NO; o += 4) {
-        const uint64_t au = aux[o];
-        const Real *crow = MODE == 0 ? (const Real *)ca.phase_major + au * (uint64_t)T : nullptr;
-        const V4 *prow = MODE == 0 ? nullptr : (const V4 *)ia.tab + (size_t)(au >> 32) * T;
-        for (int j0 = lane; j0 < T; j0 += 64 * EPT) {
-            Real cv[EPT];
-            V4 pv[MODE == 0 ? 1 : EPT];
+    constexpr int SPT = 4;
+    IO xv[SPT];
+    bool span_loaded = false, span_stored = false;
+    auto load_span = [&]() {
+        if (span_loaded) return;
+        span_loaded = true;
 #pragma unroll
-            for (int u = 0; u < EPT; ++u) {
-                const int j = j0 + u * 64;
-                cv[u] = 0;
-                if (j < T) {
-                    if (MODE == 0) cv[u] = crow[j];
-                    else pv[u] = prow[j];
+        for (int u = 0; u < SPT; ++u) {
+            const int64_t l = nfirst + (int32_t)threadIdx.x + u * 256;
+            xv[u] = 0;
+            if ((int32_t)threadIdx.x + u * 256 < span && l >= 0 && l < a.in_frames) xv[u] = xin[l * a.ifs];
+        }
+    };
+    auto store_span = [&]() {
+        if (span_stored) return;
+        span_stored = true;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u)
+            if ((int32_t)threadIdx.x + u * 256 < span) xs[threadIdx.x + u * 256] = (Real)xv[u];
+        for (int sidx = threadIdx.x + SPT * 256; sidx < span; sidx += 256) { // (spans beyond 1024 samples: very long filters)
+            const int64_t l = nfirst + sidx;
+            xs[sidx] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+        }
+    };
+    constexpr int EPT = MODE == 0 ? 12 : 8, RPW = HIPSOXR_RPW;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int o0 = wave; o0 < NO; o0 += 4 * RPW) {
+        uint64_t au[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) au[r] = aux[o0 + 4 * r < NO ? o0 + 4 * r : o0];
+        for (int j0 = lane; j0 < T; j0 += 64 * EPT) {
+            Real cv[RPW][EPT];
+            V4 pv[RPW][MODE == 0 ? 1 : EPT];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const Real *crow = MODE == 0 ? (const Real *)ca.phase_major + au[r] * (uint64_t)T : nullptr;
+                const V4 *prow = MODE == 0 ? nullptr : (const V4 *)ia.tab + (size_t)(au[r] >> 32) * T;
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const int j = j0 + u * 64;
+                    cv[r][u] = 0;
+                    if (j < T && o0 + 4 * r < NO) {
+                        if (MODE == 0) cv[r][u] = crow[j];
+                        else pv[r][u] = prow[j];
+                    }
                 }
             }
+            load_span();
 #pragma unroll
-            for (int u = 0; u < EPT; ++u) {
-                const int j = j0 + u * 64;
-                if (j < T) {
-                    if (MODE != 0) {
-                        const Real xx = (Real)(uint32_t)au * (Real)(1. / (double)(1ULL << SH));
-                        cv[u] = fma_r(fma_r(fma_r(pv[u].w, xx, pv[u].z), xx, pv[u].y), xx, pv[u].x);
+            for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const int j = j0 + u * 64;
+                    if (j < T && o0 + 4 * r < NO) {
+                        if (MODE != 0) {
+                            const Real xx = (Real)(uint32_t)au[r] * (Real)(1. / (double)(1ULL << SH));
+                            cv[r][u] = fma_r(fma_r(fma_r(pv[r][u].w, xx, pv[r][u].z), xx, pv[r][u].y), xx, pv[r][u].x);
+                        }
+                        cs[(size_t)(o0 + 4 * r) * RS + j] = cv[r][u];
                     }
-                    cs[(size_t)o * RS + j] = cv[u];
                 }
             }
         }
     }
+    load_span(); // (waves without a row)
+    store_span();
     __syncthreads();
-    if ((int)threadIdx.x < 2 * NO) { // first wave: the half-chains
-        const int o = threadIdx.x < NO ? threadIdx.x : threadIdx.x - NO;
-        const bool right = (int)threadIdx.x >= NO;
+    HIPSOXR_CB_STAMP(1);
+    // ---- the half-chains: wave 0 the left halves (ascending), wave 1 the right halves (descending) — one
+    //      instruction stream per wave; taps in blocks of UNR*V with every LDS read of a block issued before
+    //      its FMAs (the chain is a dependent sequence: what can be hidden is the read latency)
+    Real *red = reinterpret_cast<Real *>(n0s); // (positions are consumed: the right halves' sums go here)
+    const int64_t my_n0 = n0s[lane < NO ? lane : 0];
+    __syncthreads();
+    Real acc = 0;
+    if (wave < 2 && lane < NO) {
+        const int o = lane;
         const Real *row = cs + (size_t)o * RS;
-        const Real *xw = xs + (n0s[o] - nfirst); // this output's window inside the shared span
-        Real acc = 0;
-        if (!right) {
-#pragma unroll 2
-            for (int i = 0; i < H; i += V) { // taps i .. i+V-1, ascending
+        const Real *xw = xs + (my_n0 - nfirst); // this output's window inside the shared span
+        constexpr int UNR = 8;
+        if (wave == 0) {
+            int i = 0;
+            for (; i + UNR * V <= H; i += UNR * V) {
+                Real c[UNR * V], x[UNR * V];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    *reinterpret_cast<typename VecN<Real, V>::type *>(c + u * V) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i + u * V);
+#pragma unroll
+                for (int v = 0; v < UNR * V; ++v) x[v] = xw[i + v];
+#pragma unroll
+                for (int v = 0; v < UNR * V; ++v) acc = fma_r(c[v], x[v], acc);
+            }
+            for (; i < H; i += V) { // taps i .. i+V-1, ascending
                 Real c[V];
                 *reinterpret_cast<typename VecN<Real, V>::type *>(c) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i);
 #pragma unroll
                 for (int v = 0; v < V; ++v) acc = fma_r(c[v], xw[i + v], acc);
             }
         } else {
-#pragma unroll 2
-            for (int i = T - V; i >= H; i -= V) { // taps i+V-1 .. i, descending
+            int i = T - V;
+            for (; i - (UNR - 1) * V >= H; i -= UNR * V) { // taps i+V-1 .. i-(UNR-1)V, descending
+                Real c[UNR * V], x[UNR * V];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    *reinterpret_cast<typename VecN<Real, V>::type *>(c + u * V) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i - u * V);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) x[u * V + v] = xw[i - u * V + v];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int v = V - 1; v >= 0; --v) acc = fma_r(c[u * V + v], x[u * V + v], acc);
+            }
+            for (; i >= H; i -= V) { // taps i+V-1 .. i, descending
                 Real c[V];
                 *reinterpret_cast<typename VecN<Real, V>::type *>(c) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i);
 #pragma unroll
                 for (int v = V - 1; v >= 0; --v) acc = fma_r(c[v], xw[i + v], acc);
             }
+            red[o] = acc;
         }
-        const Real accR = __shfl(acc, (int)threadIdx.x + NO, 64); // NO <= 32: partner in the same wave
+    }
+    pre();
+    __syncthreads();
+    HIPSOXR_CB_STAMP(2);
+    if (veto && (*veto >> 63)) return;
+    if (wave == 0 && lane < NO) {
+        const int o = lane;
+        const Real accR = red[o];
         const int64_t idx = o_base + o;
-        if (!right && idx < a.out_frames) {
+        if (idx < a.out_frames) {
             IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + idx * a.ofs + (int64_t)ch * a.ochs;
             store_out<Real>(yo, acc + accR, a.oc, ch, a.out_k0 + idx);
         }
     }
+    HIPSOXR_CB_STAMP(3);
+#undef HIPSOXR_CB_STAMP
+}
+
+template <typename IO, typename Real, int MODE>
+__global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const GatherArgs &g = ca.ia.g;
+    const ChainMsg m = {g.in_abs0, g.in_frames, g.out_k0, g.out_frames, g.d0, g.p0};
+    chain_body<IO, Real, MODE>(ca, m, blockIdx.x, blockIdx.y, smem_raw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chain_resident — k_chain as a RESIDENT consumer: launched once, fed by messages
+// ---------------------------------------------------------------------------------------------
+// A synchronous streaming call on a small chunk costs ~31 us, of which the arithmetic is ~2: the rest is one
+// kernel launch (API ~7 us, dispatch ~4 us), the completion event and its polling.  Here the kernel stays on
+// the GPU between calls and the host talks to it through two cache lines of pinned, device-mapped host
+// memory (ResidentBox) — no HIP call per chunk at all (tools/ubench/mailbox.hip: 3.9 us for the bare round
+// trip host -> kernel -> host, 5.6 us with 1 KiB read from pinned memory on the way):
+//   host -> device  w[0..4]: the ChainMsg of the call, each 8-byte word carrying the message number in its top
+//                   16 bits (an 8-byte read is atomic whatever the load is split into: a word is either this
+//                   message's or stale, and the message is taken once all five carry the expected number);
+//                   w[5]: "instance e, leave" (between messages only);
+//   device -> host  done = number of the last message whose output is complete in pinned memory; exited = e.
+// Every workgroup polls the box itself (one wave, s_sleep between reads) and owns the same NO outputs of
+// every message as in k_chain (workgroups past the end of a short message just report in).  The input ring,
+// the result buffer and the plan are launch arguments: when one of them moves, the host retires the instance
+// and launches another.
+// Leaving.  The kernel must not outlive its host's interest (a device-wide synchronisation elsewhere in the
+// process waits for it), so an instance that hears nothing for idle_ticks leaves by itself — and all its
+// workgroups must take the SAME decision about every message, or a message would be half computed (and its
+// clipped samples counted twice when the next instance repeats it).  One word of device memory per instance
+// (ctl->dec = number of messages accepted, top bit = sealed) arbitrates: a workgroup that sees message n+1
+// does CAS(n -> n+1), one that has waited too long does CAS(n -> n|SEAL); whichever CAS lands first decides
+// for everybody (a workgroup whose seal fails because n+1 was accepted goes back for the message, one whose
+// accept fails because the instance is sealed leaves).  The host, waiting for `done`, sees `exited` instead
+// and launches the next instance, which finds the message still in the box.
+// ---------------------------------------------------------------------------------------------
+// (ResidentBox, ResidentCtl: device.h)
+struct ResidentArgs {
+    ChainArgs ca;
+    ResidentBox *box;
+    ResidentCtl *ctl;
+    uint32_t base_seq; // messages taken by earlier instances
+    uint32_t epoch;    // this instance
+    int64_t idle_ticks; // of wall_clock64 (100 MHz)
+    uint32_t n_wgs;
+};
+static constexpr unsigned long long kResidentSeal = 1ULL << 63;
+static constexpr uint64_t kResidentMask48 = (1ULL << 48) - 1;
+
+template <typename IO, typename Real, int MODE>
+__global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ uint64_t s_w[8];
+    __shared__ unsigned long long s_old;
+    __shared__ int s_state;
+    const uint32_t n_wgs = ra.n_wgs;
+    const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned long long n = 0; // messages this instance has completed
+    long long t_idle = wall_clock64();
+    for (;;) {
+        if (threadIdx.x < 64) { // one wave polls
+            const int lane = threadIdx.x;
+            const uint64_t want = (uint64_t)((ra.base_seq + (uint32_t)n + 1u) & 0xffffu);
+            int state;
+            uint64_t v = 0;
+            for (;;) {
+                if (lane < 6) v = __hip_atomic_load(&ra.box->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const bool ok = lane >= 5 || (v >> 48) == want;
+                const uint64_t leave = __shfl(v, 5, 64);
+                if (__all(ok)) { state = 1; break; }
+                if (leave == (uint64_t)ra.epoch) { state = 2; break; }
+                if (wall_clock64() - t_idle > ra.idle_ticks) { state = 3; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (lane < 5) s_w[lane] = v & kResidentMask48;
+            if (lane == 0) {
+                // too long without a message: try to seal the instance (the arbiter, see above)
+                if (state == 3) s_old = atomicCAS(&ra.ctl->dec, n, n | kResidentSeal);
+                s_state = state;
+            }
+        }
+        __syncthreads();
+        const int state = s_state;
+#ifdef HIPSOXR_RES_TRACE
+        const long long tr0 = wall_clock64();
+#endif
+        if (state == 2) break;                                   // told to leave
+        if (state == 3) {
+            const unsigned long long old = s_old;
+            if (old == n || (old & kResidentSeal)) break;        // sealed: everybody leaves after message n
+            __syncthreads();                                     // message n+1 was accepted by somebody: it is in the box
+            continue;
+        }
+        // message n+1 is here: accept it.  The arbiter's round trip (~1 us) runs behind the body's own loads:
+        // one lane of the last wave asks now and publishes the answer in front of the body's last barrier.
+        unsigned long long old = 0;
+        const bool asker = threadIdx.x == 192;
+        if (asker) old = atomicCAS(&ra.ctl->dec, n, n + 1);
+        auto publish = [&]() { if (asker) s_old = old; };
+        ChainMsg m;
+        {
+            auto uni = [](uint64_t x) {
+                return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x);
+            };
+            const uint64_t w3 = uni(s_w[3]), w4 = uni(s_w[4]);
+            m.in_abs0 = (int64_t)uni(s_w[0]); m.out_k0 = (int64_t)uni(s_w[1]); m.d0 = (int64_t)uni(s_w[2]);
+            m.p0 = (int64_t)(w3 & 0xffffffu); m.in_frames = (int64_t)(w3 >> 24);
+            m.out_frames = (int64_t)w4;
+        }
+        if ((int64_t)blockIdx.x * ra.ca.NO < m.out_frames) {
+            chain_body<IO, Real, MODE>(ra.ca, m, blockIdx.x, blockIdx.y, smem_raw,
+#ifdef HIPSOXR_RES_TRACE
+                                       wg == 0 ? ra.box->pad + 5 : nullptr,
+#else
+                                       nullptr,
+#endif
+                                       publish, &s_old);
+        } else {
+            publish();
+            __syncthreads();
+        }
+        if (s_old & kResidentSeal) break;                        // sealed before this workgroup saw the message: nothing was stored
+#ifdef HIPSOXR_RES_TRACE
+        const long long tr1 = wall_clock64();
+#endif
+        __threadfence_system(); // this workgroup's results are in host memory before it reports in
+        __syncthreads();
+#ifdef HIPSOXR_RES_TRACE
+        const long long tr2 = wall_clock64();
+#endif
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(&ra.ctl->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == n_wgs - 1) { // the last one: everything is there
+#ifdef HIPSOXR_RES_TRACE
+                ra.box->pad[0] = (uint32_t)(tr0 - t_idle); ra.box->pad[1] = (uint32_t)(tr1 - tr0); ra.box->pad[2] = (uint32_t)(tr2 - tr1);
+                ra.box->pad[3] = (uint32_t)(wall_clock64() - tr2); ra.box->pad[4] = wg;
+#endif
+                __hip_atomic_store(&ra.ctl->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ra.box->done, ra.base_seq + (uint32_t)n + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        ++n;
+        t_idle = wall_clock64();
+        __syncthreads(); // (s_w / s_state are rewritten by the next poll)
+    }
+    if (threadIdx.x == 0 && wg == 0) __hip_atomic_store(&ra.box->exited, ra.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1582,7 +1833,7 @@ void device_bank_release(Plan *p)
 // launch
 // ---------------------------------------------------------------------------------------------
 template <typename IO, typename Real>
-static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr = nullptr)
+static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr = nullptr, ResidentLaunch *res = nullptr)
 {
     const DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
     // split so that idx*M stays far below 2^63 and grid.x below 2^31
@@ -1622,6 +1873,9 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             // few outputs per workgroup: the staging loop is then two or three trips of 16 loads per
             // thread (its latency is the kernel's latency), and there are enough workgroups anyway
             int NO = nf <= 2048 ? 8 : 32;
+            // (resident form: every workgroup polls the mailbox and reads its span over PCIe — at most 64 of them)
+            if (res && nf > 512) NO = 32;
+            if (getenv("HIPSOXR_DEBUG_NO")) NO = atoi(getenv("HIPSOXR_DEBUG_NO"));
             // LDS: NO coefficient rows of T + V words, the shared input span (T + what NO-1 window shifts of at
             // most ceil(M/L) + 1 samples add; variable rate: the plan's ratio is the largest step), bookkeeping
             const int64_t shift = (p->M + p->L - 1) / p->L + 2;
@@ -1672,6 +1926,29 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     ca.phase_major = dm.phase_major;
                     ck = k_chain<IO, Real, 0>;
                 }
+                if (res) { // the resident form: same staging, same chains, fed by messages (k_chain_resident)
+                    if (vr) return "resident kernel: constant rate only";
+                    if (p->L >= (1 << 24)) return "resident kernel: ratio numerator too large";
+                    void (*rk)(ResidentArgs) = p->phases ? k_chain_resident<IO, Real, 1> : k_chain_resident<IO, Real, 0>;
+                    const unsigned gx = (unsigned)((nf + NO - 1) / NO), gy = (unsigned)((uint64_t)j.n_clips * j.n_channels);
+                    // every workgroup must be on the chip at once (they wait for each other): a quarter of the slots at most
+                    int occ = 0, dev = 0, cus = 0;
+                    if (lds > 64 * 1024)
+                        HIP_TRY(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)rk, 256, lds));
+                    HIP_TRY(hipGetDevice(&dev));
+                    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                    if ((int64_t)gx * gy > (int64_t)occ * cus / 4 || (int64_t)gx * gy > 64) return "resident kernel: message too large";
+                    ResidentArgs ra;
+                    std::memset(&ra, 0, sizeof ra);
+                    ra.ca = ca; ra.box = res->box; ra.ctl = res->ctl; ra.base_seq = res->base_seq; ra.epoch = res->epoch;
+                    ra.idle_ticks = res->idle_us * 100; // wall_clock64: 100 MHz
+                    ra.n_wgs = gx * gy;
+                    res->n_wgs = ra.n_wgs; res->max_out = (int64_t)gx * NO;
+                    hipLaunchKernelGGL(rk, dim3(gx, gy, 1), dim3(256), lds, st, ra);
+                    HIP_TRY(hipGetLastError());
+                    return nullptr;
+                }
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(ck, dim3((unsigned)((nf + NO - 1) / NO), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1),
@@ -1680,6 +1957,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 continue;
             }
         }
+        if (res) return "resident kernel: unavailable for this job";
         if (p->phases) {
             InterpArgs ia;
             std::memset(&ia, 0, sizeof ia);
@@ -1877,8 +2155,9 @@ static const char *launch_wave_dot(Plan *p, const hipsoxr_job_t &j, hipStream_t 
 }
 
 template <typename IO, typename Real>
-static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr)
+static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr, ResidentLaunch *res = nullptr)
 {
+    if (res) return launch_gather<IO, Real>(p, j, st, vr, res);
     const int prec = sizeof(Real) == 4 ? 0 : 1;
     TileGeom gv, gm; // VALU-tile and MFMA-tile geometries (the latter exists for the f32 engine only)
     {
@@ -1939,9 +2218,30 @@ const char *stream_kernel(void *dst, const void *src, size_t bytes, int mode, vo
     return nullptr;
 }
 
-const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr)
+bool resident_post(const Plan &p, ResidentBox *box, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames)
 {
-    if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return nullptr;
+    const __int128 kM = (__int128)out_k0 * p.M;
+    const int64_t d0 = (int64_t)(kM / p.L), p0 = (int64_t)(kM % p.L);
+    const uint64_t lim = 1ULL << 48;
+    if ((uint64_t)in_abs0 >= lim || (uint64_t)out_k0 >= lim || (uint64_t)d0 >= lim || (uint64_t)in_frames >= (1u << 24) ||
+        (uint64_t)p0 >= (1u << 24) || (uint64_t)out_frames >= lim)
+        return false;
+    const uint64_t tag = (uint64_t)(seq & 0xffffu) << 48;
+    // (x86 keeps stores in order; the words validate themselves: k_chain_resident)
+    volatile uint64_t *w = box->w;
+    w[0] = tag | (uint64_t)in_abs0;
+    w[1] = tag | (uint64_t)out_k0;
+    w[2] = tag | (uint64_t)d0;
+    w[3] = tag | ((uint64_t)in_frames << 24) | (uint64_t)p0;
+    __atomic_store_n(&box->w[4], tag | (uint64_t)out_frames, __ATOMIC_RELEASE);
+    return true;
+}
+void resident_leave(ResidentBox *box, uint32_t epoch) { __atomic_store_n(&box->w[5], (uint64_t)epoch, __ATOMIC_RELEASE); }
+
+const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr, ResidentLaunch *res)
+{
+    if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return res ? "resident kernel: empty job" : nullptr;
+    if (res && (uint64_t)j.n_clips * j.n_channels > 65535) return "resident kernel: too many columns";
     // Kernels index (clip, channel) columns through grid.y (<= 65535).  Wider jobs — the Python surface
     // admits 65536 channels like the reference, src/soxr/__init__.py:22 — are folded into several
     // launches over channel (or clip) ranges; columns are independent, so the result is the same.
@@ -1987,7 +2287,7 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     // Frequency-domain engine: explicit request, or AUTO for large whole-signal float32 jobs.
     // It is NOT bit-identical to the canonical order (about 2e-7 relative RMS), so it is never chosen
     // for HIPSOXR_KERNEL_EXACT — which is what the stream / one-shot host entry points pass.
-    if (!vr && (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO)) {
+    if (!vr && !res && (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO)) {
         const bool no_fft = switches().no_fft;
         const bool eligible = fft_job_eligible(*p, j);
         const bool big = (int64_t)j.out_frames * j.n_clips * j.n_channels >= (1 << 13); // even one block pair beats the tiled exact kernels (7 vs 10 us)
@@ -2002,10 +2302,10 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     }
     hipStream_t st = (hipStream_t)stream;
     switch (j.elem) {
-    case HIPSOXR_F32: return launch_typed<float, float>(p, j, st, vr);
-    case HIPSOXR_F64: return launch_typed<double, double>(p, j, st, vr);
-    case HIPSOXR_I32: return launch_typed<int32_t, double>(p, j, st, vr);
-    case HIPSOXR_I16: return launch_typed<int16_t, float>(p, j, st, vr);
+    case HIPSOXR_F32: return launch_typed<float, float>(p, j, st, vr, res);
+    case HIPSOXR_F64: return launch_typed<double, double>(p, j, st, vr, res);
+    case HIPSOXR_I32: return launch_typed<int32_t, double>(p, j, st, vr, res);
+    case HIPSOXR_I16: return launch_typed<int16_t, float>(p, j, st, vr, res);
     }
     return "invalid element type";
 }

@@ -54,6 +54,7 @@ QQ, LQ, MQ, HQ, VHQ = 0, 1, 2, 4, 6
 VR = 32
 NO_DITHER = 8
 DEFER = 64
+RESIDENT = 128
 KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILE, KERNEL_TILE_VALU, KERNEL_TILE_MFMA, KERNEL_FFT, KERNEL_EXACT, KERNEL_WAVE_DOT = range(8)
 
 

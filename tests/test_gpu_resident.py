@@ -1,0 +1,97 @@
+"""Resident kernel (extension, HIPSOXR_RESIDENT / ResampleStream(resident=True)): synchronous small chunks are
+served by a kernel that stays on the GPU and is fed through a mailbox in pinned memory
+(python-soxr_amd/csrc/kernels.hip k_chain_resident, engine.cpp resident_emit).  The contract is the synchronous
+stream's, bit for bit and call for call (reference: CSoxr::process, /root/reference/src/soxr_ext.cpp:162-187)."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+@pytest.fixture(scope="module")
+def soxr():
+    import soxr_amd
+    return soxr_amd
+
+
+def _signal(dtype, n, ch, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, ch)) if ch > 1 else rng.standard_normal(n)
+    return (x * 5000).astype(dtype) if np.issubdtype(dtype, np.integer) else (x * 0.25).astype(dtype)
+
+
+def _run(rs, x, chunks, pause=0.0):
+    parts, a, i = [], 0, 0
+    while a < len(x):
+        c = chunks[i % len(chunks)]
+        parts.append(rs.resample_chunk(x[a:a + c], last=(a + c >= len(x))))
+        a += c; i += 1
+        if pause:
+            time.sleep(pause)
+    return parts
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16, np.int32])
+@pytest.mark.parametrize("rates,quality,ch,chunk", [((44100, 16000), "VHQ", 1, 441), ((48000, 44100), "HQ", 2, 480),
+                                                     ((44100, 48000), "VHQ", 1, 100), ((8000, 22050), "MQ", 3, 17),
+                                                     ((44100, 16000), "VHQ", 1, 4410)])
+def test_resident_equals_synchronous(soxr, dtype, rates, quality, ch, chunk):
+    x = _signal(dtype, 30000, ch, 41)
+    ref = _run(soxr.ResampleStream(*rates, ch, dtype=dtype, quality=quality), x, [chunk])
+    got = _run(soxr.ResampleStream(*rates, ch, dtype=dtype, quality=quality, resident=True), x, [chunk])
+    assert [len(p) for p in got] == [len(p) for p in ref]          # the same frames in the same calls
+    assert np.array_equal(np.concatenate(got), np.concatenate(ref))
+    assert np.array_equal(np.concatenate(got), soxr.resample(x, *rates, quality=quality))
+
+
+def test_resident_kernel_leaves_and_comes_back(soxr):
+    """Calls spaced further apart than the idle time (1 ms): the instance leaves by itself, the next call starts
+    another one; a device-wide synchronisation in between returns (it waits for the instance at most)."""
+    import torch
+    x = _signal(np.int16, 44100, 1, 42)
+    ref = np.concatenate(_run(soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ"), x, [441]))
+    rs = soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ", resident=True)
+    parts, t_sync = [], 0.0
+    for i, a in enumerate(range(0, len(x), 441)):
+        parts.append(rs.resample_chunk(x[a:a + 441], last=(a + 441 >= len(x))))
+        if i % 10 == 3:
+            time.sleep(0.004)
+        if i % 10 == 7:
+            t0 = time.perf_counter()
+            torch.cuda.synchronize()
+            t_sync = max(t_sync, time.perf_counter() - t0)
+    assert np.array_equal(np.concatenate(parts), ref)
+    assert t_sync < 0.5
+
+
+def test_resident_mixed_chunks_clear_and_clip_count(soxr):
+    """Chunk sizes from a few frames to beyond what the resident form serves (the ring then moves to device memory
+    and the stream continues on the ordinary path), clear() and re-use, the clip counter."""
+    x = _signal(np.int16, 150000, 2, 43)
+    x[5000:5200] = 32767  # overshoot: clipped samples
+    chunks = [441, 7, 2000, 441, 441, 1, 9000, 441, 50000, 441, 300]
+    for rep in range(2):
+        a = soxr.ResampleStream(44100, 16000, 2, dtype=np.int16, quality="HQ")
+        b = soxr.ResampleStream(44100, 16000, 2, dtype=np.int16, quality="HQ", resident=True)
+        for r in range(2):
+            ya, yb = _run(a, x, chunks), _run(b, x, chunks)
+            assert [len(p) for p in ya] == [len(p) for p in yb]
+            assert np.array_equal(np.concatenate(ya), np.concatenate(yb))
+            assert a.num_clips() == b.num_clips() and a.num_clips() > 0
+            a.clear(); b.clear()
+        chunks = chunks[::-1]
+
+
+def test_resident_many_streams_at_once(soxr):
+    """Several resident streams in one process, interleaved calls: each has its own mailbox and instance."""
+    x = _signal(np.float32, 20000, 1, 44)
+    want = np.concatenate(_run(soxr.ResampleStream(48000, 44100, 1, quality="HQ"), x, [480]))
+    streams = [soxr.ResampleStream(48000, 44100, 1, quality="HQ", resident=True) for _ in range(6)]
+    parts = [[] for _ in streams]
+    for a in range(0, len(x), 480):
+        for k, rs in enumerate(streams):
+            parts[k].append(rs.resample_chunk(x[a:a + 480], last=(a + 480 >= len(x))))
+    for p in parts:
+        assert np.array_equal(np.concatenate(p), want)
