@@ -26,9 +26,11 @@ struct VrPos {
 // instead of the plan's rational ratio (interpolated-phase plans only).
 // Resident form of the small-launch kernel (kernels.hip, k_chain_resident): the mailbox in pinned host memory
 // and what a launch of an instance needs.
+static constexpr unsigned kResidentMaxWgs = 64;
 struct ResidentBox {
     uint64_t w[8];                  // line 0: host -> device (tagged words, see k_chain_resident)
-    uint32_t done, exited, pad[14]; // line 1: device -> host
+    uint32_t exited, pad[15];       // line 1: device -> host: the instance that has left
+    uint32_t done[kResidentMaxWgs]; // lines 2..5: device -> host: last message finished, per workgroup
 };
 struct ResidentCtl { unsigned long long dec; unsigned arrived, pad; };
 struct ResidentLaunch {

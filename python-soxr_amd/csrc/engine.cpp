@@ -116,6 +116,7 @@ struct hipsoxr_stream {
         bool running = false;
         const void *in = nullptr; void *out = nullptr; // what the running instance was launched on
         int64_t max_out = 0;
+        unsigned n_wgs = 0;
         unsigned failed = 0;         // launches refused (job not eligible): stop trying
     } res;
     int device = -1;         // the device the HIP stream and every buffer above live on
@@ -664,7 +665,7 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
             ++r.failed;
             return "";
         }
-        r.running = true; r.in = j.in; r.out = j.out; r.max_out = rl.max_out; r.failed = 0;
+        r.running = true; r.in = j.in; r.out = j.out; r.max_out = rl.max_out; r.n_wgs = rl.n_wgs; r.failed = 0;
         return nullptr;
     };
     if (!r.running) {
@@ -674,17 +675,21 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
     const uint32_t seq = r.seq + 1;
     if (!resident_post(s->plan->p, r.box, seq, j.in_abs0, j.in_frames, j.out_k0, j.out_frames)) { resident_stop(s); return nullptr; }
     r.seq = seq;
-    volatile uint32_t *done = &r.box->done, *exited = &r.box->exited;
+    volatile uint32_t *done = r.box->done, *exited = &r.box->exited;
     const auto t0 = std::chrono::steady_clock::now();
+    unsigned next = 0; // workgroups [0, next) have answered
     for (uint64_t spin = 0;; ++spin) {
-        if (*done == seq) break;
+        while (next < r.n_wgs && done[next] == seq) ++next;
+        if (next == r.n_wgs) break;
         if (*exited == r.epoch) {
             // the instance left (idle for too long) before it saw the message, which is still in the box: the next
             // instance takes it.  (An instance answers a message completely or not at all: k_chain_resident.)
             (void)hipStreamSynchronize(s->st);
             r.running = false;
-            if (*done == seq) break;
+            while (next < r.n_wgs && done[next] == seq) ++next;
+            if (next == r.n_wgs) break;
             if (const char *e = launch(seq - 1)) return *e ? e : "resident kernel: relaunch refused";
+            next = 0;
         }
         __builtin_ia32_pause();
         if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
@@ -694,8 +699,8 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
 #ifdef HIPSOXR_RES_TRACE
     if ((r.seq & 1023) == 1000) {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        std::fprintf(stderr, "resident msg %u: host post->done %.2f us; last workgroup %u: CAS+decode %.2f us, body %.2f, fence %.2f, arrive %.2f\n",
-                     r.seq, us, r.box->pad[4], r.box->pad[0] * 0.01, r.box->pad[1] * 0.01, r.box->pad[2] * 0.01, r.box->pad[3] * 0.01);
+        std::fprintf(stderr, "resident msg %u: host post->done %.2f us; workgroup 0: idle+poll %.2f us, body %.2f, fence %.2f\n",
+                     r.seq, us, r.box->pad[0] * 0.01, r.box->pad[1] * 0.01, r.box->pad[2] * 0.01);
         std::fprintf(stderr, "   workgroup 0 body: positions %.2f us, (span %.2f) staged %.2f, chains %.2f, stored %.2f\n", r.box->pad[5] * 0.01, r.box->pad[9] * 0.01, r.box->pad[6] * 0.01,
                      r.box->pad[7] * 0.01, r.box->pad[8] * 0.01);
     }

@@ -645,11 +645,18 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &
     auto load_span = [&]() {
         if (span_loaded) return;
         span_loaded = true;
+        // (unconditional loads from clamped addresses, zeroed afterwards: a load under a per-lane condition is a branch
+        //  and a conservative wait each, and the compiler then serialises what should be one round trip)
 #pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const int64_t l = nfirst + (int32_t)threadIdx.x + u * 256;
-            xv[u] = 0;
-            if ((int32_t)threadIdx.x + u * 256 < span && l >= 0 && l < a.in_frames) xv[u] = xin[l * a.ifs];
+        for (int u = 0; u < SPT; ++u) xv[u] = 0;
+        if (a.in_frames > 0) {
+#pragma unroll
+            for (int u = 0; u < SPT; ++u) {
+                const int64_t l = nfirst + (int32_t)threadIdx.x + u * 256;
+                const int64_t lc = l < 0 ? 0 : l >= a.in_frames ? a.in_frames - 1 : l;
+                const IO v = xin[lc * a.ifs];
+                xv[u] = (l == lc) ? v : (IO)0;
+            }
         }
     };
     auto store_span = [&]() {
@@ -677,13 +684,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &
                 const Real *crow = MODE == 0 ? (const Real *)ca.phase_major + au[r] * (uint64_t)T : nullptr;
                 const V4 *prow = MODE == 0 ? nullptr : (const V4 *)ia.tab + (size_t)(au[r] >> 32) * T;
 #pragma unroll
-                for (int u = 0; u < EPT; ++u) {
-                    const int j = j0 + u * 64;
-                    cv[r][u] = 0;
-                    if (j < T && o0 + 4 * r < NO) {
-                        if (MODE == 0) cv[r][u] = crow[j];
-                        else pv[r][u] = prow[j];
-                    }
+                for (int u = 0; u < EPT; ++u) { // (unconditional, clamped: see load_span)
+                    const int j = j0 + u * 64, jc = j < T ? j : T - 1;
+                    if (MODE == 0) cv[r][u] = crow[jc];
+                    else pv[r][u] = prow[jc];
                 }
             }
             load_span();
@@ -718,14 +722,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &
         const int o = lane;
         const Real *row = cs + (size_t)o * RS;
         const Real *xw = xs + (my_n0 - nfirst); // this output's window inside the shared span
+        // (blocks of UNR*V taps, all LDS reads of a block in front of its FMAs.  Reading block k+1 during the FMAs
+        //  of block k — ping-pong registers — came out slower, 3.5-4.8 vs 2.6 us for 368 taps: a wave can wait on
+        //  at most 15 outstanding LDS reads, and the compiler's schedule of the two-block body was worse)
         constexpr int UNR = 8;
+        typedef typename VecN<Real, V>::type CV;
         if (wave == 0) {
             int i = 0;
             for (; i + UNR * V <= H; i += UNR * V) {
                 Real c[UNR * V], x[UNR * V];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    *reinterpret_cast<typename VecN<Real, V>::type *>(c + u * V) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i + u * V);
+                for (int u = 0; u < UNR; ++u) *reinterpret_cast<CV *>(c + u * V) = *reinterpret_cast<const CV *>(row + i + u * V);
 #pragma unroll
                 for (int v = 0; v < UNR * V; ++v) x[v] = xw[i + v];
 #pragma unroll
@@ -733,29 +740,24 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &
             }
             for (; i < H; i += V) { // taps i .. i+V-1, ascending
                 Real c[V];
-                *reinterpret_cast<typename VecN<Real, V>::type *>(c) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i);
+                *reinterpret_cast<CV *>(c) = *reinterpret_cast<const CV *>(row + i);
 #pragma unroll
                 for (int v = 0; v < V; ++v) acc = fma_r(c[v], xw[i + v], acc);
             }
         } else {
-            int i = T - V;
-            for (; i - (UNR - 1) * V >= H; i -= UNR * V) { // taps i+V-1 .. i-(UNR-1)V, descending
+            int i = T - UNR * V;
+            for (; i >= H; i -= UNR * V) { // taps i+UNR*V-1 .. i, descending
                 Real c[UNR * V], x[UNR * V];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    *reinterpret_cast<typename VecN<Real, V>::type *>(c + u * V) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i - u * V);
+                for (int u = 0; u < UNR; ++u) *reinterpret_cast<CV *>(c + u * V) = *reinterpret_cast<const CV *>(row + i + u * V);
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
+                for (int v = 0; v < UNR * V; ++v) x[v] = xw[i + v];
 #pragma unroll
-                    for (int v = 0; v < V; ++v) x[u * V + v] = xw[i - u * V + v];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                    for (int v = V - 1; v >= 0; --v) acc = fma_r(c[u * V + v], x[u * V + v], acc);
+                for (int v = UNR * V - 1; v >= 0; --v) acc = fma_r(c[v], x[v], acc);
             }
-            for (; i >= H; i -= V) { // taps i+V-1 .. i, descending
+            for (i += (UNR - 1) * V; i >= H; i -= V) { // taps i+V-1 .. i, descending
                 Real c[V];
-                *reinterpret_cast<typename VecN<Real, V>::type *>(c) = *reinterpret_cast<const typename VecN<Real, V>::type *>(row + i);
+                *reinterpret_cast<CV *>(c) = *reinterpret_cast<const CV *>(row + i);
 #pragma unroll
                 for (int v = V - 1; v >= 0; --v) acc = fma_r(c[v], xw[i + v], acc);
             }
@@ -835,7 +837,6 @@ __global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
     __shared__ uint64_t s_w[8];
     __shared__ unsigned long long s_old;
     __shared__ int s_state;
-    const uint32_t n_wgs = ra.n_wgs;
     const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
     unsigned long long n = 0; // messages this instance has completed
     long long t_idle = wall_clock64();
@@ -906,21 +907,15 @@ __global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
 #ifdef HIPSOXR_RES_TRACE
         const long long tr1 = wall_clock64();
 #endif
-        __threadfence_system(); // this workgroup's results are in host memory before it reports in
+        // this workgroup's results are in host memory before its word says so (the host waits for every word:
+        // no arrival counter, no device-wide atomic on the way out)
+        __threadfence_system();
         __syncthreads();
-#ifdef HIPSOXR_RES_TRACE
-        const long long tr2 = wall_clock64();
-#endif
         if (threadIdx.x == 0) {
-            const unsigned prev = __hip_atomic_fetch_add(&ra.ctl->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev == n_wgs - 1) { // the last one: everything is there
 #ifdef HIPSOXR_RES_TRACE
-                ra.box->pad[0] = (uint32_t)(tr0 - t_idle); ra.box->pad[1] = (uint32_t)(tr1 - tr0); ra.box->pad[2] = (uint32_t)(tr2 - tr1);
-                ra.box->pad[3] = (uint32_t)(wall_clock64() - tr2); ra.box->pad[4] = wg;
+            if (wg == 0) { ra.box->pad[0] = (uint32_t)(tr0 - t_idle); ra.box->pad[1] = (uint32_t)(tr1 - tr0); ra.box->pad[2] = (uint32_t)(wall_clock64() - tr1); }
 #endif
-                __hip_atomic_store(&ra.ctl->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ra.box->done, ra.base_seq + (uint32_t)n + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            __hip_atomic_store(&ra.box->done[wg], ra.base_seq + (uint32_t)n + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         ++n;
         t_idle = wall_clock64();
@@ -1938,7 +1933,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)rk, 256, lds));
                     HIP_TRY(hipGetDevice(&dev));
                     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-                    if ((int64_t)gx * gy > (int64_t)occ * cus / 4 || (int64_t)gx * gy > 64) return "resident kernel: message too large";
+                    if ((int64_t)gx * gy > (int64_t)occ * cus / 4 || (int64_t)gx * gy > (int64_t)kResidentMaxWgs) return "resident kernel: message too large";
                     ResidentArgs ra;
                     std::memset(&ra, 0, sizeof ra);
                     ra.ca = ca; ra.box = res->box; ra.ctl = res->ctl; ra.base_seq = res->base_seq; ra.epoch = res->epoch;
