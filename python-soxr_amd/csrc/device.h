@@ -35,6 +35,8 @@ struct ResidentBox {
 struct ResidentCtl { unsigned long long dec; unsigned arrived, pad; };
 struct ResidentLaunch {
     ResidentBox *box;      // pinned, device-mapped
+    const uint64_t *words; // where the instance reads the host -> device words: box->w, or 64 bytes of device memory
+                           // the CPU stores into directly (large-BAR systems: a shorter trip, see engine.cpp)
     ResidentCtl *ctl;      // device memory, zeroed, not used by an earlier instance
     uint32_t base_seq;     // messages taken by earlier instances
     uint32_t epoch;        // number of this instance (never 0)
@@ -45,8 +47,8 @@ struct ResidentLaunch {
 // job.out_frames = the largest message the instance must serve; launches nothing but the resident kernel
 const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream, const VrPos *vr = nullptr, ResidentLaunch *res = nullptr);
 // hand message `seq` to the instance: outputs [out_k0, out_k0 + out_frames) from ring frames [in_abs0, in_abs0 + in_frames)
-bool resident_post(const Plan &p, ResidentBox *box, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames);
-void resident_leave(ResidentBox *box, uint32_t epoch);
+bool resident_post(const Plan &p, volatile uint64_t *words, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames);
+void resident_leave(volatile uint64_t *words, uint32_t epoch);
 
 int device_count();
 
@@ -68,6 +70,7 @@ struct Switches {
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
     bool resident = false;        // HIPSOXR_RESIDENT         small-chunk synchronous streams use the resident kernel (as the HIPSOXR_RESIDENT flag)
     int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
+    bool resident_no_bar = false; // HIPSOXR_RESIDENT_NO_BAR  mailbox words and input stay in pinned host memory even on large-BAR systems
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids
     bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp
     // timing experiments on the tile kernels (results may be wrong with dbg_flags != 0)

@@ -59,7 +59,7 @@ const Switches &switches()
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_small_3pass = on("HIPSOXR_FFT_SMALL_3PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
         w.no_planes = on("HIPSOXR_NO_PLANES");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.resident = on("HIPSOXR_RESIDENT");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.resident = on("HIPSOXR_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
@@ -821,6 +821,7 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
 struct ResidentArgs {
     ChainArgs ca;
     ResidentBox *box;
+    const uint64_t *words; // host -> device words (box->w, or device memory the CPU stores into)
     ResidentCtl *ctl;
     uint32_t base_seq; // messages taken by earlier instances
     uint32_t epoch;    // this instance
@@ -847,7 +848,7 @@ __global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
             int state;
             uint64_t v = 0;
             for (;;) {
-                if (lane < 6) v = __hip_atomic_load(&ra.box->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane < 6) v = __hip_atomic_load(&ra.words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const bool ok = lane >= 5 || (v >> 48) == want;
                 const uint64_t leave = __shfl(v, 5, 64);
                 if (__all(ok)) { state = 1; break; }
@@ -1936,7 +1937,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     if ((int64_t)gx * gy > (int64_t)occ * cus / 4 || (int64_t)gx * gy > (int64_t)kResidentMaxWgs) return "resident kernel: message too large";
                     ResidentArgs ra;
                     std::memset(&ra, 0, sizeof ra);
-                    ra.ca = ca; ra.box = res->box; ra.ctl = res->ctl; ra.base_seq = res->base_seq; ra.epoch = res->epoch;
+                    ra.ca = ca; ra.box = res->box; ra.words = res->words; ra.ctl = res->ctl; ra.base_seq = res->base_seq; ra.epoch = res->epoch;
                     ra.idle_ticks = res->idle_us * 100; // wall_clock64: 100 MHz
                     ra.n_wgs = gx * gy;
                     res->n_wgs = ra.n_wgs; res->max_out = (int64_t)gx * NO;
@@ -2213,7 +2214,7 @@ const char *stream_kernel(void *dst, const void *src, size_t bytes, int mode, vo
     return nullptr;
 }
 
-bool resident_post(const Plan &p, ResidentBox *box, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames)
+bool resident_post(const Plan &p, volatile uint64_t *w, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames)
 {
     const __int128 kM = (__int128)out_k0 * p.M;
     const int64_t d0 = (int64_t)(kM / p.L), p0 = (int64_t)(kM % p.L);
@@ -2222,16 +2223,22 @@ bool resident_post(const Plan &p, ResidentBox *box, uint32_t seq, int64_t in_abs
         (uint64_t)p0 >= (1u << 24) || (uint64_t)out_frames >= lim)
         return false;
     const uint64_t tag = (uint64_t)(seq & 0xffffu) << 48;
-    // (x86 keeps stores in order; the words validate themselves: k_chain_resident)
-    volatile uint64_t *w = box->w;
+    // the words validate themselves (k_chain_resident): no order is needed among them — they may sit in
+    // write-combining device memory — only everything the message refers to must have left before them
+    __builtin_ia32_sfence();
     w[0] = tag | (uint64_t)in_abs0;
     w[1] = tag | (uint64_t)out_k0;
     w[2] = tag | (uint64_t)d0;
     w[3] = tag | ((uint64_t)in_frames << 24) | (uint64_t)p0;
-    __atomic_store_n(&box->w[4], tag | (uint64_t)out_frames, __ATOMIC_RELEASE);
+    w[4] = tag | (uint64_t)out_frames;
+    __builtin_ia32_sfence();
     return true;
 }
-void resident_leave(ResidentBox *box, uint32_t epoch) { __atomic_store_n(&box->w[5], (uint64_t)epoch, __ATOMIC_RELEASE); }
+void resident_leave(volatile uint64_t *w, uint32_t epoch)
+{
+    w[5] = (uint64_t)epoch;
+    __builtin_ia32_sfence();
+}
 
 const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr, ResidentLaunch *res)
 {
