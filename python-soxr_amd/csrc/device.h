@@ -44,8 +44,15 @@ struct ResidentLaunch {
     uint32_t n_wgs = 0;    // out: workgroups of the instance
     int64_t max_out = 0;   // out: outputs per column one message may ask for
 };
-// job.out_frames = the largest message the instance must serve; launches nothing but the resident kernel
-const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream, const VrPos *vr = nullptr, ResidentLaunch *res = nullptr);
+// Completion words for a small launch: if the job turns out to be ONE launch of the small-launch kernel (k_chain) of at
+// most `cap` workgroups, each workgroup stores `seq` into words[w] (pinned host memory) after its results are in host
+// memory, and n_wgs says how many words to wait for; otherwise n_wgs = 0 and the caller waits for the stream.
+// Polling these costs nothing; an event costs a record call, the command processor's signal after the kernel has
+// drained, and the query calls (~4 us per streaming call).
+struct ChainDone { uint32_t *words; uint32_t cap, seq; uint32_t n_wgs = 0; };
+// res: job.out_frames = the largest message the instance must serve; launches nothing but the resident kernel
+const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream, const VrPos *vr = nullptr, ResidentLaunch *res = nullptr,
+                       ChainDone *cd = nullptr);
 // hand message `seq` to the instance: outputs [out_k0, out_k0 + out_frames) from ring frames [in_abs0, in_abs0 + in_frames)
 bool resident_post(const Plan &p, volatile uint64_t *words, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames);
 void resident_leave(volatile uint64_t *words, uint32_t epoch);
@@ -68,6 +75,7 @@ struct Switches {
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
+    bool no_done_words = false;   // HIPSOXR_NO_DONE_WORDS    streaming calls wait on an event, not on the kernel's completion words
     bool resident = false;        // HIPSOXR_RESIDENT         small-chunk synchronous streams use the resident kernel (as the HIPSOXR_RESIDENT flag)
     int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
     bool resident_no_bar = false; // HIPSOXR_RESIDENT_NO_BAR  mailbox words and input stay in pinned host memory even on large-BAR systems

@@ -96,6 +96,8 @@ struct hipsoxr_stream {
     void *h_in = nullptr, *h_out = nullptr;
     size_t h_in_bytes = 0, h_out_bytes = 0;
     hipEvent_t ev = nullptr; // completion of a call's last operation (see stream_wait)
+    uint32_t *h_done = nullptr; // pinned: completion words of small launches (ChainDone, device.h)
+    uint32_t done_seq = 0;
     // Deferred output (HIPSOXR_DEFER): a call enqueues its copy and launch and returns the PREVIOUS call's
     // result, which finished long ago — no GPU round trip inside the call (see stream_process_deferred)
     bool defer = false;
@@ -644,6 +646,7 @@ static const char *stream_emit(hipsoxr_stream *s, void *out, size_t olen, size_t
 // Synchronous small chunk through the resident kernel: post the call's numbers, spin on the answer.
 // Returns nullptr with *served = false when this call has to take the ordinary path.
 static const size_t kCtlSlots = 1024;
+static const uint32_t kDoneWords = 64; // (larger launches: an event — 200 workgroups reporting one by one took 10 us longer than it)
 static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool *served)
 {
     hipsoxr_stream::Resident &r = s->res;
@@ -793,6 +796,8 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     if (s->in_fill == 0) { // nothing staged yet (e.g. flush of an empty stream): any valid pointer
         j.in = s->d_out;
     }
+    ChainDone cd;
+    cd.words = nullptr; cd.cap = 0; cd.seq = 0;
     bool served = false;
     if (s->resident && s->ring_on_host && direct && !v.on && !s->split && s->in_fill > 0 && n <= 2048) {
         if (const char *e = resident_emit(s, j, &served)) return e;
@@ -808,9 +813,26 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
         VrPos vp = {(uint64_t)((u128)T0 >> 64), (uint64_t)(u128)T0, (uint64_t)((u128)S0 >> 64), (uint64_t)(u128)S0,
                     (uint64_t)((u128)D >> 64), (uint64_t)(u128)D};
         if (const char *e = launch_job(&s->plan->p, j, s->st, &vp)) return e;
-    } else if (const char *e = launch_job(&s->plan->p, j, s->st)) return e;
+    } else {
+        if (direct && !s->h_done && !switches().no_done_words &&
+            hipHostMalloc((void **)&s->h_done, kDoneWords * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess)
+            std::memset(s->h_done, 0, kDoneWords * sizeof(uint32_t));
+        cd.words = s->h_done; cd.cap = s->h_done && direct ? kDoneWords : 0; cd.seq = ++s->done_seq;
+        if (const char *e = launch_job(&s->plan->p, j, s->st, nullptr, nullptr, cd.cap ? &cd : nullptr)) return e;
+    }
     if (direct) {
-        HIP_TRY(stream_wait(s));
+        bool seen = false;
+        if (cd.n_wgs) { // the kernel reports by itself (ChainDone): no event
+            volatile uint32_t *w = cd.words;
+            unsigned next = 0;
+            for (uint64_t spin = 0; spin < (1ULL << 22); ++spin) { // (~10 ms: then the ordinary wait, which also reports errors)
+                while (next < cd.n_wgs && w[next] == cd.seq) ++next;
+                if (next == cd.n_wgs) { seen = true; break; }
+                __builtin_ia32_pause();
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        if (!seen) HIP_TRY(stream_wait(s));
         if (!s->split) {
             std::memcpy(out, s->h_out, out_bytes);
         } else {
@@ -1026,6 +1048,7 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
     resident_stop(s);
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->res.box) (void)hipHostFree(s->res.box);
+    if (s->h_done) (void)hipHostFree(s->h_done);
     if (s->res.words_dev) (void)hipFree(s->res.words_dev);
     if (s->res.mirror) (void)hipFree(s->res.mirror);
     if (s->res.ctl) (void)hipFree(s->res.ctl);

@@ -59,7 +59,7 @@ const Switches &switches()
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_small_3pass = on("HIPSOXR_FFT_SMALL_3PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
         w.no_planes = on("HIPSOXR_NO_PLANES");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.resident = on("HIPSOXR_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
@@ -571,6 +571,8 @@ struct ChainArgs {
     const void *phase_major; // exact plans: [L][T] Real
     int32_t NO;              // outputs per workgroup (power of two, <= 32)
     int32_t span_cap;        // LDS room for the shared input span, in samples
+    uint32_t *done_words;    // (optional, pinned host memory) workgroup w stores done_seq into done_words[w] once its
+    uint32_t done_seq;       //  results are in host memory: the host polls these instead of an event (ChainDone)
 };
 
 // what changes from one launch (or one message to the resident form, below) to the next
@@ -788,6 +790,12 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
     const GatherArgs &g = ca.ia.g;
     const ChainMsg m = {g.in_abs0, g.in_frames, g.out_k0, g.out_frames, g.d0, g.p0};
     chain_body<IO, Real, MODE>(ca, m, blockIdx.x, blockIdx.y, smem_raw);
+    if (ca.done_words) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&ca.done_words[blockIdx.y * gridDim.x + blockIdx.x], ca.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1829,8 +1837,10 @@ void device_bank_release(Plan *p)
 // launch
 // ---------------------------------------------------------------------------------------------
 template <typename IO, typename Real>
-static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr = nullptr, ResidentLaunch *res = nullptr)
+static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr = nullptr, ResidentLaunch *res = nullptr,
+                                 ChainDone *cd = nullptr)
 {
+    if (cd) cd->n_wgs = 0;
     const DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
     // split so that idx*M stays far below 2^63 and grid.x below 2^31
     const int64_t max_chunk = (int64_t)1 << 30;
@@ -1947,6 +1957,13 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 }
                 if (lds > 64 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                {
+                    const uint64_t wgs = (uint64_t)((nf + NO - 1) / NO) * ((uint64_t)j.n_clips * j.n_channels);
+                    if (cd && done == 0 && nf == j.out_frames && wgs <= cd->cap) { // the whole job is this launch
+                        ca.done_words = cd->words; ca.done_seq = cd->seq;
+                        cd->n_wgs = (uint32_t)wgs;
+                    }
+                }
                 hipLaunchKernelGGL(ck, dim3((unsigned)((nf + NO - 1) / NO), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1),
                                    dim3(256), lds, st, ca);
                 HIP_TRY(hipGetLastError());
@@ -2151,7 +2168,8 @@ static const char *launch_wave_dot(Plan *p, const hipsoxr_job_t &j, hipStream_t 
 }
 
 template <typename IO, typename Real>
-static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr, ResidentLaunch *res = nullptr)
+static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr, ResidentLaunch *res = nullptr,
+                                ChainDone *cd = nullptr)
 {
     if (res) return launch_gather<IO, Real>(p, j, st, vr, res);
     const int prec = sizeof(Real) == 4 ? 0 : 1;
@@ -2167,7 +2185,7 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st,
     if (p->phases) { // interpolated-phase plan: one kernel (k_interp, dispatched by launch_gather)
         if (kernel != HIPSOXR_KERNEL_AUTO && kernel != HIPSOXR_KERNEL_GATHER)
             return "tile kernel unavailable for this plan";
-        return launch_gather<IO, Real>(p, j, st, vr);
+        return launch_gather<IO, Real>(p, j, st, vr, nullptr, cd);
     }
     if (vr) return "variable-rate needs an interpolated-phase plan";
     if (kernel == HIPSOXR_KERNEL_TILE_VALU && !gv.ok) return "tile kernel unavailable for this plan";
@@ -2184,7 +2202,7 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st,
     }
     if (kernel == HIPSOXR_KERNEL_TILE_MFMA) return launch_tile<IO, Real>(p, j, st, gm);
     if (kernel == HIPSOXR_KERNEL_TILE_VALU) return launch_tile<IO, Real>(p, j, st, gv);
-    return launch_gather<IO, Real>(p, j, st);
+    return launch_gather<IO, Real>(p, j, st, nullptr, nullptr, cd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2240,8 +2258,9 @@ void resident_leave(volatile uint64_t *w, uint32_t epoch)
     __builtin_ia32_sfence();
 }
 
-const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr, ResidentLaunch *res)
+const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr, ResidentLaunch *res, ChainDone *cd)
 {
+    if (cd) cd->n_wgs = 0;
     if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return res ? "resident kernel: empty job" : nullptr;
     if (res && (uint64_t)j.n_clips * j.n_channels > 65535) return "resident kernel: too many columns";
     // Kernels index (clip, channel) columns through grid.y (<= 65535).  Wider jobs — the Python surface
@@ -2304,10 +2323,10 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     }
     hipStream_t st = (hipStream_t)stream;
     switch (j.elem) {
-    case HIPSOXR_F32: return launch_typed<float, float>(p, j, st, vr, res);
-    case HIPSOXR_F64: return launch_typed<double, double>(p, j, st, vr, res);
-    case HIPSOXR_I32: return launch_typed<int32_t, double>(p, j, st, vr, res);
-    case HIPSOXR_I16: return launch_typed<int16_t, float>(p, j, st, vr, res);
+    case HIPSOXR_F32: return launch_typed<float, float>(p, j, st, vr, res, cd);
+    case HIPSOXR_F64: return launch_typed<double, double>(p, j, st, vr, res, cd);
+    case HIPSOXR_I32: return launch_typed<int32_t, double>(p, j, st, vr, res, cd);
+    case HIPSOXR_I16: return launch_typed<int16_t, float>(p, j, st, vr, res, cd);
     }
     return "invalid element type";
 }
