@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -150,6 +151,12 @@ struct DeviceGuard {
 // Wait for everything queued on the stream.  A chunked call is a 20-30 us round trip on the GPU;
 // the runtime's blocking hipStreamSynchronize adds an interrupt-and-wake-up latency of the same
 // order, so the first ~100 us are spent polling an event instead.
+// Resident kernels hold workgroup slots for as long as they live, and one that cannot get its slots keeps its
+// host waiting: the process admits at most kResidentBudget resident workgroups at a time (a stream over the
+// budget simply takes the ordinary path for that call and tries again later).
+static std::atomic<int> g_resident_wgs{0};
+static const int kResidentBudget = 512;
+
 // Retire the stream's resident kernel, if one is running: everything else that uses the HIP stream queues
 // behind it (and would wait until it leaves by itself, HIPSOXR_RESIDENT_IDLE_US later).
 static void resident_stop(hipsoxr_stream *s)
@@ -158,6 +165,7 @@ static void resident_stop(hipsoxr_stream *s)
     resident_leave(s->res.words, s->res.epoch);
     (void)hipStreamSynchronize(s->st);
     s->res.running = false;
+    g_resident_wgs -= (int)s->res.n_wgs;
 }
 
 static hipError_t stream_wait(hipsoxr_stream *s)
@@ -695,11 +703,13 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
         rl.epoch = r.epoch; rl.idle_us = std::max(50, switches().resident_idle_us);
         hipsoxr_job_t cap = jr; // room for chunks a quarter longer than this one
         cap.out_frames = std::max<int64_t>(64, j.out_frames + j.out_frames / 4 + 2);
+        if (g_resident_wgs.load() >= kResidentBudget) return ""; // (over the budget: the ordinary path, this time)
         if (const char *e = launch_job(&s->plan->p, cap, s->st, nullptr, &rl)) {
             (void)e; // not a job the resident form serves: the ordinary path does
             ++r.failed;
             return "";
         }
+        g_resident_wgs += (int)rl.n_wgs;
         r.running = true; r.in = jr.in; r.out = j.out; r.max_out = rl.max_out; r.n_wgs = rl.n_wgs; r.failed = 0;
         return nullptr;
     };
@@ -721,9 +731,12 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
             // instance takes it.  (An instance answers a message completely or not at all: k_chain_resident.)
             (void)hipStreamSynchronize(s->st);
             r.running = false;
+            g_resident_wgs -= (int)r.n_wgs;
             while (next < r.n_wgs && done[next] == seq) ++next;
             if (next == r.n_wgs) break;
-            if (const char *e = launch(seq - 1)) return *e ? e : "resident kernel: relaunch refused";
+            // (refused — over the budget, say: nobody has touched the message, the ordinary path serves this call;
+            //  a later instance starts behind it, at r.seq, and ignores the stale words)
+            if (const char *e = launch(seq - 1)) return *e ? e : nullptr;
             next = 0;
         }
         __builtin_ia32_pause();

@@ -95,3 +95,17 @@ def test_resident_many_streams_at_once(soxr):
             parts[k].append(rs.resample_chunk(x[a:a + 480], last=(a + 480 >= len(x))))
     for p in parts:
         assert np.array_equal(np.concatenate(p), want)
+
+
+def test_resident_budget(soxr):
+    """More resident streams than the process admits resident workgroups for (512; a 480-frame-chunk stream holds
+    ~70): the ones over the budget run on the ordinary path, every stream's output is the same."""
+    x = _signal(np.float32, 6000, 1, 45)
+    want = np.concatenate(_run(soxr.ResampleStream(48000, 44100, 1, quality="HQ"), x, [480]))
+    streams = [soxr.ResampleStream(48000, 44100, 1, quality="HQ", resident=True) for _ in range(24)]
+    parts = [[] for _ in streams]
+    for a in range(0, len(x), 480):
+        for k, rs in enumerate(streams):
+            parts[k].append(rs.resample_chunk(x[a:a + 480], last=(a + 480 >= len(x))))
+    for p in parts:
+        assert np.array_equal(np.concatenate(p), want)
