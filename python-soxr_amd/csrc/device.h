@@ -80,6 +80,7 @@ struct Switches {
     int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
     bool resident_no_bar = false; // HIPSOXR_RESIDENT_NO_BAR  mailbox words and input stay in pinned host memory even on large-BAR systems
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids
+    bool no_tile_split = false;   // HIPSOXR_NO_TILE_SPLIT    k_tile / k_tile_mfma: never spread a slab's row tiles over several workgroups
     bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp
     // timing experiments on the tile kernels (results may be wrong with dbg_flags != 0)
     int dbg_flags = 0;            // HIPSOXR_DEBUG_FLAGS      1 no staging, 2 no LDS reads, 4 no coefficient loads, 8 no stores

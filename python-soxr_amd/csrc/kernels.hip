@@ -59,7 +59,7 @@ const Switches &switches()
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_small_3pass = on("HIPSOXR_FFT_SMALL_3PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
         w.no_planes = on("HIPSOXR_NO_PLANES");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
@@ -1057,7 +1057,7 @@ __global__ void __launch_bounds__(1024) k_tile(TileArgs a)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_waves = a.n_waves; // == blockDim.x / 64, passed as an argument so it stays scalar
+    const int n_waves = a.n_waves; // waves that compute (all of them, or the first few of a split slab's workgroup: launch_tile)
     const Real *xl = xs + lane * (Mc + pad);
     const int64_t b = bw + lane; // this lane's period
     typedef const __attribute__((address_space(4))) Real *CPtr;
@@ -1067,7 +1067,8 @@ __global__ void __launch_bounds__(1024) k_tile(TileArgs a)
     IO *const yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs +
                    (b * a.Lc - a.out_k0) * a.ofs; // this lane's period start (may be out of range)
 
-    for (int rt_ = wave; rt_ < a.n_rt; rt_ += n_waves) {
+    // (few slabs: the row tiles of a slab are spread over gridDim.z workgroups, each staging the slab — launch_tile)
+    for (int rt_ = wave < n_waves ? wave + n_waves * (int)blockIdx.z : a.n_rt; rt_ < a.n_rt; rt_ += n_waves * (int)gridDim.z) {
         // keep the tile index (and everything derived from it) provably wave-uniform: the
         // coefficient loads below must be scalar (s_load), not per-lane
         const int rt = __builtin_amdgcn_readfirstlane(rt_);
@@ -1198,7 +1199,7 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
     const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
     IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
 
-    for (int rt_ = wave; rt_ < a.n_rt; rt_ += n_waves) {
+    for (int rt_ = wave < n_waves ? wave + n_waves * (int)blockIdx.z : a.n_rt; rt_ < a.n_rt; rt_ += n_waves * (int)gridDim.z) { // (gridDim.z: see k_tile)
         const int rt = __builtin_amdgcn_readfirstlane(rt_);
         const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]);
         const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
@@ -1997,6 +1998,9 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     const int64_t bytes = span_cap * (int64_t)sizeof(Real) + k * 10 + (2 * p->phases + 2) * 4 + 64;
                     if (bytes <= 150 * 1024) KO = k;
                 }
+                // ... which pays off once the launch fills the chip: one column of a stream chunk is a handful of such
+                // workgroups (96 000-frame chunk, 7 workgroups: 1.5 ms, where lane-per-output k_interp takes 0.1)
+                if (KO && (nf + KO - 1) / KO * (int64_t)j.n_clips * j.n_channels < 128) KO = 0;
             }
             if (KO) {
                 InterpTileArgs ta;
@@ -2106,6 +2110,16 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         }
     } else {
         a.xz = 0; a.nx = (int32_t)n_blocks;
+        // few slabs (one column of a stream chunk: 96 000 frames at 44.1k -> 16k are 4 slabs on 256 CUs): the
+        // row tiles of a slab go to several workgroups of fewer waves, each staging the slab for itself
+        const int64_t wgs = n_blocks * (int64_t)cols;
+        if (wgs < 128 && g.n_rt > 1 && !switches().dbg_nw && !switches().no_tile_split) {
+            const int per_wg = g.n_rt >= 8 && wgs * g.n_rt > 256 ? 2 : 1; // row tiles (= waves) per workgroup
+            nw = per_wg; a.n_waves = nw;
+            block = dim3(256); // (four waves stage the slab; the first per_wg of them compute)
+            grid.z = (unsigned)((g.n_rt + per_wg - 1) / per_wg);
+        }
+        if (switches().dbg_split) grid.z = (unsigned)switches().dbg_split;
     }
     size_t lds_bytes = g.lds_bytes;
     lds_bytes = std::max<size_t>(lds_bytes, switches().dbg_lds); // occupancy experiments
