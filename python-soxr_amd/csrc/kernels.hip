@@ -2111,15 +2111,18 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     } else {
         a.xz = 0; a.nx = (int32_t)n_blocks;
         // few slabs (one column of a stream chunk: 96 000 frames at 44.1k -> 16k are 4 slabs on 256 CUs): the
-        // row tiles of a slab go to several workgroups of fewer waves, each staging the slab for itself
+        // row tiles of a slab go to several workgroups of fewer computing waves, each staging the slab for itself
         const int64_t wgs = n_blocks * (int64_t)cols;
-        if (wgs < 128 && g.n_rt > 1 && !switches().dbg_nw && !switches().no_tile_split) {
-            const int per_wg = g.n_rt >= 8 && wgs * g.n_rt > 256 ? 2 : 1; // row tiles (= waves) per workgroup
+        int split = 1;
+        // (as many workgroups as fill the chip once: every one of them stages the whole slab)
+        if (wgs < 128 && g.n_rt > 1 && !switches().dbg_nw && !switches().no_tile_split) split = (int)std::min<int64_t>(g.n_rt, 256 / wgs);
+        if (switches().dbg_split) split = std::min(switches().dbg_split, g.n_rt);
+        if (split > 1) {
+            const int per_wg = (g.n_rt + split - 1) / split; // row tiles (= computing waves) per workgroup
             nw = per_wg; a.n_waves = nw;
-            block = dim3(256); // (four waves stage the slab; the first per_wg of them compute)
+            block = dim3((unsigned)std::max(256, 64 * per_wg)); // (at least four waves stage the slab)
             grid.z = (unsigned)((g.n_rt + per_wg - 1) / per_wg);
         }
-        if (switches().dbg_split) grid.z = (unsigned)switches().dbg_split;
     }
     size_t lds_bytes = g.lds_bytes;
     lds_bytes = std::max<size_t>(lds_bytes, switches().dbg_lds); // occupancy experiments
