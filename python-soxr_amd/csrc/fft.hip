@@ -909,6 +909,108 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Paired kernel, second generation, CHANNEL-PAIR mode: interleaved data with an even channel count.
+// The two real signals of a transform are the same block of two neighbouring channels — one aligned (Real, Real)
+// word per frame — and the workgroup ids are XCD-aware, exactly as in k_fft_pair (see there).  What differs is how
+// HBM is touched, as in k_fft_pair2: one raw buffer load per element (8 or 16 bytes; descriptor over [first frame
+// of the block, end of the column), hardware range check instead of per-element bounds code, the per-butterfly
+// offset t*N/R0*frame in the instruction's scalar operand) and one range-checked buffer store per kept output.
+// The first-generation kernel spent a third of its time on the address arithmetic and bounds code of these loads:
+// configs[2] (8 channels) 61.4 -> see DESIGN.md §6; the same 61 us at 2 channels, where every byte of every line
+// fetched is used, which is what ruled the data layout out as the cause.
+// ---------------------------------------------------------------------------------------------
+template <typename Real> struct CpIo;
+template <> struct CpIo<float> {
+    static __device__ __forceinline__ float2 load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ void store(float2 v, __amdgpu_buffer_rsrc_t r, int voff)
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), r, voff, 0, 0);
+    }
+};
+template <> struct CpIo<double> {
+    static __device__ __forceinline__ double2 load(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ void store(double2 v, __amdgpu_buffer_rsrc_t r, int voff)
+    {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), r, voff, 0, 0);
+    }
+};
+
+template <typename Spec, typename Real>
+__global__ void __launch_bounds__(Spec::NT) k_fft_chpair2(FftArgs a)
+{
+    typedef typename PairTabs<Real>::C C;
+    constexpr int ES = (int)sizeof(Real);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C *cur = reinterpret_cast<C *>(smem_raw);
+    constexpr int NA = Spec::NA, NB = Spec::NB, nbA = NA / Spec::RA0;
+#ifdef FFT2_TRACE
+    unsigned long long *g_tr = nullptr;
+    int g_tri = 0;
+#endif
+    // XCD-aware ids (k_fft_pair): x = 8 * slot + xcd, slot = chunk * pairs + pair, block = 8 * chunk + xcd
+    const uint32_t cpr = a.n_channels / 2;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t cu = __builtin_amdgcn_readfirstlane(slot % cpr);
+    const uint32_t clip = blockIdx.y;
+    const int64_t bx = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((slot / cpr) * 8 + xcd);
+    if (bx >= a.pairs_per_col) return; // grid.x is padded to a multiple of 8 blocks per channel pair
+    const int64_t pa = bx * a.hop_periods - a.lead_periods; // first period of the block
+    const int64_t ina = pa * a.M, outa = pa * a.L;
+    const Real *xin = (const Real *)a.in + (int64_t)clip * a.ics + (int64_t)(2 * cu) * a.ichs;
+    const int32_t ifb = (int32_t)a.ifs * ES, ofb = (int32_t)a.ofs * ES; // bytes per frame (launcher: N * frame < 2^30)
+    auto lds_store = [&](int n, C v) { cur[n] = v; };
+    typename Spec::Tw tw;
+
+    // ---- forward: z[n] = x_c[n] + i x_{c+1}[n], first pass straight from HBM ------------------------
+    if (ina >= 0) {
+        const int64_t left = (a.in_frames - ina) * (int64_t)ifb; // bytes from the block's first frame to the end of the column
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(xin + ina * a.ifs), 0, (int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left), 0x00020000);
+        const int32_t stepb = nbA * ifb; // one butterfly input further: N/R0 frames
+        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int t) -> C {
+            return CpIo<Real>::load(rs, (n - t * nbA) * ifb, t * stepb);
+        }, lds_store, false, tw);
+    } else { // the first block of a column reaches before its start: explicit zero-extension
+        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int) -> C {
+            const int64_t l = ina + n;
+            if (l < 0 || l >= a.in_frames) return C((Real)0, (Real)0);
+            return *reinterpret_cast<const C *>(xin + l * a.ifs);
+        }, lds_store, false, tw);
+    }
+    __syncthreads();
+
+    // ---- inverse (see k_fft_pair2), outputs straight to HBM: frame outa + n holds (y_c, y_{c+1}) ----
+    const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out;
+    Real *ybase = (Real *)a.out + (int64_t)clip * a.ocs + (int64_t)(2 * cu) * a.ochs + (outa + v0) * a.ofs; // outa + v0 >= 0
+    const int64_t oleft = (a.out_frames - (outa + v0)) * (int64_t)ofb;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)ybase, 0, (int)(oleft < 0 ? 0 : oleft > 0x40000000 ? 0x40000000 : oleft), 0x00020000);
+    const Real *Hr = PairTabs<Real>::hr(a);
+    auto h_load = [&](int n, int) -> C {
+        const bool neg = n > NB / 2;
+        const int q = neg ? NB - n : n; // |frequency| in bins
+        const Real h = Hr[q];
+        if constexpr (NA >= NB) {
+            const C x = cur[neg ? n + (NA - NB) : n];
+            return C(x.x * h, x.y * h);
+        } else {
+            const bool in_band = q < NA / 2;
+            const C x = cur[in_band ? (neg ? NA - q : q) : 0];
+            return in_band ? C(x.x * h, x.y * h) : C((Real)0, (Real)0);
+        }
+    };
+    Spec::inv(FFT_STAMP_ARGS cur, PairTabs<Real>::wb(a), h_load, [&](int n, C w) {
+        if (n >= v0 && n < v1) CpIo<Real>::store(w, ro, (n - v0) * ofb);
+    }, true, tw);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host: geometry, tables
 // ---------------------------------------------------------------------------------------------
 struct FftGeom {
@@ -1068,9 +1170,13 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         return nullptr;
     };
     // ---- paired-block kernels: compile-time schedules for the common ratios -------------------
-    struct PairEntry { int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); void (*kern2d)(FftArgs); };
+    struct PairEntry {
+        int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); void (*kern2d)(FftArgs);
+        void (*kcp)(FftArgs); void (*kcpd)(FftArgs); // channel-pair mode (interleaved data), float32 / float64
+    };
 #define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) \
-    {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>}
+    {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>, \
+     k_fft_chpair2<PairOf<NA, NB, NT>, float>, k_fft_chpair2<PairOf<NA, NB, NT>, double>}
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
         HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
@@ -1092,7 +1198,10 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     const bool no_pair = switches().fft_no_pair;
     const uint64_t cols_p = (uint64_t)j.n_clips * j.n_channels;
     const bool f64 = j.elem == HIPSOXR_F64;
-    if (f64 && (no_pair || cols_p > 65535 || j.in_frame_stride != 1 || j.out_frame_stride != 1)) return nullptr; // exact engine
+    // float64: unit-stride columns, or interleaved data with an even channel count (channel pairs); else the exact engine
+    const bool f64_layout = (j.in_frame_stride == 1 && j.out_frame_stride == 1) ||
+                            (j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1);
+    if (f64 && (no_pair || cols_p > 65535 || !f64_layout)) return nullptr;
     if (!no_pair && cols_p <= 65535) {
         const PairEntry *big = nullptr, *sml = nullptr;
         int big_i = 0, sml_i = 0;
@@ -1121,7 +1230,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             // Latency-bound jobs (everything resident at once, about one workgroup per CU slot):
             // the four-pass schedule with prefetched tables has the shorter critical path (7.1 vs
             // 9.0 us for one workgroup); from ~400 workgroups on, the three-pass one wins on work.
-            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr};
+            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr};
             if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && !switches().fft_small_3pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
                 if (wgs < 400 && !f64) use = &low_latency;
@@ -1144,10 +1253,16 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const int64_t n_blocks = (j.out_frames + g.hop_out - 1) / g.hop_out;
                 if (n_blocks > 2147483647LL) return "job too long for one launch";
                 // interleaved data with an even channel count: pair channels (aligned float2 per frame)
+                const size_t esz = f64 ? sizeof(double) : sizeof(float);
                 a.chpair = (j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1 &&
                             j.in_frame_stride % 2 == 0 && j.out_frame_stride % 2 == 0 && j.in_clip_stride % 2 == 0 &&
-                            j.out_clip_stride % 2 == 0 && ((uintptr_t)j.in & 7) == 0 && ((uintptr_t)j.out & 7) == 0 &&
-                            !switches().fft_no_chpair && !f64) ? 1 : 0;
+                            j.out_clip_stride % 2 == 0 && ((uintptr_t)j.in & (2 * esz - 1)) == 0 && ((uintptr_t)j.out & (2 * esz - 1)) == 0 &&
+                            !switches().fft_no_chpair) ? 1 : 0;
+                // ... with the second-generation channel-pair kernel when a block's byte offsets fit its 32-bit operands
+                // (float64 has no first-generation kernel: it pairs channels through this one or not at all)
+                const bool cp2 = (f64 ? use->kcpd : use->kcp) != nullptr && !switches().fft_pair_v1 &&
+                                 (int64_t)std::max(g.N_in, g.N_out) * std::max(j.in_frame_stride, j.out_frame_stride) * (int64_t)esz < (1LL << 30);
+                if (f64 && !cp2) a.chpair = 0;
                 const size_t lds = std::max((size_t)std::max(g.N_in, g.N_out) * (f64 ? sizeof(double2) : sizeof(float2)), switches().dbg_fft_lds);
                 if (f64 && lds > 160 * 1024) return nullptr;
                 if (lds > 64 * 1024)
@@ -1156,17 +1271,22 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const int64_t items = a.chpair ? n_blocks : (n_blocks + 1) / 2, items8 = (items + 7) / 8 * 8;
                 const int64_t units = a.chpair ? j.n_channels / 2 : j.n_channels;
                 a.xcd_map = (j.n_channels > 1 && j.in_chan_stride == 1 && j.out_chan_stride == 1 && j.n_clips <= 65535 &&
-                             items8 * units <= 2147483647LL && !switches().fft_no_xcd_map && !f64) ? 1 : 0;
-                if (a.chpair && !a.xcd_map) a.chpair = 0; // (channel pairing is only laid out through the XCD map)
+                             items8 * units <= 2147483647LL && !switches().fft_no_xcd_map && (!f64 || a.chpair)) ? 1 : 0;
+                if (a.chpair && !a.xcd_map) return f64 ? nullptr : "internal: channel pairing needs the XCD map"; // (decided before the work items were counted)
                 a.pairs_per_col = items;
                 const dim3 grid = a.xcd_map ? dim3((unsigned)(items8 * units), j.n_clips, 1)
                                             : dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols_p, 1);
                 // unit-stride columns (mono / planar): the second-generation kernel (buffer loads, staged aligned stores)
                 void (*kern)(FftArgs) = use->kern;
-                const size_t esz = f64 ? sizeof(double) : sizeof(float);
                 const bool v2ok = use->kern2 && !a.xcd_map && !a.chpair && j.in_frame_stride == 1 && j.out_frame_stride == 1 &&
                                   2 * (size_t)g.hop_out * esz + 16 <= lds;
-                if (f64 && !v2ok) return nullptr; // (no float64 instance of the first-generation kernel: exact engine)
+                const bool cp2ok = a.chpair && a.xcd_map && cp2;
+                if (f64 && !v2ok && !cp2ok) return nullptr; // (no float64 instance of the first-generation kernel: exact engine)
+                if (cp2ok) {
+                    kern = f64 ? use->kcpd : use->kcp;
+                    if (lds > 64 * 1024)
+                        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                }
                 if (v2ok && (f64 || !switches().fft_pair_v1)) {
                     kern = f64 ? use->kern2d : use->kern2;
                     if (lds > 64 * 1024)
