@@ -39,7 +39,7 @@ KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, secon
 # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 +
 # WRITE_SIZE, see profiles/r02_traffic.json); bench.py cannot collect counters itself.
 TRAFFIC_BYTES = {("configs1", 0): 23304192, ("configs1", 5): 23304192,
-                 ("batch_shard", 0): 480613990, ("batch_shard", 5): 480613990}  # profiles/r02_traffic.json
+                 ("batch_shard", 0): 480371917, ("batch_shard", 5): 480371917}  # profiles/r02_traffic.json
 # VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/r02_rocprofv3_summary.txt): the other
 # resource the frequency-domain kernel is limited by.  An fp32 wave-instruction occupies a SIMD for
 # 2 cycles (SIMD-32, wave64); 256 CUs x 4 SIMDs at 2.4 GHz.
@@ -463,7 +463,9 @@ def main():
                                               f"interleaved [frames, 8], device-resident",
                                   "value": x2.numel() / k2 / 1e6, "unit": "Msamples/s", "launch_us": k2 * 1e6,
                                   "roofline": {"bound": "hbm", "achieved": bytes2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
-                                               "unit": "GB/s", "frac": bytes2 / k2 / 1e9 / HBM_PEAK_GBS}}
+                                               "unit": "GB/s", "frac": bytes2 / k2 / 1e9 / HBM_PEAK_GBS,
+                                               "traffic": 137344922 if args.seconds == 60 else None,  # profiles/r02_traffic.json
+                                               "kernel": "k_fft_chpair2<4410x1600,float>"}}
             del x2, y2, plan2
         except RuntimeError as e:  # context only
             result["configs2"] = {"error": str(e)}
