@@ -646,6 +646,8 @@ static const char *stream_emit(hipsoxr_stream *s, void *out, size_t olen, size_t
         if (const char *e = stream_emit_once(s, o, olen - total, &got)) return e;
         total += got;
         if (!got) break;
+        // another pass only if this one stopped at the end of a slew (an empty pass costs a wait on the stream)
+        if (!(s->vr.n_slew && s->k_done == s->vr.k_s + s->vr.n_slew)) break;
     }
     *odone = total;
     return nullptr;
@@ -821,16 +823,16 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
         return nullptr;
     }
     resident_stop(s);
+    if (direct && !s->h_done && !switches().no_done_words &&
+        hipHostMalloc((void **)&s->h_done, kDoneWords * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess)
+        std::memset(s->h_done, 0, kDoneWords * sizeof(uint32_t));
+    cd.words = s->h_done; cd.cap = s->h_done && direct ? kDoneWords : 0; cd.seq = ++s->done_seq;
     if (v.on) {
         const i128 T0 = v.pos(s->k_done), S0 = v.step(s->k_done), D = s->k_done < v.k_s + v.n_slew ? v.delta : 0;
         VrPos vp = {(uint64_t)((u128)T0 >> 64), (uint64_t)(u128)T0, (uint64_t)((u128)S0 >> 64), (uint64_t)(u128)S0,
                     (uint64_t)((u128)D >> 64), (uint64_t)(u128)D};
-        if (const char *e = launch_job(&s->plan->p, j, s->st, &vp)) return e;
+        if (const char *e = launch_job(&s->plan->p, j, s->st, &vp, nullptr, cd.cap ? &cd : nullptr)) return e;
     } else {
-        if (direct && !s->h_done && !switches().no_done_words &&
-            hipHostMalloc((void **)&s->h_done, kDoneWords * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess)
-            std::memset(s->h_done, 0, kDoneWords * sizeof(uint32_t));
-        cd.words = s->h_done; cd.cap = s->h_done && direct ? kDoneWords : 0; cd.seq = ++s->done_seq;
         if (const char *e = launch_job(&s->plan->p, j, s->st, nullptr, nullptr, cd.cap ? &cd : nullptr)) return e;
     }
     if (direct) {
