@@ -109,3 +109,17 @@ def test_resident_budget(soxr):
             parts[k].append(rs.resample_chunk(x[a:a + 480], last=(a + 480 >= len(x))))
     for p in parts:
         assert np.array_equal(np.concatenate(p), want)
+
+
+def test_environment_switch_runs_the_stream_contract():
+    """HIPSOXR_RESIDENT in the environment turns every eligible stream of the process into a resident one (the way a
+    user of the libsoxr-named library would switch it on): the reference's behavioural contract and the stream parity
+    tests pass unchanged."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIPSOXR_RESIDENT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_reference_contract.py"),
+                        os.path.join(root, "tests", "test_soxr_abi.py")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
