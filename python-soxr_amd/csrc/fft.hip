@@ -1254,15 +1254,16 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 if (n_blocks > 2147483647LL) return "job too long for one launch";
                 // interleaved data with an even channel count: pair channels (aligned float2 per frame)
                 const size_t esz = f64 ? sizeof(double) : sizeof(float);
-                a.chpair = (j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1 &&
-                            j.in_frame_stride % 2 == 0 && j.out_frame_stride % 2 == 0 && j.in_clip_stride % 2 == 0 &&
-                            j.out_clip_stride % 2 == 0 && ((uintptr_t)j.in & (2 * esz - 1)) == 0 && ((uintptr_t)j.out & (2 * esz - 1)) == 0 &&
-                            !switches().fft_no_chpair) ? 1 : 0;
-                // ... with the second-generation channel-pair kernel when a block's byte offsets fit its 32-bit operands
-                // (float64 has no first-generation kernel: it pairs channels through this one or not at all)
+                const bool cp_layout = j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1 && !switches().fft_no_chpair;
+                // (the first-generation kernel reads the pair through a float2 pointer: every frame 8-byte aligned)
+                const bool cp_aligned = j.in_frame_stride % 2 == 0 && j.out_frame_stride % 2 == 0 && j.in_clip_stride % 2 == 0 &&
+                                        j.out_clip_stride % 2 == 0 && ((uintptr_t)j.in & (2 * esz - 1)) == 0 && ((uintptr_t)j.out & (2 * esz - 1)) == 0;
+                // ... the second-generation channel-pair kernel (buffer loads: element alignment is enough) when a block's
+                // byte offsets fit its 32-bit operands; float64 has no first-generation kernel and pairs channels
+                // through this one or not at all
                 const bool cp2 = (f64 ? use->kcpd : use->kcp) != nullptr && !switches().fft_pair_v1 &&
                                  (int64_t)std::max(g.N_in, g.N_out) * std::max(j.in_frame_stride, j.out_frame_stride) * (int64_t)esz < (1LL << 30);
-                if (f64 && !cp2) a.chpair = 0;
+                a.chpair = (cp_layout && (cp2 || (cp_aligned && !f64))) ? 1 : 0;
                 const size_t lds = std::max((size_t)std::max(g.N_in, g.N_out) * (f64 ? sizeof(double2) : sizeof(float2)), switches().dbg_fft_lds);
                 if (f64 && lds > 160 * 1024) return nullptr;
                 if (lds > 64 * 1024)

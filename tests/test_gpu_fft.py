@@ -205,3 +205,9 @@ def test_channel_pair_kernel(oracle, dtype, tol, in_rate, out_rate, ch):
         view = xt[:, :, 2:6]                                   # frame stride ch, 4 channels, 8/16-byte aligned start
         yv = dev.resample_tensor(plan, view, kernel=FFT).cpu().numpy()
         assert np.array_equal(yv, y[:, :, 2:6])
+    if ch >= 6:
+        view = xt[:, :, 1:5]                                   # pairs (1,2), (3,4): words aligned to the element only
+        yv = dev.resample_tensor(plan, view, kernel=FFT).cpu().numpy()
+        for clip in range(2):
+            ref = oracle.resample(x[clip][:, 1:5].astype(np.float64), in_rate, out_rate, "VHQ", mode="ref")
+            assert _rms(yv[clip] - ref) / _rms(ref) <= tol
