@@ -465,7 +465,7 @@ def main():
                                   "roofline": {"bound": "hbm", "achieved": bytes2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
                                                "unit": "GB/s", "frac": bytes2 / k2 / 1e9 / HBM_PEAK_GBS,
                                                "traffic": 137344922 if args.seconds == 60 else None,  # profiles/r02_traffic.json
-                                               "kernel": "k_fft_chpair2<4410x1600,float>"}}
+                                               "kernel": "k_fft_strided2<4410x1600,float,channel pairs>"}}
             del x2, y2, plan2
         except RuntimeError as e:  # context only
             result["configs2"] = {"error": str(e)}

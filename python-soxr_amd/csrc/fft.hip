@@ -785,6 +785,14 @@ template <> __device__ __forceinline__ double buf_load_real<double>(__amdgpu_buf
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+__device__ __forceinline__ void buf_store_real(float v, __amdgpu_buffer_rsrc_t r, int voff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store_real(double v, __amdgpu_buffer_rsrc_t r, int voff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), r, voff, 0, 0);
+}
 // per-precision views of the kernel arguments
 template <typename Real> struct PairTabs;
 template <> struct PairTabs<float> {
@@ -941,8 +949,11 @@ template <> struct CpIo<double> {
     }
 };
 
-template <typename Spec, typename Real>
-__global__ void __launch_bounds__(Spec::NT) k_fft_chpair2(FftArgs a)
+// CP = true: channel pairs (above).  CP = false: strided columns that cannot be paired by channel (odd channel counts
+// of interleaved data, a channel slice with a frame stride): two consecutive blocks of ONE column are paired, as in
+// k_fft_pair2, each element a 4/8-byte buffer load or store at the column's frame stride.
+template <typename Spec, typename Real, bool CP>
+__global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
 {
     typedef typename PairTabs<Real>::C C;
     constexpr int ES = (int)sizeof(Real);
@@ -953,41 +964,50 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_chpair2(FftArgs a)
     unsigned long long *g_tr = nullptr;
     int g_tri = 0;
 #endif
-    // XCD-aware ids (k_fft_pair): x = 8 * slot + xcd, slot = chunk * pairs + pair, block = 8 * chunk + xcd
-    const uint32_t cpr = a.n_channels / 2;
+    // XCD-aware ids (k_fft_pair): x = 8 * slot + xcd, slot = chunk * units + unit, item = 8 * chunk + xcd;
+    // or (a.xcd_map == 0: one column per grid row) items along x, columns along y
+    const uint32_t units = CP ? a.n_channels / 2 : a.n_channels;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t cu = __builtin_amdgcn_readfirstlane(slot % cpr);
-    const uint32_t clip = blockIdx.y;
-    const int64_t bx = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((slot / cpr) * 8 + xcd);
-    if (bx >= a.pairs_per_col) return; // grid.x is padded to a multiple of 8 blocks per channel pair
-    const int64_t pa = bx * a.hop_periods - a.lead_periods; // first period of the block
+    const bool xm = a.xcd_map != 0;
+    const uint32_t cu = __builtin_amdgcn_readfirstlane(xm ? slot % units : blockIdx.y % units);
+    const uint32_t clip = __builtin_amdgcn_readfirstlane(xm ? blockIdx.y : blockIdx.y / units);
+    const int64_t bx = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane(xm ? (slot / units) * 8 + xcd : blockIdx.x);
+    if (bx >= a.pairs_per_col) return; // grid.x is padded to a multiple of 8 items per unit
+    const uint32_t ch = CP ? 2 * cu : cu;
+    const int64_t pa = (CP ? 1 : 2) * bx * a.hop_periods - a.lead_periods; // first period of the (first) block
     const int64_t ina = pa * a.M, outa = pa * a.L;
-    const Real *xin = (const Real *)a.in + (int64_t)clip * a.ics + (int64_t)(2 * cu) * a.ichs;
-    const int32_t ifb = (int32_t)a.ifs * ES, ofb = (int32_t)a.ofs * ES; // bytes per frame (launcher: N * frame < 2^30)
+    const int32_t hop_in = (int32_t)(a.hop_periods * a.M), hop_out = a.hop_out;
+    const Real *xin = (const Real *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    const int32_t ifb = (int32_t)a.ifs * ES, ofb = (int32_t)a.ofs * ES; // bytes per frame (launcher: 2 N * frame < 2^30)
     auto lds_store = [&](int n, C v) { cur[n] = v; };
     typename Spec::Tw tw;
 
-    // ---- forward: z[n] = x_c[n] + i x_{c+1}[n], first pass straight from HBM ------------------------
+    // ---- forward: z[n] = x_c[n] + i x_{c+1}[n]  (CP)  or  x_a[n] + i x_b[n]  (two blocks), first pass straight from HBM
     if (ina >= 0) {
         const int64_t left = (a.in_frames - ina) * (int64_t)ifb; // bytes from the block's first frame to the end of the column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(xin + ina * a.ifs), 0, (int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left), 0x00020000);
         const int32_t stepb = nbA * ifb; // one butterfly input further: N/R0 frames
         Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int t) -> C {
-            return CpIo<Real>::load(rs, (n - t * nbA) * ifb, t * stepb);
+            if constexpr (CP) return CpIo<Real>::load(rs, (n - t * nbA) * ifb, t * stepb);
+            else return C(buf_load_real<Real>(rs, (n - t * nbA) * ifb, t * stepb), buf_load_real<Real>(rs, (n - t * nbA) * ifb, t * stepb + hop_in * ifb));
         }, lds_store, false, tw);
     } else { // the first block of a column reaches before its start: explicit zero-extension
         Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int) -> C {
-            const int64_t l = ina + n;
-            if (l < 0 || l >= a.in_frames) return C((Real)0, (Real)0);
-            return *reinterpret_cast<const C *>(xin + l * a.ifs);
+            const int64_t l = ina + n, lb = l + hop_in;
+            if constexpr (CP) {
+                if (l < 0 || l >= a.in_frames) return C((Real)0, (Real)0);
+                return C(xin[l * a.ifs], xin[l * a.ifs + 1]);
+            } else {
+                return C((l >= 0 && l < a.in_frames) ? xin[l * a.ifs] : (Real)0, (lb >= 0 && lb < a.in_frames) ? xin[lb * a.ifs] : (Real)0);
+            }
         }, lds_store, false, tw);
     }
     __syncthreads();
 
-    // ---- inverse (see k_fft_pair2), outputs straight to HBM: frame outa + n holds (y_c, y_{c+1}) ----
-    const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out;
-    Real *ybase = (Real *)a.out + (int64_t)clip * a.ocs + (int64_t)(2 * cu) * a.ochs + (outa + v0) * a.ofs; // outa + v0 >= 0
+    // ---- inverse (see k_fft_pair2), outputs straight to HBM -----------------------------------------
+    const int32_t v0 = a.v0, v1 = a.v0 + hop_out;
+    Real *ybase = (Real *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0) * a.ofs; // outa + v0 >= 0
     const int64_t oleft = (a.out_frames - (outa + v0)) * (int64_t)ofb;
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
         (void *)ybase, 0, (int)(oleft < 0 ? 0 : oleft > 0x40000000 ? 0x40000000 : oleft), 0x00020000);
@@ -1006,7 +1026,14 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_chpair2(FftArgs a)
         }
     };
     Spec::inv(FFT_STAMP_ARGS cur, PairTabs<Real>::wb(a), h_load, [&](int n, C w) {
-        if (n >= v0 && n < v1) CpIo<Real>::store(w, ro, (n - v0) * ofb);
+        if (n >= v0 && n < v1) {
+            if constexpr (CP) {
+                CpIo<Real>::store(w, ro, (n - v0) * ofb); // frame outa + n holds (y_c, y_{c+1})
+            } else {
+                buf_store_real(w.x, ro, (n - v0) * ofb);             // block a
+                buf_store_real(w.y, ro, (n - v0 + hop_out) * ofb);   // block b: hop_out frames further
+            }
+        }
     }, true, tw);
 }
 
@@ -1173,10 +1200,12 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     struct PairEntry {
         int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); void (*kern2d)(FftArgs);
         void (*kcp)(FftArgs); void (*kcpd)(FftArgs); // channel-pair mode (interleaved data), float32 / float64
+        void (*kst)(FftArgs); void (*kstd)(FftArgs); // strided columns, two blocks per transform
     };
 #define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) \
     {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>, \
-     k_fft_chpair2<PairOf<NA, NB, NT>, float>, k_fft_chpair2<PairOf<NA, NB, NT>, double>}
+     k_fft_strided2<PairOf<NA, NB, NT>, float, true>, k_fft_strided2<PairOf<NA, NB, NT>, double, true>, \
+     k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>}
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
         HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
@@ -1198,10 +1227,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     const bool no_pair = switches().fft_no_pair;
     const uint64_t cols_p = (uint64_t)j.n_clips * j.n_channels;
     const bool f64 = j.elem == HIPSOXR_F64;
-    // float64: unit-stride columns, or interleaved data with an even channel count (channel pairs); else the exact engine
-    const bool f64_layout = (j.in_frame_stride == 1 && j.out_frame_stride == 1) ||
-                            (j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1);
-    if (f64 && (no_pair || cols_p > 65535 || !f64_layout)) return nullptr;
+    // float64: the second-generation kernels only (unit-stride columns; channel pairs; strided columns) — else the exact engine
+    if (f64 && (no_pair || cols_p > 65535)) return nullptr;
     if (!no_pair && cols_p <= 65535) {
         const PairEntry *big = nullptr, *sml = nullptr;
         int big_i = 0, sml_i = 0;
@@ -1230,7 +1257,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             // Latency-bound jobs (everything resident at once, about one workgroup per CU slot):
             // the four-pass schedule with prefetched tables has the shorter critical path (7.1 vs
             // 9.0 us for one workgroup); from ~400 workgroups on, the three-pass one wins on work.
-            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr};
+            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && !switches().fft_small_3pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
                 if (wgs < 400 && !f64) use = &low_latency;
@@ -1272,7 +1299,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const int64_t items = a.chpair ? n_blocks : (n_blocks + 1) / 2, items8 = (items + 7) / 8 * 8;
                 const int64_t units = a.chpair ? j.n_channels / 2 : j.n_channels;
                 a.xcd_map = (j.n_channels > 1 && j.in_chan_stride == 1 && j.out_chan_stride == 1 && j.n_clips <= 65535 &&
-                             items8 * units <= 2147483647LL && !switches().fft_no_xcd_map && (!f64 || a.chpair)) ? 1 : 0;
+                             items8 * units <= 2147483647LL && !switches().fft_no_xcd_map) ? 1 : 0;
                 if (a.chpair && !a.xcd_map) return f64 ? nullptr : "internal: channel pairing needs the XCD map"; // (decided before the work items were counted)
                 a.pairs_per_col = items;
                 const dim3 grid = a.xcd_map ? dim3((unsigned)(items8 * units), j.n_clips, 1)
@@ -1282,9 +1309,13 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const bool v2ok = use->kern2 && !a.xcd_map && !a.chpair && j.in_frame_stride == 1 && j.out_frame_stride == 1 &&
                                   2 * (size_t)g.hop_out * esz + 16 <= lds;
                 const bool cp2ok = a.chpair && a.xcd_map && cp2;
-                if (f64 && !v2ok && !cp2ok) return nullptr; // (no float64 instance of the first-generation kernel: exact engine)
-                if (cp2ok) {
-                    kern = f64 ? use->kcpd : use->kcp;
+                // strided columns that are not channel pairs (odd channel counts, channel slices): the strided second-
+                // generation kernel when the byte offsets of a pair of blocks fit its 32-bit operands
+                const bool st2ok = !a.chpair && !v2ok && (f64 ? use->kstd : use->kst) != nullptr && !switches().fft_pair_v1 &&
+                                   2 * (int64_t)std::max(g.N_in, g.N_out) * std::max(j.in_frame_stride, j.out_frame_stride) * (int64_t)esz < (1LL << 30);
+                if (f64 && !v2ok && !cp2ok && !st2ok) return nullptr; // (no float64 instance of the first-generation kernel: exact engine)
+                if (cp2ok || st2ok) {
+                    kern = cp2ok ? (f64 ? use->kcpd : use->kcp) : (f64 ? use->kstd : use->kst);
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }

@@ -185,7 +185,7 @@ def test_auto_engine_float64_large_job_is_frequency_domain_and_close(oracle):
 @pytest.mark.parametrize("dtype,tol", [(np.float32, 1e-6), (np.float64, 2e-9)])
 @pytest.mark.parametrize("in_rate,out_rate,ch", [(44100, 16000, 8), (48000, 44100, 4), (44100, 48000, 2), (16000, 44100, 6)])
 def test_channel_pair_kernel(oracle, dtype, tol, in_rate, out_rate, ch):
-    """Interleaved data with an even channel count runs the channel-pair kernel (k_fft_chpair2: buffer loads and
+    """Interleaved data with an even channel count runs the channel-pair kernel (k_fft_strided2<..., true>: buffer loads and
     stores of one (Real, Real) word per frame, XCD-aware ids), float32 and float64: every channel within the
     engine's tolerance of the oracle's float64 direct form, first and last blocks included, and a strided view
     (channels 2..5 of a wider tensor) gives the same numbers."""
@@ -211,3 +211,28 @@ def test_channel_pair_kernel(oracle, dtype, tol, in_rate, out_rate, ch):
         for clip in range(2):
             ref = oracle.resample(x[clip][:, 1:5].astype(np.float64), in_rate, out_rate, "VHQ", mode="ref")
             assert _rms(yv[clip] - ref) / _rms(ref) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 1e-6), (np.float64, 2e-9)])
+@pytest.mark.parametrize("in_rate,out_rate,ch", [(48000, 44100, 3), (44100, 16000, 5), (44100, 48000, 1)])
+def test_strided_column_kernel(oracle, dtype, tol, in_rate, out_rate, ch):
+    """Columns with a frame stride that cannot be paired by channel — odd channel counts of interleaved data, a
+    single channel sliced out of a wider tensor — run the strided second-generation kernel (two blocks of one column
+    per transform): every channel within tolerance of the oracle, float32 and float64."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(ch * 77 + in_rate)
+    wide = (rng.standard_normal((2, 50021, ch + 2)) * 0.25).astype(dtype)
+    plan = dev.Plan(in_rate, out_rate, "VHQ")
+    wt = torch.from_numpy(wide).cuda()
+    for view, ref_in in ((wt[:, :, :ch], wide[:, :, :ch]), (wt[:, :, 2:2 + ch], wide[:, :, 2:2 + ch])):
+        y = dev.resample_tensor(plan, view, kernel=FFT).cpu().numpy()          # frame stride ch + 2
+        for clip in range(2):
+            ref = oracle.resample(ref_in[clip].astype(np.float64), in_rate, out_rate, "VHQ", mode="ref")
+            assert y[clip].shape == ref.shape
+            for c in range(ch):
+                assert _rms(y[clip][:, c] - ref[:, c]) / _rms(ref[:, c]) <= tol
+    xc = torch.from_numpy(np.ascontiguousarray(wide[:, :, :ch])).cuda()          # frame stride ch (odd)
+    if ch > 1:
+        yc = dev.resample_tensor(plan, xc, kernel=FFT).cpu().numpy()
+        assert _rms(yc - dev.resample_tensor(plan, wt[:, :, :ch], kernel=FFT).cpu().numpy()) <= 5e-7 * _rms(yc)
