@@ -920,16 +920,6 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
             }
         }
     }
-        if (i0 >= 0 && i0 + EPS - 1 < valid) {
-            *reinterpret_cast<V16 *>(ybase + i0) = v;
-        } else {
-            const Real *e = reinterpret_cast<const Real *>(&v);
-#pragma unroll
-            for (int c = 0; c < EPS; ++c)
-                if (i0 + c >= 0 && i0 + c < valid) ybase[i0 + c] = e[c];
-        }
-    }
-#endif
 #ifdef FFT2_TRACE
     g_tri = 15;
     FFT_STAMP();
