@@ -955,6 +955,7 @@ struct TileArgs {
     unsigned long long *trace; // HIPSOXR_DEBUG_TRACE: per-wave s_memtime stamps [block][wave][16]
     int32_t dbg; // timing ablations only (HIPSOXR_DEBUG_FLAGS): 1 no staging loads, 2 no LDS reads, 4 no coefficient loads, 8 no stores
     int32_t pad, i_min, x_count; // LDS row padding; first staged input; samples staged per tile
+    int32_t pb;                  // k_tile: periods per slab (64, or fewer with the upper lanes idle)
     uint32_t n_clips, n_channels;
     int64_t ics, ifs, ichs, ocs, ofs, ochs;
     int64_t in_abs0, in_frames;
@@ -1049,21 +1050,23 @@ __global__ void __launch_bounds__(1024) k_tile(TileArgs a)
     // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
     // address derived from them) on the scalar side
     const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64; // first period of this workgroup
+    const int32_t pb = a.pb; // periods per slab: 64, or fewer (the lanes above compute a copy of the last row and store nothing)
+    const int64_t bw = a.b_first + (int64_t)blockIdx.x * pb; // first period of this workgroup
     const int32_t Mc = (int32_t)a.Mc, pad = a.pad;
 
     stage_slab<IO, Real, ALIGNED>(a, xs, clip, ch, bw);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
+    const bool live = lane < pb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_waves = a.n_waves; // waves that compute (all of them, or the first few of a split slab's workgroup: launch_tile)
-    const Real *xl = xs + lane * (Mc + pad);
+    const Real *xl = xs + (live ? lane : pb - 1) * (Mc + pad);
     const int64_t b = bw + lane; // this lane's period
     typedef const __attribute__((address_space(4))) Real *CPtr;
 
     // whole workgroup inside the requested output range? (uniform) -> stores need no per-sample test
-    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
+    const bool interior = pb == 64 && bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
     IO *const yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs +
                    (b * a.Lc - a.out_k0) * a.ofs; // this lane's period start (may be out of range)
 
@@ -1146,7 +1149,7 @@ __global__ void __launch_bounds__(1024) k_tile(TileArgs a)
 #pragma unroll
             for (int rr = 0; rr < RT; ++rr) {
                 const int64_t k = b * a.Lc + r0 + rr, idx = k - a.out_k0;
-                if (r0 + rr < a.Lc && idx >= 0 && idx < a.out_frames)
+                if (live && r0 + rr < a.Lc && idx >= 0 && idx < a.out_frames)
                     store_out<Real>(yt + rr * a.ofs, accL[rr] + accR[rr], a.oc, ch, k);
             }
         }
@@ -1570,6 +1573,7 @@ struct TileGeom {
     int variant = 0; // 0: k_tile (coefficients on the scalar path), 1: k_tile_mfma
     bool aligned = false;
     int32_t n_rt = 0, I_h = 0, pad = 0, i_min = 0, x_count = 0;
+    int32_t pb = 64; // periods per slab (k_tile: 32 or 16 when a 64-period slab does not fit LDS — float64, long periods)
     int64_t Lc = 0, Mc = 0;
     size_t lds_bytes = 0;
     int32_t rowR = 0, plane = 0; // variant 2 (k_tile_mfma_p)
@@ -1706,8 +1710,16 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab, int var
     }
     i_min = floor4(i_min); i_max = floor4(i_max) + 3; // slab = whole quads (vectorised staging)
     g.i_min = i_min;
-    g.x_count = (63 * Mc + (i_max - i_min + 1) + 3) / 4 * 4; // whole quads (63*Mc may be odd)
-    g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / Mc + 1) + 8) * sizeof(Real);
+    // periods per slab: 64 (one per lane); the VALU kernel also runs with 32 or 16 (the other lanes idle) when the
+    // slab would not fit — float64 at 44.1k -> 16k: 64 x 441 x 8 B = 226 KB — which still beats one lane per output
+    // walking T dependent loads by 5x (60 s mono int32: 1015 us on k_gather)
+    g.pb = 64;
+    for (;;) {
+        g.x_count = ((g.pb - 1) * Mc + (i_max - i_min + 1) + 3) / 4 * 4; // whole quads ((pb-1)*Mc may be odd)
+        g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / Mc + 1) + 8) * sizeof(Real);
+        if (g.lds_bytes <= 160 * 1024 || variant != 0 || g.pb == 16) break;
+        g.pb /= 2;
+    }
     g.e0.resize((size_t)g.n_rt * 2);
     for (int rt = 0; rt < g.n_rt; ++rt) {
         g.e0[rt * 2 + 0] = i0L[rt] - i_min;
@@ -2055,7 +2067,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     a.tab = g.variant >= 1 ? d.tile_tab_m : d.tile_tab;
     a.e0 = g.variant >= 1 ? d.tile_i0_m : d.tile_i0;
     a.Lc = g.Lc; a.Mc = g.Mc; a.n_rt = g.n_rt; a.I_h = g.I_h;
-    a.pad = g.pad; a.i_min = g.i_min; a.x_count = g.x_count;
+    a.pad = g.pad; a.i_min = g.i_min; a.x_count = g.x_count; a.pb = g.pb;
     a.n_clips = j.n_clips; a.n_channels = j.n_channels;
     a.ics = j.in_clip_stride; a.ifs = j.in_frame_stride; a.ichs = j.in_chan_stride;
     a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
@@ -2065,7 +2077,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     // periods touched: floor(k0/Lc) .. floor((k0+n-1)/Lc)
     const int64_t b_lo = j.out_k0 / g.Lc, b_hi = (j.out_k0 + j.out_frames - 1) / g.Lc;
     a.b_first = b_lo;
-    const int64_t n_blocks = (b_hi - b_lo + 1 + 63) / 64;
+    const int64_t n_blocks = (b_hi - b_lo + g.pb) / g.pb;
     const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
     if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";
     if (n_blocks > 2147483647LL) return "job too long for one launch";
