@@ -30,6 +30,17 @@ def _windows_match_oracle(oracle, plan_args, x_np, y_np, rng, n_windows=6, width
         assert np.array_equal(y_np[k0:k0 + width], want), f"window at {k0}"
 
 
+def _windows_close_to_reference(oracle, plan_args, x_np, y_np, rng, n_windows=6, width=2000, tol=1e-6):
+    """The frequency-domain engine's output against the oracle's float64 direct form, window by window (first and
+    last outputs included): the north star's bar holds locally, not just as an average over the signal."""
+    pl = oracle.plan(*plan_args)
+    for k0 in [0, len(y_np) - width] + list(rng.integers(0, len(y_np) - width, n_windows)):
+        k0 = int(k0)
+        want = oracle.resample_channel(pl, x_np.astype(np.float64), "ref", k0=k0, n_out=width)
+        err = y_np[k0:k0 + width].astype(np.float64) - want
+        assert np.sqrt(np.mean(err ** 2)) <= tol * max(np.sqrt(np.mean(want ** 2)), 0.05), f"window at {k0}"
+
+
 def test_config1_vhq_60s_mono(oracle):
     import torch
     from soxr_amd import device as dev
@@ -40,6 +51,7 @@ def test_config1_vhq_60s_mono(oracle):
     assert y.shape[0] == 2646000
     y_auto = dev.resample_tensor(plan, x)                      # AUTO -> frequency-domain engine
     assert y_auto.shape == y.shape and _rel_rms(y_auto, y) <= 1e-6
+    _windows_close_to_reference(oracle, (48000, 44100, "VHQ"), x.cpu().numpy(), y_auto.cpu().numpy(), np.random.default_rng(10))
     # shift invariance, exact
     xs = torch.cat([torch.zeros(plan.M * 5, device="cuda"), x])
     ys = dev.resample_tensor(plan, xs, kernel=EXACT)
@@ -66,6 +78,9 @@ def test_config2_vhq_8ch_44k1_16k(oracle):
     assert tuple(y.shape) == (960000, 8)
     y_auto = dev.resample_tensor(plan, x)
     assert _rel_rms(y_auto, y) <= 1e-6
+    for c in (0, 6):
+        _windows_close_to_reference(oracle, (44100, 16000, "VHQ"), x[:, c].cpu().numpy(), y_auto[:, c].cpu().numpy(),
+                                    np.random.default_rng(11 + c), n_windows=2, width=600)
     for c in (0, 5, 7):   # channel independence: interleaved launch == planar mono launch
         assert torch.equal(y[:, c], dev.resample_tensor(plan, x[:, c].contiguous(), kernel=EXACT))
     assert torch.equal(y, dev.resample_tensor(plan, x, kernel=1))
@@ -84,6 +99,9 @@ def test_config3_batch_of_clips(oracle):
     assert tuple(y.shape) == (128, 441000, 1)
     y_auto = dev.resample_tensor(plan, x)
     assert _rel_rms(y_auto, y) <= 1e-6
+    for clip in (0, 77, 127):
+        _windows_close_to_reference(oracle, (48000, 44100, "VHQ"), x[clip, :, 0].cpu().numpy(), y_auto[clip, :, 0].cpu().numpy(),
+                                    np.random.default_rng(20 + clip), n_windows=2)
     for clip in (0, 63, 127):
         assert torch.equal(y[clip, :, 0], dev.resample_tensor(plan, x[clip, :, 0].contiguous(), kernel=EXACT))
     _windows_match_oracle(oracle, (48000, 44100, "VHQ"), x[77, :, 0].cpu().numpy(), y[77, :, 0].cpu().numpy(),
