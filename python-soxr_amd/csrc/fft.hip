@@ -16,12 +16,21 @@
 // What is neglected is the aliasing of g's stop band (<= -176 dB for VHQ): measured against the
 // direct form 2.5e-10 relative RMS in float64, 1.5e-7 to 2.2e-7 in float32 (FFT rounding) — inside the 1e-6
 // bar, but NOT bit-identical to the canonical order, so this engine is used only where no
-// bit-exact contract exists: whole-signal float32 device jobs (hipsoxr_run_device).  The host
-// surface (soxr.resample / ResampleStream), integer and float64 I/O stay on the exact engine.
+// bit-exact contract exists: whole-signal float32 and float64 device jobs (hipsoxr_run_device).  The host
+// surface (soxr.resample / ResampleStream) and integer I/O stay on the exact engine.
 //
-// Kernel: one workgroup (256 threads) per block, everything in LDS: load -> mixed-radix Stockham
-// FFT (radices 16/8/4/2/3/5/7, twiddles from L2-resident tables) -> real-FFT untangling * H ->
-// inverse real-FFT tangling -> Stockham inverse FFT -> store the valid outputs.
+//
+// Kernels:
+//   k_fft_block     general path, any 7-smooth plan: one workgroup per block, everything in LDS: load -> mixed-radix
+//                   Stockham FFT (radices 16/8/4/2/3/5/7, twiddles from L2-resident tables) -> real-FFT untangling
+//                   * H -> inverse real-FFT tangling -> Stockham inverse FFT -> store the valid outputs.
+//   k_fft_pair      paired blocks (two real blocks as one complex signal), compile-time three- or four-pass
+//                   schedules for the standard audio ratios; today the low-latency schedule of small jobs.
+//   k_fft_pair2     second generation for unit-stride columns (mono, planar, batches): raw buffer loads with the
+//                   hardware range check, output runs staged through LDS and stored as 16-byte granules;
+//                   float32 and float64 instances.  AUTO's kernel for configs[1] and configs[3].
+//   k_fft_strided2  the same for columns with a frame stride: interleaved data paired by channel (CP = true:
+//                   one (Real, Real) word per frame; configs[2]) or strided columns paired by block (CP = false).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

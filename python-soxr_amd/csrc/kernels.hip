@@ -22,11 +22,14 @@
 //                   [T][Lpad], input read straight from global memory.  Universal fallback: every
 //                   ratio / layout / length.
 //   k_chain         small launches (streaming chunks, < 4096 outputs): a workgroup stages the coefficient
-//                   rows and the input span its outputs share into LDS in one round trip, then
-//                   2*NO lanes run the two canonical half-chains.  Exact, interpolated and variable-rate plans.
+//                   rows and the input span its outputs share into LDS in one round trip, then two waves run
+//                   the two canonical half-chains of every output.  Exact, interpolated and variable-rate
+//                   plans.  Reports completion through words in pinned host memory (ChainDone) when asked.
+//   k_chain_resident  the same body as a RESIDENT kernel: launched once, fed through a mailbox (pinned host
+//                   memory, or device memory the CPU stores into on large-BAR systems) — no HIP call per chunk.
 //   k_interp(_tile) interpolated-phase plans (arbitrary ratios) and variable rate: per tap a cubic in
 //                   the fractional position (Horner FMAs), small / large launches.
-//   k_tile          period-tiled VALU kernel: 64 periods of one column staged in LDS, a wave = 16
+//   k_tile          period-tiled VALU kernel: 64 (32, 16 where LDS demands) periods of one column staged in LDS, a wave = 16
 //                   output phases whose coefficients travel on the scalar path (s_load -> SGPR operands
 //                   of v_pk_fma_f32).  The f64 engine (float64 / int32 I/O); f32 A/B reference.
 //   k_tile_mfma(_p) the same tiling on v_mfma_f32_16x16x4_f32 — on gfx950 the f32-input MFMA IS the
