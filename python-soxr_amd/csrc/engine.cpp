@@ -1142,6 +1142,7 @@ hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
     if (!s) return "null argument";
     DeviceGuard guard(s->device);
     resident_stop(s);
+    s->res.mirror_of = nullptr; // (the ring starts over at frame 0: nothing in the device mirror is current)
     if (s->st) (void)hipStreamSynchronize(s->st);
     s->ended = false; s->n_in_total = 0; s->k_done = 0; s->in_base = 0; s->in_fill = 0;
     s->pend_n = s->pend_off = 0;

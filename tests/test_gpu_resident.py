@@ -123,3 +123,17 @@ def test_environment_switch_runs_the_stream_contract():
                         os.path.join(root, "tests", "test_soxr_abi.py")],
                        cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_resident_clear_then_longer_first_chunk(soxr):
+    """clear() restarts the ring at frame 0; a first chunk LONGER than what the previous signal had left staged must
+    not inherit its head from the device-side copy of the old ring."""
+    a = _signal(np.float32, 3000, 1, 46)
+    b = _signal(np.float32, 3000, 1, 47)
+    rs = soxr.ResampleStream(48000, 44100, 1, quality="HQ", resident=True)
+    ref = soxr.ResampleStream(48000, 44100, 1, quality="HQ")
+    for x, chunks in ((a[:100], [100]), (b, [441, 300, 1000]), (a[:50], [50]), (a, [2000, 50])):
+        got = np.concatenate(_run(rs, x, chunks))
+        want = np.concatenate(_run(ref, x, chunks))
+        assert np.array_equal(got, want)
+        rs.clear(); ref.clear()
