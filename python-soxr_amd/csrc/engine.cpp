@@ -1133,6 +1133,10 @@ hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size
 hipsoxr_error_t hipsoxr_stream_set_dither_seed(hipsoxr_stream_t *s, uint32_t seed)
 {
     if (!s) return "null argument";
+    if (s->res.running) { // (the seed is a launch argument of the resident kernel)
+        DeviceGuard guard(s->device);
+        resident_stop(s);
+    }
     s->dither_seed = seed;
     return nullptr;
 }
