@@ -70,7 +70,7 @@ struct Switches {
     bool fft_no_xcd_map = false;  // HIPSOXR_FFT_NO_XCD_MAP   plain (block, column) workgroup ids for interleaved data
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
-    bool fft_small_3pass = false; // HIPSOXR_FFT_SMALL_3PASS  small 147/160 blocks on the 3-pass (radix 16/21) schedule
+    bool fft_small_4pass = false; // HIPSOXR_FFT_SMALL_4PASS  small 48k->44.1k jobs on round 1's four-pass low-latency schedule (first-generation kernel)
     bool fft_pair_v1 = false;     // HIPSOXR_FFT_PAIR_V1      unit-stride jobs on k_fft_pair instead of k_fft_pair2
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)

@@ -1273,11 +1273,12 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     if (gs.ok) { g = gs; use = sml; }
                 }
             }
-            // Latency-bound jobs (everything resident at once, about one workgroup per CU slot):
-            // the four-pass schedule with prefetched tables has the shorter critical path (7.1 vs
-            // 9.0 us for one workgroup); from ~400 workgroups on, the three-pass one wins on work.
+            // Round 1: latency-bound jobs (under ~400 workgroups) ran a four-pass radix <= 8 schedule with prefetched
+            // tables on the first-generation kernel (7.1 vs 9.0 us for one workgroup).  Against the second-generation
+            // three-pass kernel it no longer wins anywhere (0.5 s .. 20 s clips: equal within 0.2 us; 30 s: 10.6 vs
+            // 9.4 us): kept behind HIPSOXR_FFT_SMALL_4PASS for A/B only.
             static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-            if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && !switches().fft_small_3pass) {
+            if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && switches().fft_small_4pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
                 if (wgs < 400 && !f64) use = &low_latency;
             }
