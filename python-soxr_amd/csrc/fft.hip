@@ -626,6 +626,7 @@ HIPSOXR_SCHED(4704, 21, 16, 14, false);
 HIPSOXR_SCHED(4410, 21, 14, 15, false);
 HIPSOXR_SCHED(4096, 16, 16, 16, true);
 HIPSOXR_SCHED(3584, 14, 16, 16, false);
+HIPSOXR_SCHED(3528, 21, 12, 14, false);
 HIPSOXR_SCHED(2560, 16, 16, 10, true);
 HIPSOXR_SCHED(2352, 21, 16, 7, false);
 HIPSOXR_SCHED(2048, 16, 16, 8, true);
@@ -1241,6 +1242,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         HIPSOXR_PAIR(147, 320, 16, false, 5120, 2352, 384), HIPSOXR_PAIR(320, 147, 16, false, 2352, 5120, 384),  // 96k <-> 44.1k
         HIPSOXR_PAIR(80, 441, 16, false, 7056, 1280, 448), HIPSOXR_PAIR(441, 80, 16, false, 1280, 7056, 448),    // 44.1k <-> 8k
         HIPSOXR_PAIR(147, 640, 8, false, 5120, 1176, 320), HIPSOXR_PAIR(640, 147, 8, false, 1176, 5120, 320),    // 192k <-> 44.1k
+        HIPSOXR_PAIR(640, 441, 8, false, 3528, 5120, 384), HIPSOXR_PAIR(441, 640, 8, false, 5120, 3528, 384),    // 22.05k <-> 32k, 11.025k <-> 16k
     };
 #undef HIPSOXR_PAIR
     const bool no_pair = switches().fft_no_pair;

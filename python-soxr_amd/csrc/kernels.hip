@@ -2133,7 +2133,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         if (wgs < 128 && g.n_rt > 1 && !switches().dbg_nw && !switches().no_tile_split) split = (int)std::min<int64_t>(g.n_rt, 256 / wgs);
         if (switches().dbg_split) split = std::min(switches().dbg_split, g.n_rt);
         if (split > 1) {
-            const int per_wg = (g.n_rt + split - 1) / split; // row tiles (= computing waves) per workgroup
+            const int per_wg = std::min(16, (g.n_rt + split - 1) / split); // row tiles (= computing waves) per workgroup: a block holds 16 waves
             nw = per_wg; a.n_waves = nw;
             block = dim3((unsigned)std::max(256, 64 * per_wg)); // (at least four waves stage the slab)
             grid.z = (unsigned)((g.n_rt + per_wg - 1) / per_wg);

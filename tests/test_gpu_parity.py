@@ -186,3 +186,25 @@ def test_channel_limit_65536(soxr, oracle, dtype, order):
             v = oracle.resample_channel(pl, x[:, c].astype(np.float32), "port_f32")
             want = oracle.quantize(v, np.int16, channel=c)[0][:, None]
         assert np.array_equal(y[:, c:c + 1], want), c
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+@pytest.mark.parametrize("in_rate,out_rate,frames", [(22050, 32000, 300000), (32000, 22050, 300000), (11025, 48000, 150000)])
+def test_tile_kernels_many_row_tiles_few_slabs(oracle, dtype, in_rate, out_rate, frames):
+    """Ratios with many output phases per period (L = 640: 40 row tiles) on jobs of a few dozen slabs: the launch
+    spreads a slab's row tiles over several workgroups, at most 16 computing waves each (a split that asked for a
+    1280-thread block once failed to launch).  Windows of the device result, bit for bit against the oracle."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(frames + in_rate)
+    x = rng.standard_normal(frames)
+    x = (x * 2e8).astype(dtype) if np.issubdtype(dtype, np.integer) else (x * 0.25).astype(dtype)
+    plan = dev.Plan(in_rate, out_rate, "VHQ")
+    y = dev.resample_tensor(plan, torch.from_numpy(x).cuda(), kernel=dev.KERNEL_EXACT).cpu().numpy()
+    pl = oracle.plan(in_rate, out_rate, "VHQ")
+    mode = "port_f32" if dtype == np.float32 else "port_f64"
+    for k0 in (0, len(y) // 2, len(y) - 400):
+        want = oracle.resample_channel(pl, x.astype(np.float32 if dtype == np.float32 else np.float64), mode, k0=k0, n_out=400)
+        if np.issubdtype(dtype, np.integer):
+            want, _ = oracle.quantize(want, dtype, channel=0, k0=k0, dither=False, seed=0)
+        assert np.array_equal(y[k0:k0 + 400], want), k0
