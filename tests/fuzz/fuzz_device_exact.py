@@ -14,7 +14,7 @@ import _provider  # noqa: F401  (port mode on the product's bank: arithmetic-ord
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 r = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-STD = [8000, 16000, 22050, 32000, 44100, 48000, 96000]
+STD = [8000, 11025, 12000, 16000, 22050, 32000, 44100, 48000, 88200, 96000, 192000]
 TORCH = {np.float32: torch.float32, np.float64: torch.float64, np.int16: torch.int16, np.int32: torch.int32}
 fails = 0
 for case in range(n_cases):
@@ -27,7 +27,10 @@ for case in range(n_cases):
     q = r.choice(["VHQ", "HQ", "MQ", "LQ", "QQ"])
     dtype = r.choice([np.float32, np.float64, np.int16, np.int32])
     ch, clips = r.choice([1, 2, 3, 5]), r.choice([1, 1, 3])
-    n = r.choice([1, 37, r.randint(100, 5000), r.randint(5000, 40000), r.randint(40000, 120000)])
+    n = r.choice([1, 37, r.randint(100, 5000), r.randint(5000, 40000), r.randint(40000, 120000), r.randint(40000, 120000),
+                  r.randint(300000, 1200000)])  # (the last: few-slab launches of the tile kernels, row-tile splits)
+    if n > 300000:
+        ch, clips = r.choice([1, 2]), 1
     rng = np.random.default_rng(case)
     x = rng.standard_normal((clips, n, ch))
     x = (x * 5000).astype(dtype) if np.issubdtype(dtype, np.integer) else (x * 0.25).astype(dtype)
