@@ -2013,9 +2013,18 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     const int64_t bytes = span_cap * (int64_t)sizeof(Real) + k * 10 + (2 * p->phases + 2) * 4 + 64;
                     if (bytes <= 150 * 1024) KO = k;
                 }
-                // ... which pays off once the launch fills the chip: one column of a stream chunk is a handful of such
-                // workgroups (96 000-frame chunk, 7 workgroups: 1.5 ms, where lane-per-output k_interp takes 0.1)
-                if (KO && (nf + KO - 1) / KO * (int64_t)j.n_clips * j.n_channels < 128) KO = 0;
+                // ... which pays off once the launch fills the chip.  A workgroup of it is long (KO outputs x T taps one
+                // interval at a time: ~130 us at VHQ, 1.5 ms with the variable-rate clock), so a launch of a few of them
+                // loses to lane-per-output k_interp, whose time grows with the work instead (measured, us per output x tap:
+                // k_interp 2.5e-6; a k_interp_tile workgroup 6.3e-5 constant rate, 2.9e-4 variable rate; 256 CUs):
+                // 96 000-frame variable-rate chunk 1.5 ms -> 0.1 ms on k_interp; 10 s stereo constant rate 134 us on
+                // the tile kernel (503 on k_interp); 1 s stereo 75 us on k_interp (127 on the tile kernel).
+                if (KO) {
+                    const double cols = (double)j.n_clips * j.n_channels, wgs = (double)((nf + KO - 1) / KO) * cols;
+                    const double t_tile = std::ceil(wgs / 256.) * (double)KO * p->T * (vr ? 2.9e-4 : 6.3e-5);
+                    const double t_lane = 2.5e-6 * (double)nf * cols * p->T;
+                    if (t_lane < t_tile) KO = 0;
+                }
             }
             if (KO) {
                 InterpTileArgs ta;
