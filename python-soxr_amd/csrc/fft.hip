@@ -1243,6 +1243,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         HIPSOXR_PAIR(80, 441, 16, false, 7056, 1280, 448), HIPSOXR_PAIR(441, 80, 16, false, 1280, 7056, 448),    // 44.1k <-> 8k
         HIPSOXR_PAIR(147, 640, 8, false, 5120, 1176, 320), HIPSOXR_PAIR(640, 147, 8, false, 1176, 5120, 320),    // 192k <-> 44.1k
         HIPSOXR_PAIR(640, 441, 8, false, 3528, 5120, 384), HIPSOXR_PAIR(441, 640, 8, false, 5120, 3528, 384),    // 22.05k <-> 32k, 11.025k <-> 16k
+        HIPSOXR_PAIR(40, 147, 32, false, 4704, 1280, 384), HIPSOXR_PAIR(147, 40, 32, false, 1280, 4704, 384),    // 44.1k <-> 12k, 88.2k <-> 24k
     };
 #undef HIPSOXR_PAIR
     const bool no_pair = switches().fft_no_pair;
