@@ -269,6 +269,7 @@ struct StreamShell {
     uint64_t *d_clips = nullptr;
     void *h_in = nullptr, *h_out = nullptr;
     size_t h_in_bytes = 0, h_out_bytes = 0;
+    uint32_t *h_done = nullptr; uint32_t done_seq = 0; // completion words of small launches, and the last number used in them
     hipEvent_t ev = nullptr;
 };
 static std::mutex g_pool_mu;
@@ -283,6 +284,7 @@ static void shell_free(StreamShell &sh)
     if (sh.d_clips) (void)hipFree(sh.d_clips);
     if (sh.h_in) (void)hipHostFree(sh.h_in);
     if (sh.h_out) (void)hipHostFree(sh.h_out);
+    if (sh.h_done) (void)hipHostFree(sh.h_done);
     if (sh.ev) (void)hipEventDestroy(sh.ev);
     if (sh.st) (void)hipStreamDestroy(sh.st);
     sh = StreamShell();
@@ -991,6 +993,7 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
                     const size_t frame = (size_t)ch * esz(s);
                     s->st = sh.st; s->d_clips = sh.d_clips; s->ev = sh.ev;
                     s->h_in = sh.h_in; s->h_in_bytes = sh.h_in_bytes; s->h_out = sh.h_out; s->h_out_bytes = sh.h_out_bytes;
+                    s->h_done = sh.h_done; s->done_seq = sh.done_seq;
                     s->ring_on_host = sh.ring_on_host && !s->split;
                     if (sh.ring_on_host && s->split) { // (split layouts keep the ring on the device)
                         if (sh.d_in) (void)hipHostFree(sh.d_in);
@@ -1063,7 +1066,6 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
     resident_stop(s);
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->res.box) (void)hipHostFree(s->res.box);
-    if (s->h_done) (void)hipHostFree(s->h_done);
     if (s->res.words_dev) (void)hipFree(s->res.words_dev);
     if (s->res.mirror) (void)hipFree(s->res.mirror);
     if (s->res.ctl) (void)hipFree(s->res.ctl);
@@ -1079,6 +1081,7 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
     const size_t frame = (size_t)s->ch * esz(s);
     sh.st = s->st; sh.d_clips = s->d_clips; sh.ev = s->ev;
     sh.h_in = s->h_in; sh.h_in_bytes = s->h_in_bytes; sh.h_out = s->h_out; sh.h_out_bytes = s->h_out_bytes;
+    sh.h_done = s->h_done; sh.done_seq = s->done_seq;
     sh.d_in = s->d_in; sh.in_bytes = s->d_in ? s->in_cap * frame : 0;
     sh.d_in_alt = s->d_in_alt; sh.alt_bytes = s->d_in_alt ? s->alt_cap * frame : 0;
     sh.d_out = s->d_out; sh.out_bytes = s->d_out ? s->out_cap * frame : 0;
