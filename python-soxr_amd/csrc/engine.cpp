@@ -1156,8 +1156,10 @@ hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
     if (s->vr.on) { // fresh signal at the ratio last requested
         s->vr.k_s = 0; s->vr.t_s = 0; s->vr.s0 = s->vr.s1; s->vr.delta = 0; s->vr.n_slew = 0;
     }
-    HIP_TRY(hipMemsetAsync(s->d_clips, 0, sizeof(uint64_t), s->st));
-    HIP_TRY(stream_wait(s));
+    if (s->elem == HIPSOXR_I16 || s->elem == HIPSOXR_I32) { // (float streams never touch the clip counter)
+        HIP_TRY(hipMemsetAsync(s->d_clips, 0, sizeof(uint64_t), s->st));
+        HIP_TRY(stream_wait(s));
+    }
     return nullptr;
 }
 
