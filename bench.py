@@ -110,10 +110,10 @@ def time_workload(plan, x, steps, warmup, world, device, kernel=0, windows=50):
     for _ in range(steps):
         job.launch()
     torch.cuda.synchronize(device)
-    if world > 1:
+    wall = time.perf_counter() - t0  # this rank's K steps; the MAX over ranks is taken below, behind the closing bracket
+    if world > 1:                    # (a collective's own latency is tens of us: not part of K x 12 us steps)
         dist.barrier()
     torch.cuda.synchronize(device)
-    wall = time.perf_counter() - t0
     kern = wall / steps
     if windows:
         per = []
