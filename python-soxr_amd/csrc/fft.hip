@@ -625,6 +625,7 @@ HIPSOXR_SCHED(5120, 16, 16, 20, true);
 HIPSOXR_SCHED(4704, 21, 16, 14, false);
 HIPSOXR_SCHED(4410, 21, 14, 15, false);
 HIPSOXR_SCHED(4096, 16, 16, 16, true);
+HIPSOXR_SCHED(3840, 16, 16, 15, true);
 HIPSOXR_SCHED(3584, 14, 16, 16, false);
 HIPSOXR_SCHED(3528, 21, 12, 14, false);
 HIPSOXR_SCHED(2560, 16, 16, 10, true);
@@ -1244,6 +1245,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         HIPSOXR_PAIR(147, 640, 8, false, 5120, 1176, 320), HIPSOXR_PAIR(640, 147, 8, false, 1176, 5120, 320),    // 192k <-> 44.1k
         HIPSOXR_PAIR(640, 441, 8, false, 3528, 5120, 384), HIPSOXR_PAIR(441, 640, 8, false, 5120, 3528, 384),    // 22.05k <-> 32k, 11.025k <-> 16k
         HIPSOXR_PAIR(40, 147, 32, false, 4704, 1280, 384), HIPSOXR_PAIR(147, 40, 32, false, 1280, 4704, 384),    // 44.1k <-> 12k, 88.2k <-> 24k
+        HIPSOXR_PAIR(4, 3, 1280, false, 3840, 5120, 384), HIPSOXR_PAIR(3, 4, 1280, false, 5120, 3840, 384),      // 24k <-> 32k, 12k <-> 16k, 48k <-> 64k
     };
 #undef HIPSOXR_PAIR
     const bool no_pair = switches().fft_no_pair;

@@ -100,7 +100,7 @@ def test_paired_kernel_families_at_size(oracle, in_rate, out_rate, frames):
                                               (192000, 48000), (48000, 192000), (48000, 8000), (8000, 48000),
                                               (44100, 32000), (32000, 44100), (88200, 48000), (48000, 88200),
                                               (96000, 44100), (44100, 96000), (44100, 8000), (8000, 44100),
-                                              (192000, 44100), (44100, 192000), (22050, 32000), (32000, 22050), (44100, 12000), (12000, 44100)])
+                                              (192000, 44100), (44100, 192000), (22050, 32000), (32000, 22050), (44100, 12000), (12000, 44100), (24000, 32000), (32000, 24000)])
 def test_paired_kernel_schedule_table(oracle, in_rate, out_rate):
     """Every further ratio with a compile-time schedule (hipsoxr::launch_fft `pairs` table), HQ and
     VHQ, mono (block pairing) and stereo interleaved (channel pairing), against the float64 oracle."""
