@@ -777,7 +777,8 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     if (v.on && v.n_slew && s->k_done + n > v.k_s + v.n_slew) n = (size_t)(v.k_s + v.n_slew - s->k_done);
     *odone = n;
     if (n == 0) {
-        if (!s->res.running) HIP_TRY(stream_wait(s)); // the caller's input buffer is borrowed only for the call (host ring: copied already)
+        // the caller's input buffer is borrowed only for the call; a host ring took its copy with memcpy, nothing is queued
+        if (!s->res.running && !s->ring_on_host) HIP_TRY(stream_wait(s));
         return nullptr;
     }
     if (n > s->out_cap) {
@@ -1127,7 +1128,7 @@ hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size
         if (const char *e = stream_append(s, in, ilen)) return e;
     }
     if (olen == 0 || out == nullptr) {
-        if (in && ilen && !s->res.running) HIP_TRY(stream_wait(s)); // host buffer is borrowed only for the call
+        if (in && ilen && !s->res.running && !s->ring_on_host) HIP_TRY(stream_wait(s)); // host buffer is borrowed only for the call
         return nullptr;
     }
     return stream_emit(s, out, olen, odone);
