@@ -1508,16 +1508,17 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
     for (int u_ = wave + n_waves * (int)bz; u_ < 2 * a.n_rt; u_ += n_waves * (int)nz) {
         const int unit = __builtin_amdgcn_readfirstlane(u_);
         const int rt = unit >> 1, ph = unit & 1; // periods 32*ph .. 32*ph + 31
-        const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]); // multiples of 16
-        const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
+        const int32_t wL = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]), wR = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
+        const int32_t eL0 = wL & 0xffffff, eR0 = wR & 0xffffff; // multiples of 16
+        const int32_t gL = (a.dbg & 16) ? n_groups : wL >> 24, gR = (a.dbg & 16) ? n_groups : wR >> 24; // groups this tile's half-chains need (build_mfma_planes; HIPSOXR_DEBUG_FLAGS 16: all of them)
         const float4 *tL = (const float4 *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane;
         const float4 *tR = (const float4 *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane;
         f32x4 accL[2], accR[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) { accL[g] = (f32x4){0, 0, 0, 0}; accR[g] = (f32x4){0, 0, 0, 0}; }
 
-        mfma_half_chain<false>(accL, tL, xL + ph * 32 * R, eL0, n_groups, Mc, R, padR);
-        mfma_half_chain<true>(accR, tR, xR + ph * 32 * R, eR0, n_groups, Mc, R, padR);
+        mfma_half_chain<false>(accL, tL, xL + ph * 32 * R, eL0, gL, Mc, R, padR);
+        mfma_half_chain<true>(accR, tR, xR + ph * 32 * R, eR0, gR, Mc, R, padR);
         HIPSOXR_STAMP();
 
         const int32_t r0 = rt * 16 + 4 * kq;
@@ -1628,12 +1629,18 @@ static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
     const int32_t rows_total = (g.x_count + Mc - 1) / Mc + 3; // + slack rows: pipelined reads overrun by one group
     g.plane = (rows_total * g.rowR + 63) / 64 * 64;
     g.lds_bytes = ((size_t)g.plane * 4 + g.rowR) * sizeof(float);
+    // Groups a tile's half-chain really needs (bits 24..31 of its e0 word): the table rows are I_h long for every
+    // tile — the longest span over all tiles, rounded to 16, from a start rounded down to 16 — but the groups past a
+    // tile's own last tap hold only zero coefficients, and fma(0, x, acc) == acc: they are not issued (10-11 of 12
+    // groups at 48k -> 44.1k VHQ).
     g.e0.resize((size_t)g.n_rt * 2);
     for (int rt = 0; rt < g.n_rt; ++rt) {
-        g.e0[rt * 2 + 0] = i0L[rt] - i_min;
-        g.e0[rt * 2 + 1] = i1R[rt] - 15 - i_min;
+        const int64_t r0 = (int64_t)rt * 16, r1 = std::min<int64_t>(r0 + 16, g.Lc) - 1;
+        const int32_t gl = (n_of(r1) + H - i0L[rt] + 15) / 16, gr = (i1R[rt] - (n_of(r0) + H) + 1 + 15) / 16;
+        g.e0[rt * 2 + 0] = (i0L[rt] - i_min) | (std::min(gl, I_h / 16) << 24);
+        g.e0[rt * 2 + 1] = (i1R[rt] - 15 - i_min) | (std::min(gr, I_h / 16) << 24);
     }
-    if (g.lds_bytes > 160 * 1024) return g;
+    if (g.lds_bytes > 160 * 1024 || g.x_count + I_h >= (1 << 24) || I_h / 16 > 127) return g;
     g.ok = true;
     if (tab) {
         const int ng = I_h / 16;
