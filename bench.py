@@ -38,8 +38,8 @@ KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, secon
                 4: "k_tile_mfma_p<float>", 5: "k_fft_pair2<.., float>", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
 # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 +
 # WRITE_SIZE, see profiles/r02_traffic.json); bench.py cannot collect counters itself.
-TRAFFIC_BYTES = {("configs1", 0): 23299277, ("configs1", 5): 23299277,
-                 ("batch_shard", 0): 480381235, ("batch_shard", 5): 480381235}  # profiles/r02_traffic.json
+TRAFFIC_BYTES = {("configs1", 0): 23303168, ("configs1", 5): 23303168,
+                 ("batch_shard", 0): 480379904, ("batch_shard", 5): 480379904}  # profiles/r02_traffic.json
 # VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/r02_rocprofv3_summary.txt): the other
 # resource the frequency-domain kernel is limited by.  An fp32 wave-instruction occupies a SIMD for
 # 2 cycles (SIMD-32, wave64); 256 CUs x 4 SIMDs at 2.4 GHz.
@@ -464,7 +464,7 @@ def main():
                                   "value": x2.numel() / k2 / 1e6, "unit": "Msamples/s", "launch_us": k2 * 1e6,
                                   "roofline": {"bound": "hbm", "achieved": bytes2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
                                                "unit": "GB/s", "frac": bytes2 / k2 / 1e9 / HBM_PEAK_GBS,
-                                               "traffic": 137273344 if args.seconds == 60 else None,  # profiles/r02_traffic.json
+                                               "traffic": 137313485 if args.seconds == 60 else None,  # profiles/r02_traffic.json
                                                "kernel": "k_fft_strided2<4410x1600,float,channel pairs>"}}
             del x2, y2, plan2
         except RuntimeError as e:  # context only
