@@ -130,6 +130,16 @@ class ResampleStream:
         if dither_seed:
             _n.check(_n.lib.hipsoxr_stream_set_dither_seed(self._h, int(dither_seed) & 0xFFFFFFFF))
         self._ended = False
+        self._done = _C.c_size_t(0)
+        self._done_ref = _C.byref(self._done)
+        # Output capacity of a call without asking the library for delay(): after a synchronous call the frames
+        # still pending are those whose filter support reaches past the input, at most (taps/2 + 2) * out/in + 1.
+        # (Variable-rate and deferred streams ask: their backlog is not bounded like that.)
+        self._slack = None
+        if not vr and not deferred:
+            info = _n.PlanInfo()
+            _n.check(_n.lib.hipsoxr_plan_info(_n.lib.hipsoxr_stream_plan(self._h), _C.byref(info)))
+            self._slack = int((info.taps / 2 + 2) * self._ratio) + 4
 
     def __del__(self, _delete=_n.lib.hipsoxr_stream_delete):  # bound early: globals may be gone at exit
         h = getattr(self, "_h", None)
@@ -138,22 +148,27 @@ class ResampleStream:
             self._h = None
 
     # -- the counterpart of CSoxr::process (src/soxr_ext.cpp:129-188) ---------------------------
-    def _process(self, x, last):
+    def _process(self, x, last, mono=False):
+        """x: 2-D [frame, channel], or 1-D when mono (the result then is 1-D too)."""
         if self._ended:
             raise RuntimeError("Input after last input")
-        if x.shape[1] != self._channels:
+        if (1 if mono else x.shape[1]) != self._channels:
             raise ValueError("Channel num mismatch")
-        x = np.ascontiguousarray(x)
+        if not x.flags.c_contiguous:
+            x = np.ascontiguousarray(x)
         frames = x.shape[0]
-        cap = int(_n.lib.hipsoxr_stream_delay(self._h) + frames * self._ratio) + 2
-        y = np.empty((cap, self._channels), self._type)
-        done = _C.c_size_t(0)
-        pos = 0
+        if self._slack is not None:
+            cap = int(frames * self._ratio) + self._slack
+        else:
+            cap = int(_n.lib.hipsoxr_stream_delay(self._h) + frames * self._ratio) + 2
+        y = np.empty(cap if mono else (cap, self._channels), self._type)
+        done = self._done
         # a zero-length chunk still drains (in != NULL, ilen == 0)
         in_ptr = x.ctypes.data if frames else y.ctypes.data
-        _n.check(_n.lib.hipsoxr_stream_process(self._h, in_ptr, frames, y.ctypes.data, cap,
-                                               _C.byref(done)))
-        pos += done.value
+        err = _n.lib.hipsoxr_stream_process(self._h, in_ptr, frames, y.ctypes.data, cap, self._done_ref)
+        if err:
+            _n.check(err)
+        pos = done.value
         if last:
             self._ended = True
             row = self._channels * self._type.itemsize
@@ -161,7 +176,7 @@ class ResampleStream:
                 if pos >= y.shape[0]:
                     y = np.concatenate([y, np.empty_like(y)])
                 _n.check(_n.lib.hipsoxr_stream_process(self._h, None, 0, y.ctypes.data + pos * row,
-                                                       y.shape[0] - pos, _C.byref(done)))
+                                                       y.shape[0] - pos, self._done_ref))
                 if done.value == 0:
                     break
                 pos += done.value
@@ -174,7 +189,7 @@ class ResampleStream:
             raise TypeError(
                 f"Input should be a `np.ndarray` with matching dtype for ResampleStream({self._type}).")
         if x.ndim == 1:
-            return self._process(x[:, None], last)[:, 0]
+            return self._process(x, last, True)
         if x.ndim == 2:
             return self._process(x, last)
         raise ValueError("Input must be 1-D or 2-D array")
