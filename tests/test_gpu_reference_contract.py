@@ -204,3 +204,23 @@ def test_deferred_stream_small_output_buffer(soxr):
         pos += done.value
     nat.lib.hipsoxr_stream_delete(h)
     assert pos == len(want) and np.array_equal(out[:pos], want)
+
+
+@pytest.mark.parametrize("rates,quality", [((44100, 16000), "VHQ"), ((16000, 44100), "VHQ"), ((48000, 44100), "HQ"),
+                                           ((44100, 44101), "HQ"), ((8000, 192000), "MQ"), ((192000, 8000), "LQ"),
+                                           ((48000, 47999.5), "VHQ")])
+def test_stream_backlog_bound(soxr, rates, quality):
+    """resample_chunk sizes its output buffer from a bound on the frames a synchronous stream can still owe —
+    (taps/2 + 2) * out/in + 1 — instead of asking delay() every call: the bound must hold after every call, for
+    exact and interpolated plans, whatever the chunk size (a violated bound would only delay frames, silently)."""
+    from soxr_amd import device as dev
+    plan = dev.Plan(*rates, quality)
+    ratio = rates[1] / rates[0]
+    bound = (plan.taps / 2 + 2) * ratio + 1
+    rng = np.random.default_rng(7)
+    rs = soxr.ResampleStream(*rates, 1, dtype=np.float32, quality=quality)
+    fed = 0
+    for n in [1, 7, 100, 3, 2000, 441, 1, 1, 5000, 64, 9999]:
+        rs.resample_chunk((rng.standard_normal(n) * 0.25).astype(np.float32))
+        fed += n
+        assert rs.delay() <= bound, (n, fed, rs.delay(), bound)
