@@ -86,6 +86,7 @@ struct Switches {
     int dbg_flags = 0;            // HIPSOXR_DEBUG_FLAGS      1 no staging, 2 no LDS reads, 4 no coefficient loads, 8 no stores
     int dbg_nrt = 0, dbg_nw = 0;  // HIPSOXR_DEBUG_NRT / _NW  tiles / waves per workgroup
     int dbg_split = 0;            // HIPSOXR_DEBUG_SPLIT      grid.z unit split
+    int dbg_chain_no = 0;         // HIPSOXR_DEBUG_CHAIN_NO   outputs per workgroup of k_chain (power of two <= 32)
     size_t dbg_lds = 0;           // HIPSOXR_DEBUG_LDS        extra dynamic LDS (occupancy experiments)
     size_t dbg_fft_lds = 0;       // HIPSOXR_DEBUG_FFT_LDS    the same for k_fft_block
     const char *dbg_trace = nullptr; // HIPSOXR_DEBUG_TRACE   path for per-wave s_memtime stamps (k_tile_mfma_p)

@@ -62,7 +62,7 @@ const Switches &switches()
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_small_4pass = on("HIPSOXR_FFT_SMALL_4PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
         w.no_planes = on("HIPSOXR_NO_PLANES");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
@@ -1904,7 +1904,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             int NO = nf <= 2048 ? 8 : 32;
             // (resident form: every workgroup polls the mailbox and reads its span over PCIe — at most 64 of them)
             if (res && nf > 512) NO = 32;
-            if (getenv("HIPSOXR_DEBUG_NO")) NO = atoi(getenv("HIPSOXR_DEBUG_NO"));
+            if (switches().dbg_chain_no) NO = switches().dbg_chain_no;
             // LDS: NO coefficient rows of T + V words, the shared input span (T + what NO-1 window shifts of at
             // most ceil(M/L) + 1 samples add; variable rate: the plan's ratio is the largest step), bookkeeping
             const int64_t shift = (p->M + p->L - 1) / p->L + 2;
