@@ -70,6 +70,7 @@ struct Switches {
     bool fft_no_xcd_map = false;  // HIPSOXR_FFT_NO_XCD_MAP   plain (block, column) workgroup ids for interleaved data
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
+    bool fft_no_tiny = false;     // HIPSOXR_FFT_NO_TINY      never the quarter-size blocks
     bool fft_small_4pass = false; // HIPSOXR_FFT_SMALL_4PASS  small 48k->44.1k jobs on round 1's four-pass low-latency schedule (first-generation kernel)
     bool fft_pair_v1 = false;     // HIPSOXR_FFT_PAIR_V1      unit-stride jobs on k_fft_pair instead of k_fft_pair2
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p

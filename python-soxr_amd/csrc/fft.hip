@@ -1219,7 +1219,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     };
     // ---- paired-block kernels: compile-time schedules for the common ratios -------------------
     struct PairEntry {
-        int64_t L, M; int k; bool small; void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); void (*kern2d)(FftArgs);
+        int64_t L, M; int k; int small; /* 0: full-size blocks, 1: half-size (small jobs), 2: quarter-size (smaller still) */
+        void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); void (*kern2d)(FftArgs);
         void (*kcp)(FftArgs); void (*kcpd)(FftArgs); // channel-pair mode (interleaved data), float32 / float64
         void (*kst)(FftArgs); void (*kstd)(FftArgs); // strided columns, two blocks per transform
     };
@@ -1231,6 +1232,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
         HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
         HIPSOXR_PAIR(160, 147, 32, false, 4704, 5120, 384), HIPSOXR_PAIR(160, 147, 16, true, 2352, 2560, 384),   // 44.1k -> 48k
+        HIPSOXR_PAIR(147, 160, 8, 2, 1280, 1176, 256), HIPSOXR_PAIR(160, 147, 8, 2, 1176, 1280, 256),           // ... quarter-size blocks: jobs of a few hundred pairs
         HIPSOXR_PAIR(160, 441, 16, false, 7056, 2560, 448), HIPSOXR_PAIR(441, 160, 16, false, 2560, 7056, 448),  // 44.1k <-> 16k
         HIPSOXR_PAIR(160, 441, 10, true, 4410, 1600, 320), HIPSOXR_PAIR(441, 160, 10, true, 1600, 4410, 320),    // ... 35 KB blocks: 4 workgroups per CU
         HIPSOXR_PAIR(1, 2, 2048, false, 4096, 2048, 256), HIPSOXR_PAIR(2, 1, 2048, false, 2048, 4096, 256),      // 2:1, 1:2
@@ -1254,11 +1256,13 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     // float64: the second-generation kernels only (unit-stride columns; channel pairs; strided columns) — else the exact engine
     if (f64 && (no_pair || cols_p > 65535)) return nullptr;
     if (!no_pair && cols_p <= 65535) {
-        const PairEntry *big = nullptr, *sml = nullptr;
-        int big_i = 0, sml_i = 0;
+        const PairEntry *big = nullptr, *sml = nullptr, *tiny = nullptr;
+        int big_i = 0, sml_i = 0, tiny_i = 0;
         for (int i = 0; i < (int)(sizeof pairs / sizeof pairs[0]); ++i)
             if (pairs[i].L == p->L && pairs[i].M == p->M) {
-                if (pairs[i].small) { sml = &pairs[i]; sml_i = i; } else { big = &pairs[i]; big_i = i; }
+                if (pairs[i].small == 2) { tiny = &pairs[i]; tiny_i = i; }
+                else if (pairs[i].small) { sml = &pairs[i]; sml_i = i; }
+                else { big = &pairs[i]; big_i = i; }
             }
         if (big) {
             FftGeom g;
@@ -1276,6 +1280,17 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     FftGeom gs;
                     if (const char *err = get(2 + sml_i, sml->k, &gs)) return err;
                     if (gs.ok) { g = gs; use = sml; }
+                }
+            }
+            // Fewer still (a 60 s clip is 612 pairs of half-size blocks on 2048 workgroup slots): the launch is the
+            // latency of one workgroup plus what queues behind it; quarter-size blocks (10 KB of LDS, 32 % overlap)
+            // shorten both: 2 s clip 7.4 -> 6.5 us, 10 s HQ 7.6 -> 6.2 us, 30 s 9.0 -> 7.7 us (60 s: 10.85 vs 10.73 us).
+            if (use == sml && tiny && !f64 && !switches().fft_large_only && !switches().fft_no_tiny) {
+                const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
+                if (wgs <= 500) { // (at 612 — the 60 s clip — the two sizes are within 1 %)
+                    FftGeom gt;
+                    if (const char *err = get(2 + tiny_i, tiny->k, &gt)) return err;
+                    if (gt.ok) { g = gt; use = tiny; }
                 }
             }
             // Round 1: latency-bound jobs (under ~400 workgroups) ran a four-pass radix <= 8 schedule with prefetched

@@ -236,3 +236,23 @@ def test_strided_column_kernel(oracle, dtype, tol, in_rate, out_rate, ch):
     if ch > 1:
         yc = dev.resample_tensor(plan, xc, kernel=FFT).cpu().numpy()
         assert _rms(yc - dev.resample_tensor(plan, wt[:, :, :ch], kernel=FFT).cpu().numpy()) <= 5e-7 * _rms(yc)
+
+
+@pytest.mark.parametrize("in_rate,out_rate,frames", [(48000, 44100, 96000), (48000, 44100, 1300000), (44100, 48000, 700000)])
+@pytest.mark.parametrize("quality", ["VHQ", "HQ"])
+def test_quarter_size_blocks(oracle, in_rate, out_rate, frames, quality):
+    """Jobs of a few hundred block pairs run quarter-size blocks (1280/1176 points): same bar against the oracle,
+    first and last outputs included, and no block seam stands out."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(frames)
+    x = (rng.standard_normal(frames + 11) * 0.25).astype(np.float32)
+    plan = dev.Plan(in_rate, out_rate, quality)
+    y = dev.resample_tensor(plan, torch.from_numpy(x).cuda()).cpu().numpy()        # AUTO
+    ref = oracle.resample(x, in_rate, out_rate, quality, mode="ref")
+    assert y.shape == ref.shape
+    err = y.astype(np.float64) - ref
+    assert _rms(err) / _rms(ref) <= 1e-6
+    seg = np.sqrt(np.mean(err[: len(err) // 2048 * 2048].reshape(-1, 2048) ** 2, axis=1))
+    assert seg.max() <= 4e-6 * _rms(ref)
+    assert abs(err[:500]).max() <= 1e-5 and abs(err[-500:]).max() <= 1e-5
