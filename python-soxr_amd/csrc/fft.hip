@@ -1285,9 +1285,11 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             // Fewer still (a 60 s clip is 612 pairs of half-size blocks on 2048 workgroup slots): the launch is the
             // latency of one workgroup plus what queues behind it; quarter-size blocks (10 KB of LDS, 32 % overlap)
             // shorten both: 2 s clip 7.4 -> 6.5 us, 10 s HQ 7.6 -> 6.2 us, 30 s 9.0 -> 7.7 us (60 s: 10.85 vs 10.73 us).
-            if (use == sml && tiny && !f64 && !switches().fft_large_only && !switches().fft_no_tiny) {
+            if (use == sml && tiny && !switches().fft_large_only && !switches().fft_no_tiny) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
-                if (wgs <= 500) { // (at 612 — the 60 s clip — the two sizes are within 1 %)
+                // (float32: at 612 pairs — the 60 s clip — the two sizes are within 1 %.  float64: 16 bytes per point, and
+                //  the 20 KB blocks win at every size — 60 s mono 27.1 -> 21.6 us, 64 x 10 s 236 -> 202 us, stereo 60 s 47 -> 37 us)
+                if (f64 || wgs <= 500) {
                     FftGeom gt;
                     if (const char *err = get(2 + tiny_i, tiny->k, &gt)) return err;
                     if (gt.ok) { g = gt; use = tiny; }
