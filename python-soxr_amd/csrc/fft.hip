@@ -628,6 +628,7 @@ HIPSOXR_SCHED(4096, 16, 16, 16, true);
 HIPSOXR_SCHED(3840, 16, 16, 15, true);
 HIPSOXR_SCHED(3584, 14, 16, 16, false);
 HIPSOXR_SCHED(3528, 21, 12, 14, false);
+HIPSOXR_SCHED(2688, 21, 16, 8, false);
 HIPSOXR_SCHED(2560, 16, 16, 10, true);
 HIPSOXR_SCHED(2352, 21, 16, 7, false);
 HIPSOXR_SCHED(2048, 16, 16, 8, true);
@@ -1240,6 +1241,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         HIPSOXR_PAIR(1, 2, 1024, true, 2048, 1024, 256), HIPSOXR_PAIR(2, 1, 1024, true, 1024, 2048, 256),        // ... half-size blocks: small jobs (10 s mono 7.5 -> 6.6 us), float64
         HIPSOXR_PAIR(1, 3, 1792, false, 5376, 1792, 384), HIPSOXR_PAIR(3, 1, 1792, false, 1792, 5376, 384),      // 48k <-> 16k
         HIPSOXR_PAIR(2, 3, 1792, false, 5376, 3584, 384), HIPSOXR_PAIR(3, 2, 1792, false, 3584, 5376, 384),      // 48k <-> 32k
+        HIPSOXR_PAIR(1, 3, 896, true, 2688, 896, 384), HIPSOXR_PAIR(3, 1, 896, true, 896, 2688, 384),            // ... half-size blocks for both:
+        HIPSOXR_PAIR(2, 3, 896, true, 2688, 1792, 384), HIPSOXR_PAIR(3, 2, 896, true, 1792, 2688, 384),          //     small jobs, float64
         HIPSOXR_PAIR(1, 4, 1280, false, 5120, 1280, 320), HIPSOXR_PAIR(4, 1, 1280, false, 1280, 5120, 320),      // 4:1, 1:4
         HIPSOXR_PAIR(1, 6, 896, false, 5376, 896, 384), HIPSOXR_PAIR(6, 1, 896, false, 896, 5376, 384),          // 48k <-> 8k
         HIPSOXR_PAIR(320, 441, 16, false, 7056, 5120, 448), HIPSOXR_PAIR(441, 320, 16, false, 5120, 7056, 448),  // 44.1k <-> 32k
