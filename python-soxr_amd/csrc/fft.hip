@@ -1226,17 +1226,21 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         void (*kcp)(FftArgs); void (*kcpd)(FftArgs); // channel-pair mode (interleaved data), float32 / float64
         void (*kst)(FftArgs); void (*kstd)(FftArgs); // strided columns, two blocks per transform
     };
-#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) \
-    {L, M, k, small, k_fft_pair<PairOf<NA, NB, NT>>, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>, \
+// (the first-generation kernel is instantiated only where the A/B tools use it — the 44.1k <-> 48k and 44.1k <-> 16k
+//  families: HIPSOXR_PAIR_V1; elsewhere a job the second-generation kernels cannot take goes to k_fft_block)
+#define HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, V1) \
+    {L, M, k, small, V1, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, true>, k_fft_strided2<PairOf<NA, NB, NT>, double, true>, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>}
+#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, nullptr)
+#define HIPSOXR_PAIR_V1(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, (k_fft_pair<PairOf<NA, NB, NT>>))
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
-        HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
-        HIPSOXR_PAIR(160, 147, 32, false, 4704, 5120, 384), HIPSOXR_PAIR(160, 147, 16, true, 2352, 2560, 384),   // 44.1k -> 48k
+        HIPSOXR_PAIR_V1(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR_V1(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
+        HIPSOXR_PAIR_V1(160, 147, 32, false, 4704, 5120, 384), HIPSOXR_PAIR_V1(160, 147, 16, true, 2352, 2560, 384),   // 44.1k -> 48k
         HIPSOXR_PAIR(147, 160, 8, 2, 1280, 1176, 256), HIPSOXR_PAIR(160, 147, 8, 2, 1176, 1280, 256),           // ... quarter-size blocks: jobs of a few hundred pairs
-        HIPSOXR_PAIR(160, 441, 16, false, 7056, 2560, 448), HIPSOXR_PAIR(441, 160, 16, false, 2560, 7056, 448),  // 44.1k <-> 16k
-        HIPSOXR_PAIR(160, 441, 10, true, 4410, 1600, 320), HIPSOXR_PAIR(441, 160, 10, true, 1600, 4410, 320),    // ... 35 KB blocks: 4 workgroups per CU
+        HIPSOXR_PAIR_V1(160, 441, 16, false, 7056, 2560, 448), HIPSOXR_PAIR_V1(441, 160, 16, false, 2560, 7056, 448),  // 44.1k <-> 16k
+        HIPSOXR_PAIR_V1(160, 441, 10, true, 4410, 1600, 320), HIPSOXR_PAIR_V1(441, 160, 10, true, 1600, 4410, 320),    // ... 35 KB blocks: 4 workgroups per CU
         HIPSOXR_PAIR(1, 2, 2048, false, 4096, 2048, 256), HIPSOXR_PAIR(2, 1, 2048, false, 2048, 4096, 256),      // 2:1, 1:2
         HIPSOXR_PAIR(1, 2, 1024, true, 2048, 1024, 256), HIPSOXR_PAIR(2, 1, 1024, true, 1024, 2048, 256),        // ... half-size blocks: small jobs (10 s mono 7.5 -> 6.6 us), float64
         HIPSOXR_PAIR(1, 3, 1792, false, 5376, 1792, 384), HIPSOXR_PAIR(3, 1, 1792, false, 1792, 5376, 384),      // 48k <-> 16k
@@ -1337,10 +1341,10 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 // through this one or not at all
                 const bool cp2 = (f64 ? use->kcpd : use->kcp) != nullptr && !switches().fft_pair_v1 &&
                                  (int64_t)std::max(g.N_in, g.N_out) * std::max(j.in_frame_stride, j.out_frame_stride) * (int64_t)esz < (1LL << 30);
-                a.chpair = (cp_layout && (cp2 || (cp_aligned && !f64))) ? 1 : 0;
+                a.chpair = (cp_layout && (cp2 || (cp_aligned && !f64 && use->kern))) ? 1 : 0;
                 const size_t lds = std::max((size_t)std::max(g.N_in, g.N_out) * (f64 ? sizeof(double2) : sizeof(float2)), switches().dbg_fft_lds);
                 if (f64 && lds > 160 * 1024) return nullptr;
-                if (lds > 64 * 1024)
+                if (lds > 64 * 1024 && use->kern)
                     HIP_TRY(hipFuncSetAttribute((const void *)use->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 // work items per channel unit: blocks (channel pairs) or pairs of blocks (single channels)
                 const int64_t items = a.chpair ? n_blocks : (n_blocks + 1) / 2, items8 = (items + 7) / 8 * 8;
@@ -1371,6 +1375,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }
+                if (!kern) return nullptr; // (no first-generation instance of this schedule: the general path takes the job)
 #ifdef FFT2_TRACE
                 size_t trace_n = 0;
                 if (switches().dbg_trace && (kern == use->kern2 || kern == use->kern2d)) {
