@@ -1061,6 +1061,29 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two translation units.  Every schedule of the table below is 6 kernels (k_fft_pair2 and k_fft_strided2 x 2, each in
+// float32 and float64); compiled in one piece they are the build's critical path (4 minutes).  build.sh compiles this
+// file twice: -DFFT_PART=0 = everything except the kernels of the schedules listed here (declared extern), and
+// -DFFT_PART=1 = the templates above plus exactly those kernels, no host code.  Without FFT_PART: one piece.
+// ---------------------------------------------------------------------------------------------
+#define HIPSOXR_PART1_SPECS(X) X(4096, 2048, 256) X(2048, 4096, 256) X(2048, 1024, 256) X(1024, 2048, 256) X(5376, 1792, 384) X(1792, 5376, 384) X(5376, 3584, 384) X(3584, 5376, 384) X(2688, 896, 384) X(896, 2688, 384) X(2688, 1792, 384) X(1792, 2688, 384) X(5120, 1280, 320) X(1280, 5120, 320) X(5376, 896, 384) X(896, 5376, 384) X(7056, 5120, 448) X(5120, 7056, 448) X(4704, 2560, 384) X(2560, 4704, 384) X(5120, 2352, 384) X(2352, 5120, 384) X(7056, 1280, 448) X(1280, 7056, 448) X(5120, 1176, 320) X(1176, 5120, 320) X(3528, 5120, 384) X(5120, 3528, 384) X(4704, 1280, 384) X(1280, 4704, 384) X(3840, 5120, 384) X(5120, 3840, 384)
+#define HIPSOXR_INST(NA, NB, NT)                                                                        \
+    HIPSOXR_EXTERN template __global__ void k_fft_pair2<PairOf<NA, NB, NT>, float>(FftArgs);             \
+    HIPSOXR_EXTERN template __global__ void k_fft_pair2<PairOf<NA, NB, NT>, double>(FftArgs);            \
+    HIPSOXR_EXTERN template __global__ void k_fft_strided2<PairOf<NA, NB, NT>, float, true>(FftArgs);    \
+    HIPSOXR_EXTERN template __global__ void k_fft_strided2<PairOf<NA, NB, NT>, double, true>(FftArgs);   \
+    HIPSOXR_EXTERN template __global__ void k_fft_strided2<PairOf<NA, NB, NT>, float, false>(FftArgs);   \
+    HIPSOXR_EXTERN template __global__ void k_fft_strided2<PairOf<NA, NB, NT>, double, false>(FftArgs);
+#if defined(FFT_PART) && FFT_PART == 0
+#define HIPSOXR_EXTERN extern
+HIPSOXR_PART1_SPECS(HIPSOXR_INST)
+#elif defined(FFT_PART) && FFT_PART == 1
+#define HIPSOXR_EXTERN
+HIPSOXR_PART1_SPECS(HIPSOXR_INST)
+#endif
+
+#if !defined(FFT_PART) || FFT_PART != 1
+// ---------------------------------------------------------------------------------------------
 // host: geometry, tables
 // ---------------------------------------------------------------------------------------------
 struct FftGeom {
@@ -1445,5 +1468,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     *handled = true;
     return nullptr;
 }
+
+#endif // host part (FFT_PART != 1)
 
 } // namespace hipsoxr
