@@ -95,9 +95,14 @@ typedef enum {
     HIPSOXR_KERNEL_FFT = 5,    /* frequency-domain overlap-save engine (whole-signal float32 jobs; 1e-6-class,
                                   not bit-identical to the canonical order) */
     HIPSOXR_KERNEL_EXACT = 6,  /* AUTO restricted to the canonical-order kernels (bit-exact invariances) */
-    HIPSOXR_KERNEL_WAVE_DOT = 7 /* reference point only: one wavefront per output sample + shuffle reduction
+    HIPSOXR_KERNEL_WAVE_DOT = 7, /* reference point only: one wavefront per output sample + shuffle reduction
                                   (the shape BASELINE.json's north star describes); 64-way tree order, so
                                   1e-6-class like FFT, never chosen automatically */
+    HIPSOXR_KERNEL_FFT_F64 = 8  /* the frequency-domain engine computing in float64 whatever the I/O type: float32
+                                  jobs at the width libsoxr's VHQ recipe itself computes in (its float64 engine;
+                                  reference src/soxr_ext.cpp:74,228 pass the recipe through unchanged) — results
+                                  differ from the float64 direct form by the float32 OUTPUT rounding only
+                                  (~3e-8 relative RMS).  Unit-stride columns of the tabled ratios. */
 } hipsoxr_kernel_t;
 
 typedef struct hipsoxr_plan hipsoxr_plan_t;     /* immutable: ratio + polyphase bank (host + device) */

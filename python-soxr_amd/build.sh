@@ -12,8 +12,12 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/csrc"
-OUT="$HERE/soxr_amd/libhipsoxr.so"
+# HIPSOXR_VARIANT=<name>: an experiment build (with HIPSOXR_EXTRA_FLAGS) into _variants/<name>/ beside the product
+# library, so that several builds made here travel to the GPU box in one snapshot (tools/with_variant.sh swaps one in).
+OUTDIR="$HERE/soxr_amd"
 OBJ="$HERE/_obj"   # (not build/: that name belongs to setuptools when a wheel is built from this directory)
+if [ -n "$HIPSOXR_VARIANT" ]; then OUTDIR="$HERE/_variants/$HIPSOXR_VARIANT"; OBJ="$HERE/_obj/$HIPSOXR_VARIANT"; mkdir -p "$OUTDIR"; fi
+OUT="$OUTDIR/libhipsoxr.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -I$HERE/../include"
 mkdir -p "$OBJ"
@@ -29,6 +33,6 @@ OBJS="$OBJ/plan.o $OBJ/engine.o $OBJ/kernels.o $OBJ/fft.o $OBJ/fft1.o $OBJ/soxr_
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT"
 # The same engine under libsoxr's name: what `find_library(SOXR_LIBRARY NAMES soxr)` of the
 # reference's USE_SYSTEM_LIBSOXR build picks up (reference CMakeLists.txt:83-93).
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libsoxr.so.0 $OBJS -o "$HERE/soxr_amd/libsoxr.so.0"
-ln -sf libsoxr.so.0 "$HERE/soxr_amd/libsoxr.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libsoxr.so.0 $OBJS -o "$OUTDIR/libsoxr.so.0"
+ln -sf libsoxr.so.0 "$OUTDIR/libsoxr.so"
 echo "built $OUT (+ libsoxr.so.0)"

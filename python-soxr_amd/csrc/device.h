@@ -41,8 +41,11 @@ struct ResidentLaunch {
     uint32_t base_seq;     // messages taken by earlier instances
     uint32_t epoch;        // number of this instance (never 0)
     int64_t idle_us;       // the instance leaves after this long without a message
+    int64_t used_mcu = 0;  // in: milli-CUs already held by this process's resident instances
     uint32_t n_wgs = 0;    // out: workgroups of the instance
     int64_t max_out = 0;   // out: outputs per column one message may ask for
+    uint32_t cost_mcu = 0; // out: CU capacity the instance occupies, n_wgs * 1024 / (workgroups that fit one CU)
+    bool over_budget = false; // out: refused because used_mcu + cost_mcu would exceed half the chip
 };
 // Completion words for a small launch: if the job turns out to be ONE launch of the small-launch kernel (k_chain) of at
 // most `cap` workgroups, each workgroup stores `seq` into words[w] (pinned host memory) after its results are in host

@@ -128,6 +128,7 @@ struct hipsoxr_stream {
         const void *in = nullptr; void *out = nullptr; // what the running instance was launched on
         int64_t max_out = 0;
         unsigned n_wgs = 0;
+        uint32_t cost_mcu = 0;       // what the running instance holds of the process-wide budget (milli-CUs)
         unsigned failed = 0;         // launches refused (job not eligible): stop trying
     } res;
     int device = -1;         // the device the HIP stream and every buffer above live on
@@ -154,8 +155,10 @@ struct DeviceGuard {
 // Resident kernels hold workgroup slots for as long as they live, and one that cannot get its slots keeps its
 // host waiting: the process admits at most kResidentBudget resident workgroups at a time (a stream over the
 // budget simply takes the ordinary path for that call and tries again later).
-static std::atomic<int> g_resident_wgs{0};
-static const int kResidentBudget = 512;
+// The budget counts CU capacity, not workgroups: an instance of n workgroups whose kernel fits `occ` per CU costs
+// n * 1024 / occ milli-CUs (with a large-LDS plan, one workgroup per CU, 64 workgroups are 64 CUs), and the process
+// keeps at most half the chip resident, so every admitted instance's workgroups really are on the chip together.
+static std::atomic<int64_t> g_resident_mcu{0};
 
 // Retire the stream's resident kernel, if one is running: everything else that uses the HIP stream queues
 // behind it (and would wait until it leaves by itself, HIPSOXR_RESIDENT_IDLE_US later).
@@ -165,7 +168,7 @@ static void resident_stop(hipsoxr_stream *s)
     resident_leave(s->res.words, s->res.epoch);
     (void)hipStreamSynchronize(s->st);
     s->res.running = false;
-    g_resident_wgs -= (int)s->res.n_wgs;
+    g_resident_mcu -= (int64_t)s->res.cost_mcu;
 }
 
 static hipError_t stream_wait(hipsoxr_stream *s)
@@ -707,14 +710,15 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
         rl.epoch = r.epoch; rl.idle_us = std::max(50, switches().resident_idle_us);
         hipsoxr_job_t cap = jr; // room for chunks a quarter longer than this one
         cap.out_frames = std::max<int64_t>(64, j.out_frames + j.out_frames / 4 + 2);
-        if (g_resident_wgs.load() >= kResidentBudget) return ""; // (over the budget: the ordinary path, this time)
+        rl.used_mcu = g_resident_mcu.load(); // (the launcher knows occupancy and CU count: it refuses what does not fit)
         if (const char *e = launch_job(&s->plan->p, cap, s->st, nullptr, &rl)) {
+            if (rl.over_budget) return ""; // over the budget: the ordinary path, this time
             (void)e; // not a job the resident form serves: the ordinary path does
             ++r.failed;
             return "";
         }
-        g_resident_wgs += (int)rl.n_wgs;
-        r.running = true; r.in = jr.in; r.out = j.out; r.max_out = rl.max_out; r.n_wgs = rl.n_wgs; r.failed = 0;
+        g_resident_mcu += (int64_t)rl.cost_mcu;
+        r.running = true; r.in = jr.in; r.out = j.out; r.max_out = rl.max_out; r.n_wgs = rl.n_wgs; r.cost_mcu = rl.cost_mcu; r.failed = 0;
         return nullptr;
     };
     if (!r.running) {
@@ -735,7 +739,7 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
             // instance takes it.  (An instance answers a message completely or not at all: k_chain_resident.)
             (void)hipStreamSynchronize(s->st);
             r.running = false;
-            g_resident_wgs -= (int)r.n_wgs;
+            g_resident_mcu -= (int64_t)r.cost_mcu;
             while (next < r.n_wgs && done[next] == seq) ++next;
             if (next == r.n_wgs) break;
             // (refused — over the budget, say: nobody has touched the message, the ordinary path serves this call;
@@ -744,8 +748,13 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
             next = 0;
         }
         __builtin_ia32_pause();
-        if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+        if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+            // Retire the instance (leave word, wait for it to drain, give its budget back) and stop using the resident
+            // path on this stream: later calls must not post to a dead instance or hold capacity it no longer uses.
+            resident_stop(s);
+            r.failed = 2;
             return "resident kernel does not answer";
+        }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
 #ifdef HIPSOXR_RES_TRACE
@@ -881,6 +890,21 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
 // and returns without waiting for 2 and 3.  The concatenated output is bit-identical to the synchronous
 // mode; only the call on which a frame appears moves (one call later), and delay() counts it as pending.
 // Constant-rate interleaved streams with small chunks (results <= 1 MiB); anything else runs synchronously.
+// Hand out (up to olen frames of) what the last deferred launch produced, waiting for it if need be.
+static const char *deferred_take(hipsoxr_stream *s, void *out, size_t olen, size_t *got)
+{
+    *got = 0;
+    if (s->pend_off >= s->pend_n) return nullptr;
+    const size_t frame = (size_t)s->ch * esz(s);
+    if (s->ev_res[s->pend_slot]) HIP_TRY(hipEventSynchronize(s->ev_res[s->pend_slot]));
+    else HIP_TRY(hipStreamSynchronize(s->st));
+    const size_t take = std::min(s->pend_n - s->pend_off, olen);
+    std::memcpy(out, (char *)s->h_res[s->pend_slot] + s->pend_off * frame, take * frame);
+    s->pend_off += take;
+    *got = take;
+    return nullptr;
+}
+
 static const char *stream_process_deferred(hipsoxr_stream *s, const void *in, size_t ilen, void *out, size_t olen,
                                            size_t *odone)
 {
@@ -888,14 +912,7 @@ static const char *stream_process_deferred(hipsoxr_stream *s, const void *in, si
     const size_t frame = (size_t)s->ch * esz(s);
     size_t got = 0;
     // 1. the previous launch's result
-    if (s->pend_off < s->pend_n) {
-        if (s->ev_res[s->pend_slot]) HIP_TRY(hipEventSynchronize(s->ev_res[s->pend_slot]));
-        else HIP_TRY(hipStreamSynchronize(s->st));
-        const size_t take = std::min(s->pend_n - s->pend_off, olen);
-        std::memcpy(out, (char *)s->h_res[s->pend_slot] + s->pend_off * frame, take * frame);
-        s->pend_off += take;
-        got = take;
-    }
+    if (const char *e = deferred_take(s, out, olen, &got)) return e;
     // 2. this call's input.  Device ring: through one of two pinned bounce buffers, alternating; the copy
     //    issued from this one two calls ago may still sit in the stream behind a long kernel (no launch, hence
     //    no completion observed, while the caller drains a backlog): its own event says when it is free.
@@ -934,7 +951,17 @@ static const char *stream_process_deferred(hipsoxr_stream *s, const void *in, si
         s->pend_n = s->pend_off = 0;
         const uint64_t k_end = k_avail(p, s->n_in_total);
         size_t n = k_end > s->k_done ? (size_t)(k_end - s->k_done) : 0;
-        if (n * frame > kPinnedMax) n = kPinnedMax / frame;
+        if (n * frame > kPinnedMax) {
+            // More than one pinned result buffer holds (chunks whose output exceeds 1 MiB, or a backlog left by a
+            // caller who drained slowly): one capped launch per call would fall behind by the excess on every call
+            // and the ring would grow without bound.  This call runs synchronously instead — everything computable
+            // now, as far as the caller's buffer reaches; the rest stays pending exactly as in synchronous mode.
+            size_t more = 0;
+            if (got < olen)
+                if (const char *e = stream_emit(s, (char *)out + got * frame, olen - got, &more)) return e;
+            *odone = got + more;
+            return nullptr;
+        }
         const int slot = s->pend_slot ^ 1;
         if (n && !pinned_ensure(&s->h_res[slot], &s->h_res_bytes[slot], n * frame)) {
             if (!s->ev_res[slot] && hipEventCreateWithFlags(&s->ev_res[slot], hipEventDisableTiming) != hipSuccess)
@@ -1106,15 +1133,13 @@ hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size
     *odone = 0;
     if (s->defer && out && olen) {
         if (in != nullptr) return stream_process_deferred(s, in, ilen, out, olen, odone);
-        // end of input: what is still pending first, then the synchronous flush for the rest
+        // End of input: what the last launch produced first, then — in the SAME call — the synchronous flush for
+        // everything else (frames appended without a launch included).  No deferred launch is made here, so a
+        // return of 0 means the stream is dry, which is what drain loops take it to mean (src/soxr_ext.cpp:114-125).
         size_t got = 0;
-        if (const char *e = stream_process_deferred(s, s /* non-null, no input */, 0, out, olen, &got)) return e;
-        if (s->pend_off < s->pend_n || got == olen) { *odone = got; return nullptr; }
-        // (the deferred step may have launched once more: hand that out too before flushing)
-        size_t got2 = 0;
-        if (const char *e = stream_process_deferred(s, s, 0, (char *)out + got * s->ch * esz(s), olen - got, &got2)) return e;
-        got += got2;
-        if (s->pend_off < s->pend_n || got == olen) { *odone = got; return nullptr; }
+        if (const char *e = deferred_take(s, out, olen, &got)) return e;
+        if (s->pend_off < s->pend_n || got == olen) { *odone = got; return nullptr; } // (olen > 0: got > 0 here)
+        s->pend_n = s->pend_off = 0;
         s->ended = true;
         size_t tail = 0;
         if (const char *e = stream_emit(s, (char *)out + got * s->ch * esz(s), olen - got, &tail)) return e;

@@ -824,15 +824,19 @@ template <> struct PairTabs<double> {
 // Real = float: float32 device jobs.  Real = double: float64 device jobs — libsoxr's own VHQ engine is a
 // float64 one; the same chain in double2 (LDS 16 bytes per point), results within the
 // method's own floor of the float64 direct form (the neglected stop-band aliasing, ~3e-10 for VHQ).
-template <typename Spec, typename Real>
+// IO = the signal's element type when it differs from the arithmetic: <double, float> is float32 I/O on float64
+// arithmetic — what libsoxr's VHQ recipe itself does for float32 clients (reference src/soxr_ext.cpp:74,228 hand the
+// recipe to soxr_quality_spec) — selected by HIPSOXR_KERNEL_FFT_F64.  Loads widen, the staged run and
+// the stores are in the I/O type; everything between is the float64 instance.
+template <typename Spec, typename Real, typename IO = Real>
 __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 {
     typedef typename PairTabs<Real>::C C;
-    typedef typename PairTabs<Real>::V16 V16;
-    constexpr int ES = (int)sizeof(Real), EPS = 16 / ES; // element size, elements per 16-byte store
+    typedef typename PairTabs<IO>::V16 V16;
+    constexpr int ES = (int)sizeof(IO), EPS = 16 / ES; // element size, elements per 16-byte store
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C *cur = reinterpret_cast<C *>(smem_raw);
-    Real *stage = reinterpret_cast<Real *>(smem_raw);
+    IO *stage = reinterpret_cast<IO *>(smem_raw);
     constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0;
 #ifdef FFT2_TRACE
     unsigned long long *g_tr = a.trace ? a.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + threadIdx.x / 64) * 16 : nullptr;
@@ -846,7 +850,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     const int64_t pa = 2 * bx * a.hop_periods - a.lead_periods; // first period of block a; block b starts hop_periods later
     const int64_t ina = pa * a.M, outa = pa * a.L;
     const int32_t hop_in = (int32_t)(a.hop_periods * a.M);
-    const Real *xin = (const Real *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
 #if defined(FFT2_ABL) && (FFT2_ABL & 8)
     auto lds_store = [&](int n, C v) { if (v.x == (Real)1234.5) cur[n] = v; };
 #else
@@ -864,13 +868,13 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 #if defined(FFT2_ABL) && (FFT2_ABL & 2)
             return C((Real)(j4 + t) * (Real)1e-4, (Real)(j4 ^ t) * (Real)1e-4);
 #endif
-            return C(buf_load_real<Real>(rs, j4, t * nbA * ES), buf_load_real<Real>(rs, j4, (t * nbA + hop_in) * ES));
+            return C((Real)buf_load_real<IO>(rs, j4, t * nbA * ES), (Real)buf_load_real<IO>(rs, j4, (t * nbA + hop_in) * ES));
         }, lds_store, false, tw);
     } else { // the first pair of a column reaches before its start: explicit zero-extension
         const int64_t inb = ina + hop_in;
         Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int) -> C {
             const int64_t la = ina + n, lb = inb + n;
-            return C((la >= 0 && la < a.in_frames) ? xin[la] : (Real)0, (lb >= 0 && lb < a.in_frames) ? xin[lb] : (Real)0);
+            return C((la >= 0 && la < a.in_frames) ? (Real)xin[la] : (Real)0, (lb >= 0 && lb < a.in_frames) ? (Real)xin[lb] : (Real)0);
         }, lds_store, false, tw);
     }
     __syncthreads();
@@ -878,7 +882,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 
     // ---- inverse (see k_fft_pair), last pass into the staging layout -------------------------------
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
-    Real *ybase = (Real *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
+    IO *ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
     // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
     const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
     const Real *Hr = PairTabs<Real>::hr(a);
@@ -897,8 +901,8 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     };
     Spec::inv_staged(FFT_STAMP_ARGS cur, PairTabs<Real>::wb(a), h_load, [&](int n, C w) {
         if (n >= v0 && n < v1) {
-            stage[n - v0 + sh] = w.x;
-            stage[n - v0 + sh + hop_out] = w.y;
+            stage[n - v0 + sh] = (IO)w.x;
+            stage[n - v0 + sh + hop_out] = (IO)w.y;
         }
     });
     __syncthreads();
@@ -921,10 +925,10 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
             const int q = (int)threadIdx.x + it * NT;
             const V16 v = *reinterpret_cast<const V16 *>(stage + EPS * (q < LQ ? q : LQ - 1));
 #if defined(FFT2_ABL) && (FFT2_ABL & 4)
-            if (v.x != (Real)1234.5) continue;
+            if (v.x != (IO)1234.5) continue;
 #endif
             if (q == 0 && sh != 0) {
-                const Real *e = reinterpret_cast<const Real *>(&v);
+                const IO *e = reinterpret_cast<const IO *>(&v);
 #pragma unroll
                 for (int c = 0; c < EPS; ++c)
                     if (c >= sh && c - sh < valid) ybase[c - sh] = e[c];
@@ -934,6 +938,10 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
         }
     }
 #ifdef FFT2_TRACE
+    if (g_tr && (threadIdx.x & 63) == 0) { // where the wave ran: HW_ID (wave/simd/cu/sh/se fields) and the XCC id
+        g_tr[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_tr[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
     g_tri = 15;
     FFT_STAMP();
 #endif
@@ -1070,6 +1078,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
 #define HIPSOXR_INST(NA, NB, NT)                                                                        \
     HIPSOXR_EXTERN template __global__ void k_fft_pair2<PairOf<NA, NB, NT>, float>(FftArgs);             \
     HIPSOXR_EXTERN template __global__ void k_fft_pair2<PairOf<NA, NB, NT>, double>(FftArgs);            \
+    HIPSOXR_EXTERN template __global__ void k_fft_pair2<PairOf<NA, NB, NT>, double, float>(FftArgs);     \
     HIPSOXR_EXTERN template __global__ void k_fft_strided2<PairOf<NA, NB, NT>, float, true>(FftArgs);    \
     HIPSOXR_EXTERN template __global__ void k_fft_strided2<PairOf<NA, NB, NT>, double, true>(FftArgs);   \
     HIPSOXR_EXTERN template __global__ void k_fft_strided2<PairOf<NA, NB, NT>, float, false>(FftArgs);   \
@@ -1246,6 +1255,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     struct PairEntry {
         int64_t L, M; int k; int small; /* 0: full-size blocks, 1: half-size (small jobs), 2: quarter-size (smaller still) */
         void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); void (*kern2d)(FftArgs);
+        void (*kern2fd)(FftArgs);                    // float32 I/O on float64 arithmetic (HIPSOXR_KERNEL_FFT_F64)
         void (*kcp)(FftArgs); void (*kcpd)(FftArgs); // channel-pair mode (interleaved data), float32 / float64
         void (*kst)(FftArgs); void (*kstd)(FftArgs); // strided columns, two blocks per transform
     };
@@ -1253,6 +1263,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
 //  families: HIPSOXR_PAIR_V1; elsewhere a job the second-generation kernels cannot take goes to k_fft_block)
 #define HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, V1) \
     {L, M, k, small, V1, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>, \
+     k_fft_pair2<PairOf<NA, NB, NT>, double, float>, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, true>, k_fft_strided2<PairOf<NA, NB, NT>, double, true>, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>}
 #define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, nullptr)
@@ -1284,7 +1295,10 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
 #undef HIPSOXR_PAIR
     const bool no_pair = switches().fft_no_pair;
     const uint64_t cols_p = (uint64_t)j.n_clips * j.n_channels;
-    const bool f64 = j.elem == HIPSOXR_F64;
+    // f64: the ARITHMETIC is float64 (block size, LDS bytes per point, table set) — float64 jobs, and float32 jobs that
+    // ask for libsoxr's own VHQ width with HIPSOXR_KERNEL_FFT_F64 (io64 = the signal's elements are 8 bytes)
+    const bool io64 = j.elem == HIPSOXR_F64, wide32 = !io64 && j.kernel == HIPSOXR_KERNEL_FFT_F64;
+    const bool f64 = io64 || wide32;
     // float64: the second-generation kernels only (unit-stride columns; channel pairs; strided columns) — else the exact engine
     if (f64 && (no_pair || cols_p > 65535)) return nullptr;
     if (!no_pair && cols_p <= 65535) {
@@ -1331,7 +1345,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             // tables on the first-generation kernel (7.1 vs 9.0 us for one workgroup).  Against the second-generation
             // three-pass kernel it no longer wins anywhere (0.5 s .. 20 s clips: equal within 0.2 us; 30 s: 10.6 vs
             // 9.4 us): kept behind HIPSOXR_FFT_SMALL_4PASS for A/B only.
-            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && switches().fft_small_4pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
                 if (wgs < 400 && !f64) use = &low_latency;
@@ -1354,7 +1368,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const int64_t n_blocks = (j.out_frames + g.hop_out - 1) / g.hop_out;
                 if (n_blocks > 2147483647LL) return "job too long for one launch";
                 // interleaved data with an even channel count: pair channels (aligned float2 per frame)
-                const size_t esz = f64 ? sizeof(double) : sizeof(float);
+                const size_t esz = io64 ? sizeof(double) : sizeof(float);
                 const bool cp_layout = j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1 && !switches().fft_no_chpair;
                 // (the first-generation kernel reads the pair through a float2 pointer: every frame 8-byte aligned)
                 const bool cp_aligned = j.in_frame_stride % 2 == 0 && j.out_frame_stride % 2 == 0 && j.in_clip_stride % 2 == 0 &&
@@ -1362,9 +1376,14 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 // ... the second-generation channel-pair kernel (buffer loads: element alignment is enough) when a block's
                 // byte offsets fit its 32-bit operands; float64 has no first-generation kernel and pairs channels
                 // through this one or not at all
-                const bool cp2 = (f64 ? use->kcpd : use->kcp) != nullptr && !switches().fft_pair_v1 &&
+                const bool cp2 = !wide32 && (f64 ? use->kcpd : use->kcp) != nullptr && !switches().fft_pair_v1 &&
                                  (int64_t)std::max(g.N_in, g.N_out) * std::max(j.in_frame_stride, j.out_frame_stride) * (int64_t)esz < (1LL << 30);
-                a.chpair = (cp_layout && (cp2 || (cp_aligned && !f64 && use->kern))) ? 1 : 0;
+                // (channel pairing rides on the XCD-aware work-item map: decided together, so that a job without the
+                //  map — HIPSOXR_FFT_NO_XCD_MAP, or too many work items — runs unpaired on the strided kernel instead of failing)
+                const int64_t cp_items8 = (n_blocks + 7) / 8 * 8;
+                const bool cp_map_ok = j.n_channels > 1 && j.n_clips <= 65535 && cp_items8 * (int64_t)(j.n_channels / 2) <= 2147483647LL &&
+                                       !switches().fft_no_xcd_map;
+                a.chpair = (cp_layout && cp_map_ok && (cp2 || (cp_aligned && !f64 && use->kern))) ? 1 : 0;
                 const size_t lds = std::max((size_t)std::max(g.N_in, g.N_out) * (f64 ? sizeof(double2) : sizeof(float2)), switches().dbg_fft_lds);
                 if (f64 && lds > 160 * 1024) return nullptr;
                 if (lds > 64 * 1024 && use->kern)
@@ -1374,7 +1393,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const int64_t units = a.chpair ? j.n_channels / 2 : j.n_channels;
                 a.xcd_map = (j.n_channels > 1 && j.in_chan_stride == 1 && j.out_chan_stride == 1 && j.n_clips <= 65535 &&
                              items8 * units <= 2147483647LL && !switches().fft_no_xcd_map) ? 1 : 0;
-                if (a.chpair && !a.xcd_map) return f64 ? nullptr : "internal: channel pairing needs the XCD map"; // (decided before the work items were counted)
+                if (a.chpair && !a.xcd_map) return "internal: channel pairing needs the XCD map"; // (cannot happen: cp_map_ok above)
                 a.pairs_per_col = items;
                 const dim3 grid = a.xcd_map ? dim3((unsigned)(items8 * units), j.n_clips, 1)
                                             : dim3((unsigned)((n_blocks + 1) / 2), (unsigned)cols_p, 1);
@@ -1385,7 +1404,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const bool cp2ok = a.chpair && a.xcd_map && cp2;
                 // strided columns that are not channel pairs (odd channel counts, channel slices): the strided second-
                 // generation kernel when the byte offsets of a pair of blocks fit its 32-bit operands
-                const bool st2ok = !a.chpair && !v2ok && (f64 ? use->kstd : use->kst) != nullptr && !switches().fft_pair_v1 &&
+                const bool st2ok = !wide32 && !a.chpair && !v2ok && (f64 ? use->kstd : use->kst) != nullptr && !switches().fft_pair_v1 &&
                                    2 * (int64_t)std::max(g.N_in, g.N_out) * std::max(j.in_frame_stride, j.out_frame_stride) * (int64_t)esz < (1LL << 30);
                 if (f64 && !v2ok && !cp2ok && !st2ok) return nullptr; // (no float64 instance of the first-generation kernel: exact engine)
                 if (cp2ok || st2ok) {
@@ -1393,8 +1412,9 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }
+                if (wide32 && !v2ok) return nullptr; // (float32 on float64 arithmetic: unit-stride columns only)
                 if (v2ok && (f64 || !switches().fft_pair_v1)) {
-                    kern = f64 ? use->kern2d : use->kern2;
+                    kern = io64 ? use->kern2d : wide32 ? use->kern2fd : use->kern2;
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }

@@ -825,7 +825,8 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
 // (ctl->dec = number of messages accepted, top bit = sealed) arbitrates: a workgroup that sees message n+1
 // does CAS(n -> n+1), one that has waited too long does CAS(n -> n|SEAL); whichever CAS lands first decides
 // for everybody (a workgroup whose seal fails because n+1 was accepted goes back for the message, one whose
-// accept fails because the instance is sealed leaves).  The host, waiting for `done`, sees `exited` instead
+// accept fails because the instance was sealed AT n leaves; an accept that finds (n+1)|SEAL was merely late — the
+// message had been accepted before the seal — and is answered like any other).  The host, waiting for `done`, sees `exited` instead
 // and launches the next instance, which finds the message still in the box.
 // ---------------------------------------------------------------------------------------------
 // (ResidentBox, ResidentCtl: device.h)
@@ -891,7 +892,10 @@ __global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
         unsigned long long old = 0;
         const bool asker = threadIdx.x == 192;
         if (asker) old = atomicCAS(&ra.ctl->dec, n, n + 1);
-        auto publish = [&]() { if (asker) s_old = old; };
+        // (old == (n+1)|SEAL: the others accepted message n+1, finished it and sealed after idling before this
+        //  workgroup's CAS arrived — "accepted, then sealed", not a veto: the message is partly answered already and
+        //  this workgroup owes its share; it stores, and leaves on its next poll.  Only a seal AT n withholds.)
+        auto publish = [&]() { if (asker) s_old = old == ((n + 1) | kResidentSeal) ? n + 1 : old; };
         ChainMsg m;
         {
             auto uni = [](uint64_t x) {
@@ -1967,7 +1971,10 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)rk, 256, lds));
                     HIP_TRY(hipGetDevice(&dev));
                     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-                    if ((int64_t)gx * gy > (int64_t)occ * cus / 4 || (int64_t)gx * gy > (int64_t)kResidentMaxWgs) return "resident kernel: message too large";
+                    if (occ < 1 || (int64_t)gx * gy > (int64_t)occ * cus / 4 || (int64_t)gx * gy > (int64_t)kResidentMaxWgs) return "resident kernel: message too large";
+                    // process-wide budget in CU capacity (engine.cpp): all resident instances together hold at most half the chip
+                    res->cost_mcu = (uint32_t)(((int64_t)gx * gy * 1024 + occ - 1) / occ);
+                    if (res->used_mcu + (int64_t)res->cost_mcu > (int64_t)cus * 1024 / 2) { res->over_budget = true; return "resident kernel: over the budget"; }
                     ResidentArgs ra;
                     std::memset(&ra, 0, sizeof ra);
                     ra.ca = ca; ra.box = res->box; ra.words = res->words; ra.ctl = res->ctl; ra.base_seq = res->base_seq; ra.epoch = res->epoch;
@@ -2356,17 +2363,22 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     // Frequency-domain engine: explicit request, or AUTO for large whole-signal float32 jobs.
     // It is NOT bit-identical to the canonical order (about 2e-7 relative RMS), so it is never chosen
     // for HIPSOXR_KERNEL_EXACT — which is what the stream / one-shot host entry points pass.
-    if (!vr && !res && (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_AUTO)) {
+    // HIPSOXR_KERNEL_FFT_F64: the same engine with float64 arithmetic whatever the I/O type (float32 jobs at the width
+    // libsoxr's VHQ recipe computes in; float64 jobs run it anyway).
+    const bool want_fft = j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_FFT_F64;
+    if (want_fft && (vr || res)) return "FFT engine: whole-signal device jobs only";
+    if (!vr && !res && (want_fft || j.kernel == HIPSOXR_KERNEL_AUTO)) {
         const bool no_fft = switches().no_fft;
         const bool eligible = fft_job_eligible(*p, j);
         const bool big = (int64_t)j.out_frames * j.n_clips * j.n_channels >= (1 << 13); // even one block pair beats the tiled exact kernels (7 vs 10 us)
-        if (j.kernel == HIPSOXR_KERNEL_FFT && !eligible)
-            return "FFT engine needs a whole-signal float32 job (in_abs0 == 0, out_k0 == 0)";
-        if (eligible && (j.kernel == HIPSOXR_KERNEL_FFT || (big && !no_fft))) {
+        if (want_fft && !eligible)
+            return "FFT engine needs a whole-signal float32 or float64 job (in_abs0 == 0, out_k0 == 0) on an HQ/VHQ exact-ratio plan";
+        if (eligible && (want_fft || (big && !no_fft))) {
             bool handled = false;
             if (const char *e = launch_fft(p, j, stream, &handled)) return e;
             if (handled) return nullptr;
-            if (j.kernel == HIPSOXR_KERNEL_FFT) return "FFT engine unavailable for this plan";
+            if (want_fft) return j.kernel == HIPSOXR_KERNEL_FFT_F64 ? "FFT engine (float64 arithmetic) unavailable for this plan or layout (unit-stride columns of a tabled ratio)"
+                                                                     : "FFT engine unavailable for this plan";
         }
     }
     hipStream_t st = (hipStream_t)stream;

@@ -10,6 +10,7 @@ include/hipsoxr.h (libhipsoxr.so, loaded with ctypes); there is no CPU fallback.
     y = soxr.resample(x, 48000, 44100, quality="VHQ")
 """
 import ctypes as _C
+import weakref as _weakref
 
 import numpy as np
 
@@ -81,6 +82,57 @@ def _ptr_array(ptrs):
     return arr
 
 
+class _CSoxrView:
+    """What `ResampleStream._csoxr` is in the reference: the binding's handle object
+    (nb::class_<CSoxr>, src/soxr_ext.cpp:408-423).  The reference's own tests reach through it
+    (`rs._csoxr.engine()`, tests/conftest.py:7,10); here it is a view of the stream, same attribute and
+    method names, arguments in the binding's units (io_ratio, not two rates)."""
+
+    def __init__(self, rs, in_rate, out_rate):
+        self._rs = _weakref.proxy(rs)  # (no reference cycle: the stream's __del__ releases device state promptly)
+        self.in_rate, self.out_rate = float(in_rate), float(out_rate)
+        self.channels = rs._channels
+        self.ntype = _elem_code(rs._type)  # SOXR_*_I numbering (src/soxr_ext.cpp:35-38)
+
+    @property
+    def ended(self):
+        return self._rs._ended
+
+    def _proc(self, dtype, x, last):
+        if self._rs._type != np.dtype(dtype):  # (nanobind would refuse the ndarray<T> argument)
+            raise TypeError(f"process_{dtype}: stream was created for {self._rs._type}")
+        return self._rs._process(x, last)
+
+    def process_float32(self, x, last=False):
+        return self._proc("float32", x, last)
+
+    def process_float64(self, x, last=False):
+        return self._proc("float64", x, last)
+
+    def process_int32(self, x, last=False):
+        return self._proc("int32", x, last)
+
+    def process_int16(self, x, last=False):
+        return self._proc("int16", x, last)
+
+    def num_clips(self):
+        return self._rs.num_clips()
+
+    def delay(self):
+        return self._rs.delay()
+
+    def engine(self):
+        return self._rs.engine()
+
+    def clear(self):
+        self._rs.clear()
+
+    def set_io_ratio(self, io_ratio, slew_len=0):  # (src/soxr_ext.cpp:200-204)
+        if io_ratio <= 0:
+            raise ValueError("Sample rate should be over 0")
+        self._rs.set_io_ratio(float(io_ratio), 1.0, slew_len)
+
+
 class ResampleStream:
     """Streaming resampler: state (pending input, counters) lives on the GPU between calls.
 
@@ -130,6 +182,7 @@ class ResampleStream:
         if dither_seed:
             _n.check(_n.lib.hipsoxr_stream_set_dither_seed(self._h, int(dither_seed) & 0xFFFFFFFF))
         self._ended = False
+        self._csoxr = _CSoxrView(self, in_rate, out_rate)  # (src/soxr/__init__.py:99)
         self._done = _C.c_size_t(0)
         self._done_ref = _C.byref(self._done)
         # Output capacity of a call without asking the library for delay(): after a synchronous call the frames

@@ -55,7 +55,7 @@ VR = 32
 NO_DITHER = 8
 DEFER = 64
 RESIDENT = 128
-KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILE, KERNEL_TILE_VALU, KERNEL_TILE_MFMA, KERNEL_FFT, KERNEL_EXACT, KERNEL_WAVE_DOT = range(8)
+KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILE, KERNEL_TILE_VALU, KERNEL_TILE_MFMA, KERNEL_FFT, KERNEL_EXACT, KERNEL_WAVE_DOT, KERNEL_FFT_F64 = range(9)
 
 
 class PlanInfo(C.Structure):

@@ -12,7 +12,7 @@ import numpy as np
 from . import _native as _n
 from . import _quality_to_enum
 from ._native import (KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILE, KERNEL_TILE_VALU, KERNEL_TILE_MFMA,  # noqa: F401
-                      KERNEL_FFT, KERNEL_EXACT, KERNEL_WAVE_DOT)
+                      KERNEL_FFT, KERNEL_EXACT, KERNEL_WAVE_DOT, KERNEL_FFT_F64)
 
 
 class Plan:

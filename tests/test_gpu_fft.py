@@ -167,6 +167,45 @@ def test_fft_engine_float64_instance(oracle, in_rate, out_rate, quality, tol):
         assert _rms(y - ref) <= tol * max(_rms(ref), 1e-3), (shape, _rms(y - ref) / max(_rms(ref), 1e-3))
 
 
+FFT_F64 = 8  # hipsoxr_kernel_t: the frequency-domain engine computing in float64 whatever the I/O type
+
+
+@pytest.mark.parametrize("in_rate,out_rate,quality", [(48000, 44100, "VHQ"), (44100, 48000, "VHQ"), (44100, 16000, "VHQ"),
+                                                      (96000, 48000, "VHQ"), (48000, 44100, "HQ")])
+def test_fft_engine_float32_io_on_float64_arithmetic(oracle, in_rate, out_rate, quality):
+    """HIPSOXR_KERNEL_FFT_F64 on float32 jobs: loads widen, the whole chain runs in double2, the result is rounded to
+    float32 once — the arithmetic width libsoxr's VHQ recipe itself uses for float32 clients (SURVEY.md §0.3;
+    reference src/soxr_ext.cpp:74,228).  Against the oracle's float64 direct form (on the oracle's own bank) what is
+    left is the float32 OUTPUT rounding, 2^-24/sqrt(3) ~ 3.4e-8 of the sample magnitude: <= 5e-8 relative RMS for VHQ
+    (HQ adds its -128 dB stop-band aliasing: <= 1e-6).  The float32-arithmetic kernel sits at ~2e-7 on the same input."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(23)
+    plan = dev.Plan(in_rate, out_rate, quality)
+    tol = 5e-8 if quality == "VHQ" else 1e-6
+    for shape in ((120000,), (3, 30001, 1), (9, 1)):            # mono, a batch of planar columns, a tiny job
+        x = (rng.standard_normal(shape) * 0.25).astype(np.float32)
+        xt = torch.from_numpy(x).cuda()
+        y = dev.resample_tensor(plan, xt, kernel=FFT_F64)
+        assert y.dtype == torch.float32
+        y = y.cpu().numpy().astype(np.float64)
+        if x.ndim == 3:
+            ref = np.stack([oracle.resample(x[c, :, 0].astype(np.float64), in_rate, out_rate, quality, mode="ref")
+                            for c in range(x.shape[0])])[:, :, None]
+        else:
+            ref = oracle.resample(x.astype(np.float64), in_rate, out_rate, quality, mode="ref")
+        assert y.shape == ref.shape
+        assert _rms(y - ref) <= tol * max(_rms(ref), 1e-3), (shape, _rms(y - ref) / max(_rms(ref), 1e-3))
+        if x.ndim == 1 and quality == "VHQ":                   # and it really is tighter than the float32-arithmetic kernel
+            y32 = dev.resample_tensor(plan, xt, kernel=FFT).cpu().numpy().astype(np.float64)
+            assert _rms(y - ref) < 0.5 * _rms(y32 - ref)
+    # float64 jobs take the same kernel id (they run float64 arithmetic anyway); interleaved float32 data is refused
+    xd = torch.from_numpy(rng.standard_normal(50000) * 0.25).cuda()
+    assert torch.equal(dev.resample_tensor(plan, xd, kernel=FFT_F64), dev.resample_tensor(plan, xd, kernel=FFT))
+    with pytest.raises(RuntimeError):
+        dev.resample_tensor(plan, torch.zeros((40000, 2), dtype=torch.float32, device="cuda"), kernel=FFT_F64)
+
+
 def test_auto_engine_float64_large_job_is_frequency_domain_and_close(oracle):
     """AUTO on a large float64 device job now takes the frequency-domain engine: not bit-identical to the
     canonical order any more (the host surface still is: it passes KERNEL_EXACT), within 2e-9 of it."""

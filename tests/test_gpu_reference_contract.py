@@ -155,6 +155,36 @@ def test_stream_protocol(soxr):
         rs.set_io_ratio(44100, 22050)                           # needs vr=True (tests/test_gpu_vr.py)
 
 
+def test_csoxr_handle_view(soxr):
+    """`ResampleStream._csoxr` (src/soxr/__init__.py:99): the reference's own conftest calls
+    `rs._csoxr.engine()` (tests/conftest.py:7,10); the binding's names and units (src/soxr_ext.cpp:408-423)."""
+    import gc
+    import weakref
+    rs = soxr.ResampleStream(44100, 48000, 1, quality="VHQ")
+    c = rs._csoxr
+    assert c.engine() == rs.engine() and c.engine().startswith("hip-gfx950")
+    assert (c.in_rate, c.out_rate, c.channels, c.ended) == (44100.0, 48000.0, 1, False)
+    x = (np.random.default_rng(3).standard_normal(4000) * 0.25).astype(np.float32)
+    y = c.process_float32(x[:, None], True)                     # 2-D in, 2-D out, as the binding's process<T>
+    assert c.ended and y.ndim == 2 and np.array_equal(y[:, 0], soxr.resample(x, 44100, 48000, quality="VHQ"))
+    with pytest.raises(TypeError):
+        c.process_int16(x[:, None].astype(np.int16), False)
+    c.clear()
+    assert not c.ended and c.delay() == 0.0 and c.num_clips() == 0
+    with pytest.raises(RuntimeError):
+        c.set_io_ratio(2.0)                                     # not a variable-rate stream
+    v = soxr.ResampleStream(48000, 24000, 1, quality="HQ", vr=True)
+    v._csoxr.set_io_ratio(1.5, 10)                              # io_ratio = in/out, below the constructor's 2.0
+    gc.disable()
+    try:                                                        # the view holds no strong reference to the stream:
+        rs2 = soxr.ResampleStream(44100, 48000, 1)              # device state is released by reference counting alone
+        r2 = weakref.ref(rs2)
+        del rs2
+        assert r2() is None
+    finally:
+        gc.enable()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16, np.int32])
 @pytest.mark.parametrize("chunk", [17, 441, 4410, 50000])
 def test_deferred_stream_equals_oneshot(soxr, dtype, chunk):
