@@ -36,63 +36,76 @@ IN_RATE, OUT_RATE, QUALITY = 48000, 44100, "VHQ"
 KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, second-generation paired-block kernel, for large float32 device jobs)",
                 1: "k_gather<float,float>", 2: "k_tile_mfma_p<float>", 3: "k_tile<float,float,16,true>",
                 4: "k_tile_mfma_p<float>", 5: "k_fft_pair2<.., float>", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
-# HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 +
-# WRITE_SIZE, see profiles/r02_traffic.json); bench.py cannot collect counters itself.
-TRAFFIC_BYTES = {("configs1", 0): 23303168, ("configs1", 5): 23303168,
-                 ("batch_shard", 0): 480379904, ("batch_shard", 5): 480379904}  # profiles/r02_traffic.json
-# VALU wave-instructions per launch (SQ_INSTS_VALU, profiles/r02_rocprofv3_summary.txt): the other
-# resource the frequency-domain kernel is limited by.  An fp32 wave-instruction occupies a SIMD for
-# 2 cycles (SIMD-32, wave64); 256 CUs x 4 SIMDs at 2.4 GHz.
-VALU_INSTS = {("configs1", 0): 3203900, ("configs1", 5): 3203900, ("batch_shard", 0): 59709184, ("batch_shard", 5): 59709184}
+# HBM traffic and VALU wave-instructions per launch come from rocprofv3 PMC passes (bench.py cannot collect counters
+# itself): profiles/<TRAFFIC_FILE> records them TOGETHER WITH the SHA-256 of the kernel sources they were taken on.
+# `measured_counters()` hands a figure out only while that hash still matches the sources in this checkout — a stale
+# constant is reported as null with the reason, never silently.
+TRAFFIC_FILE = "r03_traffic.json"
+KERNEL_SOURCES = ("python-soxr_amd/csrc/fft.hip", "python-soxr_amd/csrc/kernels.hip")
+
+
+def kernel_sources_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_counters(workload):
+    """-> (traffic_bytes | None, valu_wave_insts | None, provenance dict)"""
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    here = kernel_sources_sha16()
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, None, {"traffic_source": None, "why": f"profiles/{TRAFFIC_FILE} absent", "kernel_sources_sha16": here}
+    prov = {"traffic_source": f"profiles/{TRAFFIC_FILE}", "taken_on_kernel_sources_sha16": rec.get("kernel_sources_sha16"),
+            "kernel_sources_sha16": here}
+    if rec.get("kernel_sources_sha16") != here:
+        prov["why"] = "stale: the kernel sources changed since the counters were collected (re-run tools/prof_bench.sh)"
+        return None, None, prov
+    w = rec.get("workloads", {}).get(workload)
+    if not w:
+        prov["why"] = "no record for this workload"
+        return None, None, prov
+    return w.get("traffic_bytes"), w.get("valu_wave_insts"), prov
+
+
 VALU_SLOTS_PER_S = 256 * 4 * 2.4e9 / 2
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak
 
 
 def shard(n_units, world, rank):
-    """Contiguous block partition of n_units independent clips over `world` ranks."""
-    base, rem = divmod(n_units, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """soxr_amd.dist.shard (the product owns the partition rule; kept here as the name older tools import)."""
+    from soxr_amd import dist as sdist
+    return sdist.shard(n_units, world, rank)
 
 
 def broadcast_bank(plan, rank, world, device):
-    """RCCL broadcast (over xGMI) of the float64 bank from rank 0; every other rank installs it."""
-    import torch
-    import torch.distributed as dist
-    if world == 1:
-        return
-    dev_c = device if dist.get_backend() == "nccl" else torch.device("cpu")  # (gloo: test harness only)
-    bank = torch.from_numpy(plan.bank()).to(dev_c) if rank == 0 else \
-        torch.empty((plan.L, plan.taps), dtype=torch.float64, device=dev_c)
-    dist.broadcast(bank, src=0)
-    if rank != 0:
-        plan.set_bank(bank.cpu().numpy())
+    """soxr_amd.dist.broadcast_bank over torch's communicator (RCCL over xGMI for backend nccl)."""
+    from soxr_amd import dist as sdist
+    if world > 1:
+        sdist.broadcast_bank(plan, device=device)
 
 
 def gather_rank_info(plan, rank, world, device, backend):
-    """What the job really ran on: per rank the device index, its name and the SHA-256 of the bank it holds
-    after the broadcast (all equal, or the broadcast failed) — rank 0 reports the list."""
-    import hashlib
-    import torch
-    import torch.distributed as dist
-    mine = {"rank": rank, "device": device.index, "name": torch.cuda.get_device_name(device),
-            "bank_sha256": hashlib.sha256(plan.bank().tobytes()).hexdigest()[:16]}
-    if world == 1:
-        return {"ranks_seen": 1, "backend": None, "ranks": [mine], "devices_visible": torch.cuda.device_count()}
-    got = [None] * world
-    dist.all_gather_object(got, mine)
-    return {"ranks_seen": len(got), "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "ranks": got,
-            "devices_visible": torch.cuda.device_count(),
-            "banks_identical": len({g["bank_sha256"] for g in got}) == 1}
+    from soxr_amd import dist as sdist
+    return sdist.rank_info(plan, device=device)
 
 
 def time_workload(plan, x, steps, warmup, world, device, kernel=0, windows=50):
-    """W warm-up launches, then exactly K timed launches bracketed by barrier + synchronize.
+    """W warm-up launches, then exactly K timed launches bracketed by barrier + synchronize (the contract region).
     Returns (wall seconds for K steps [max over ranks], launch duration from HIP events [s], output).
-    The launch duration is the MEDIAN over `windows` further windows of K launches each (HIP events on
-    the launch stream): at the driver's K = 20 the contract region of the 60 s clip lasts 0.3 ms, too
-    short for one window to be a measurement.  A step is the same thing in every window."""
+    The launch duration is the MEDIAN over `windows` event windows of K launches each (HIP events on the launch
+    stream): at the driver's K = 20 the contract region of the 60 s clip lasts 0.3 ms, too short for one window to be
+    a measurement.  Half of the windows run BEFORE the contract region (they are warm-up as far as the contract is
+    concerned) and half AFTER it, so that both figures are taken at the same clock state of the chip — round 2 ran
+    all windows afterwards, at a lower clock, and reported a kernel slower than the step that contained it.
+    A step is the same thing in every window."""
     import torch
     import torch.distributed as dist
     from soxr_amd import device as dev
@@ -101,11 +114,25 @@ def time_workload(plan, x, steps, warmup, world, device, kernel=0, windows=50):
     for _ in range(warmup):
         job.launch()
     torch.cuda.synchronize(device)
+    per = []
+
+    def event_windows(n):
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                job.launch()
+            e1.record()
+            e1.synchronize()
+            per.append(e0.elapsed_time(e1) * 1e-3 / steps)
+
+    event_windows(windows // 2)
+    torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     # The contract region holds the K launches and nothing else: the HIP events of the kernel timing (two more
-    # packets on the stream, ~0.4 us per step at the driver's K = 20) are recorded in the windows below.
+    # packets on the stream, ~0.4 us per step at the driver's K = 20) are recorded in the windows around it.
     t0 = time.perf_counter()
     for _ in range(steps):
         job.launch()
@@ -114,17 +141,9 @@ def time_workload(plan, x, steps, warmup, world, device, kernel=0, windows=50):
     if world > 1:                    # (a collective's own latency is tens of us: not part of K x 12 us steps)
         dist.barrier()
     torch.cuda.synchronize(device)
+    event_windows(windows - windows // 2)
     kern = wall / steps
-    if windows:
-        per = []
-        for _ in range(windows):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(steps):
-                job.launch()
-            e1.record()
-            e1.synchronize()
-            per.append(e0.elapsed_time(e1) * 1e-3 / steps)
+    if per:
         per.sort()
         kern = per[len(per) // 2]
     if world > 1:
@@ -132,6 +151,27 @@ def time_workload(plan, x, steps, warmup, world, device, kernel=0, windows=50):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, kern, y
+
+
+def sustained_leg(plan, x, seconds, device, kernel=0):
+    """The batch workload launched back to back for `seconds` of wall time (>= 3 s): long enough for an outside
+    observer (the driver's gpu_busy sampler, rocm-smi) to see the GPU busy and to corroborate the per-launch time —
+    the contract regions above keep it busy for well under a second in total."""
+    import torch
+    from soxr_amd import device as dev
+    y = dev.resample_tensor(plan, x, kernel=kernel)
+    job = dev.PreparedJob(plan, x, y, kernel=kernel)
+    torch.cuda.synchronize(device)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(200):
+            job.launch()
+        n += 200
+        torch.cuda.synchronize(device)
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return n, dt
 
 
 def cpu_baseline(seconds_in=60, budget_s=10.0):
@@ -313,21 +353,29 @@ def host_api_timings():
     return out
 
 
-def hbm_ceiling(device, n_bytes=1 << 29):
-    """What this box's HBM delivers to plain streaming kernels (torch's copy and reduction), so
-    that roofline fractions can also be read against the achievable rather than the spec peak."""
+def hbm_ceiling(device, n_bytes=1 << 30):
+    """What this box's HBM delivers to plain streaming kernels, so that roofline fractions can also be read against
+    the achievable rather than the spec peak: the probe kernels of tools/ubench/stream_probe.hip (16 bytes per lane,
+    1 / 2 / 4 / 8 loads in flight per lane, temporal and non-temporal; read-only and write-only sweeps) over 1 GiB
+    buffers — four times the 256 MiB Infinity Cache — and torch's copy_.  (Round 2 quoted a 4096-workgroup
+    grid-stride copy at 4.7 TB/s, well below what the guide documents for a float4 copy, 6.29 TB/s.)"""
+    import ctypes
     import torch
-    from soxr_amd import _native as nat
+    path = os.path.join(ROOT, "tools", "ubench", "libstream_probe.so")
+    try:
+        probe = ctypes.CDLL(path)
+    except OSError as e:
+        return {"error": f"{path}: {e} (built by __graft_entry__.build())"}
+    probe.stream_probe_run.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    probe.stream_probe_name.restype = ctypes.c_char_p
     a = torch.empty(n_bytes // 4, dtype=torch.float32, device=device).normal_()
     b = torch.empty_like(a)
     st = torch.cuda.current_stream(device).cuda_stream
     res = {}
-
-    def own(mode):
-        nat.check(nat.lib.hipsoxr_bench_stream(b.data_ptr(), a.data_ptr(), n_bytes, mode, st))
-
-    for name, fn, moved in (("copy", lambda: own(0), 2 * n_bytes), ("read", lambda: own(1), n_bytes),
-                            ("torch_copy", lambda: b.copy_(a), 2 * n_bytes)):
+    legs = [(probe.stream_probe_name(m).decode(), (lambda m=m: probe.stream_probe_run(m, b.data_ptr(), a.data_ptr(), n_bytes, st)),
+             probe.stream_probe_moves(m) * n_bytes) for m in range(9)]
+    legs.append(("torch_copy", lambda: b.copy_(a), 2 * n_bytes))
+    for name, fn, moved in legs:
         for _ in range(3):
             fn()
         torch.cuda.synchronize(device)
@@ -338,8 +386,9 @@ def hbm_ceiling(device, n_bytes=1 << 29):
         e1.record()
         torch.cuda.synchronize(device)
         res[name + "_GBs"] = moved * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    res["best_copy_GBs"] = max(res["copy_GBs"], res["torch_copy_GBs"])
-    res["note"] = "float4 grid-stride copy / read kernels (hipsoxr_bench_stream) and torch copy_, 512 MiB, HIP events"
+    res["best_copy_GBs"] = max(v for k, v in res.items() if k.startswith(("copy", "torch_copy")))
+    res["best_read_GBs"] = max(v for k, v in res.items() if k.startswith("read"))
+    res["note"] = "tools/ubench/stream_probe.hip kernels and torch copy_, 1 GiB buffers, HIP events, 10 launches each"
     return res
 
 
@@ -354,8 +403,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-batch", action="store_true")
     ap.add_argument("--kernel", type=int, default=0)
-    ap.add_argument("--strong", action="store_true", help="also time the whole 1024-clip batch on this job's ranks")
+    ap.add_argument("--strong", action="store_true", help="(kept for older command lines: the strong-scaling batch line is always timed now)")
     ap.add_argument("--windows", type=int, default=50, help="extra timing windows of K launches (median -> launch_us)")
+    ap.add_argument("--sustained-s", type=float, default=3.0, help="wall seconds of the sustained batch leg")
+    ap.add_argument("--no-sustained", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -394,6 +445,8 @@ def main():
     algo_bytes = 4.0 * (n_in + n_out)
     flops = 2.0 * plan.taps * n_out
     value = world * n_in * args.steps / wall / 1e6
+    fft_kernel = args.kernel in (0, 5)
+    c1_traffic, c1_valu, c1_prov = measured_counters("configs1") if (fft_kernel and args.seconds == 60) else (None, None, {})
 
     result = {
         "metric": "Msamples/sec VHQ 48k->44.1k float32 (input samples/s)",
@@ -407,12 +460,11 @@ def main():
                    "parallelism": f"independent clips per rank x{world}; RCCL bank broadcast at plan time"},
         "roofline": {"bound": "hbm", "achieved": algo_bytes / kern / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo_bytes / kern / 1e9 / HBM_PEAK_GBS,
-                     "traffic": TRAFFIC_BYTES.get(("configs1", args.kernel)) if args.seconds == 60 else None,
-                     "kernel": KERNEL_NAMES.get(args.kernel, "auto"), "launch_us": kern * 1e6,
+                     "traffic": c1_traffic, "kernel": KERNEL_NAMES.get(args.kernel, "auto"), "launch_us": kern * 1e6,
+                     "launch_us_le_step": bool(kern <= wall / args.steps),
                      "algorithmic_bytes_per_launch": algo_bytes,
-                     "valu_issue_frac": (VALU_INSTS[("configs1", args.kernel)] / (VALU_SLOTS_PER_S * kern)
-                                         if ("configs1", args.kernel) in VALU_INSTS and args.seconds == 60 else None),
-                     "direct_form_equiv_tflops": flops / kern / 1e12},
+                     "valu_issue_frac": c1_valu / (VALU_SLOTS_PER_S * kern) if c1_valu else None,
+                     "direct_form_equiv_tflops": flops / kern / 1e12, **c1_prov},
     }
 
     # ---- configs[3] shard: 1024 x 10 s clips over 8 GPUs -> 128 clips per GPU ----------------
@@ -422,7 +474,8 @@ def main():
         xb = torch.randn((clips, IN_RATE * 10, 1), device=device, dtype=torch.float32, generator=g) * 0.25
         bsteps = max(5, args.steps // 10)
         bwall, bkern, yb = time_workload(plan, xb, bsteps, max(2, args.warmup // 10), world, device,
-                                         args.kernel, windows=max(5, args.windows // 2))
+                                         args.kernel, windows=max(6, args.windows // 2))
+        b_traffic, b_valu, b_prov = measured_counters("batch_shard") if (fft_kernel and clips == 128) else (None, None, {})
         b_in, b_out = clips * IN_RATE * 10, clips * yb.shape[1]
         bbytes = 4.0 * (b_in + b_out)
         bflops = 2.0 * plan.taps * b_out
@@ -433,24 +486,31 @@ def main():
             "ms_per_step": bwall / bsteps * 1e3,
             "roofline": {"bound": "hbm", "achieved": bbytes / bkern / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bbytes / bkern / 1e9 / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES.get(("batch_shard", args.kernel)) if clips == 128 else None,
-                         "valu_issue_frac": (VALU_INSTS[("batch_shard", args.kernel)] / (VALU_SLOTS_PER_S * bkern)
-                                             if ("batch_shard", args.kernel) in VALU_INSTS and clips == 128 else None),
+                         "traffic": b_traffic, "valu_issue_frac": b_valu / (VALU_SLOTS_PER_S * bkern) if b_valu else None,
                          "read_frac": 4.0 * b_in / bkern / 1e9 / HBM_PEAK_GBS,
-                         "launch_us": bkern * 1e6, "direct_form_equiv_tflops": bflops / bkern / 1e12}}
+                         "launch_us": bkern * 1e6, "launch_us_le_step": bool(bkern <= bwall / bsteps),
+                         "direct_form_equiv_tflops": bflops / bkern / 1e12, **b_prov}}
+        # a sustained leg on the same workload: >= 3 s of back-to-back launches (rank 0's GPU; every rank runs it so the
+        # ranks stay in step)
+        if not args.no_sustained:
+            sn, sdt = sustained_leg(plan, xb, args.sustained_s, device, args.kernel)
+            result["batch_shard"]["sustained"] = {"seconds": sdt, "launches": sn, "us_per_launch": sdt / sn * 1e6,
+                                                  "frac": bbytes / (sdt / sn) / 1e9 / HBM_PEAK_GBS,
+                                                  "note": "back-to-back launches of the batch_shard job for >= %g s of wall time" % args.sustained_s}
         del xb, yb
-        # the same batch partitioned over THIS job's ranks (strong scaling: 1024 clips in total whatever N is)
-        if world > 1 or args.strong:
-            slo, shi = shard(args.batch_clips, world, rank)
-            xs = torch.randn((shi - slo, IN_RATE * 10, 1), device=device, dtype=torch.float32, generator=g) * 0.25
-            swall, skern, ys = time_workload(plan, xs, bsteps, 2, world, device, args.kernel, windows=5)
-            result["batch_strong"] = {
-                "workload": f"BASELINE configs[3]: {args.batch_clips} x 10 s clips partitioned over {world} rank(s) "
-                            f"(shard(n, world, rank): rank 0 holds clips [{slo}, {shi}))",
-                "scaling": "strong", "value": args.batch_clips * IN_RATE * 10 * bsteps / swall / 1e6, "unit": "Msamples/s",
-                "ms_per_step": swall / bsteps * 1e3, "launch_us_rank0": skern * 1e6,
-                "hbm_frac_rank0": 4.0 * (xs.numel() + ys.numel()) / skern / 1e9 / HBM_PEAK_GBS}
-            del xs, ys
+        # the same batch partitioned over THIS job's ranks (strong scaling: 1024 clips in total whatever N is; at N = 1
+        # all 1024 clips run on the one GPU — 3.8 GB of signal — which anchors the strong-scaling curve and exercises
+        # configs[3] whole)
+        slo, shi = shard(args.batch_clips, world, rank)
+        xs = torch.randn((shi - slo, IN_RATE * 10, 1), device=device, dtype=torch.float32, generator=g) * 0.25
+        swall, skern, ys = time_workload(plan, xs, bsteps, 2, world, device, args.kernel, windows=6)
+        result["batch_strong"] = {
+            "workload": f"BASELINE configs[3]: {args.batch_clips} x 10 s clips partitioned over {world} rank(s) "
+                        f"(soxr_amd.dist.shard(n, world, rank): rank 0 holds clips [{slo}, {shi}))",
+            "scaling": "strong", "value": args.batch_clips * IN_RATE * 10 * bsteps / swall / 1e6, "unit": "Msamples/s",
+            "ms_per_step": swall / bsteps * 1e3, "launch_us_rank0": skern * 1e6,
+            "hbm_frac_rank0": 4.0 * (xs.numel() + ys.numel()) / skern / 1e9 / HBM_PEAK_GBS}
+        del xs, ys
 
     # ---- configs[2] (context line, not the headline): 60 s x 8 channels interleaved, 44.1k -> 16k VHQ
     if not args.no_batch and world == 1:
@@ -459,13 +519,13 @@ def main():
             x2 = torch.randn((44100 * args.seconds, 8), device=device, dtype=torch.float32, generator=g) * 0.25
             w2, k2, y2 = time_workload(plan2, x2, max(5, args.steps // 10), 2, world, device, args.kernel, windows=20)
             bytes2 = 4.0 * (x2.numel() + y2.numel())
+            c2_traffic, _, c2_prov = measured_counters("configs2") if (fft_kernel and args.seconds == 60) else (None, None, {})
             result["configs2"] = {"workload": f"BASELINE configs[2]: VHQ 44100->16000 float32, {args.seconds} s x 8 ch "
                                               f"interleaved [frames, 8], device-resident",
                                   "value": x2.numel() / k2 / 1e6, "unit": "Msamples/s", "launch_us": k2 * 1e6,
                                   "roofline": {"bound": "hbm", "achieved": bytes2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
                                                "unit": "GB/s", "frac": bytes2 / k2 / 1e9 / HBM_PEAK_GBS,
-                                               "traffic": 137313485 if args.seconds == 60 else None,  # profiles/r02_traffic.json
-                                               "kernel": "k_fft_strided2<4410x1600,float,channel pairs>"}}
+                                               "traffic": c2_traffic, "kernel": "k_fft_strided2<4410x1600,float,channel pairs>", **c2_prov}}
             del x2, y2, plan2
         except RuntimeError as e:  # context only
             result["configs2"] = {"error": str(e)}
@@ -478,15 +538,27 @@ def main():
                                   "hbm_frac": algo_bytes / ek / 1e9 / HBM_PEAK_GBS,
                                   "mfma_tflops": flops / ek / 1e12, "mfma_frac": flops / ek / 1e12 / VALU_PEAK_TFLOPS}
 
+    # the headline workload at the arithmetic width libsoxr's VHQ recipe itself computes in: float32 I/O on float64
+    # arithmetic (HIPSOXR_KERNEL_FFT_F64; SURVEY.md §0.3, reference src/soxr_ext.cpp:74,228)
+    if args.kernel == 0 and world == 1:
+        try:
+            fw, fk, _ = time_workload(plan, x, max(10, args.steps // 4), 5, world, device, kernel=8, windows=20)
+            result["arith_f64"] = {"kernel": "k_fft_pair2<.., double, float> (float32 I/O, float64 arithmetic)", "dtype": "f64 arithmetic, f32 I/O",
+                                   "launch_us": fk * 1e6, "value": n_in / fk / 1e6, "unit": "Msamples/s",
+                                   "frac": algo_bytes / fk / 1e9 / HBM_PEAK_GBS, "read_frac": 4.0 * n_in / fk / 1e9 / HBM_PEAK_GBS}
+        except RuntimeError as e:
+            result["arith_f64"] = {"error": str(e)}
+
     if rank == 0:
         ceil = hbm_ceiling(device)
         result["hbm_ceiling"] = ceil
         # the north star words its target against the HBM *read* roofline: input bytes only
         result["roofline"]["read_frac"] = 4.0 * n_in / kern / 1e9 / HBM_PEAK_GBS
-        result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / ceil["best_copy_GBs"]
-        if "batch_shard" in result:
-            result["batch_shard"]["roofline"]["frac_of_measured_copy"] = \
-                result["batch_shard"]["roofline"]["achieved"] / ceil["best_copy_GBs"]
+        if "best_copy_GBs" in ceil:
+            result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / ceil["best_copy_GBs"]
+            if "batch_shard" in result:
+                result["batch_shard"]["roofline"]["frac_of_measured_copy"] = \
+                    result["batch_shard"]["roofline"]["achieved"] / ceil["best_copy_GBs"]
     if rank == 0:
         result["ranks"] = rank_info
         if "batch_shard" in result:  # the line that is real HBM traffic (the 22 MB clip lives in the Infinity Cache)

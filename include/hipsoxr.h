@@ -169,6 +169,17 @@ typedef struct {
     uint64_t *clip_counter; /* device counter of saturated integer outputs, or NULL            */
     uint32_t dither;        /* 1: TPDF dither on int16 output                                    */
     uint32_t dither_seed;
+    /* Ragged batches — independent clips of unequal length in ONE job (what a corpus is: the reference takes any
+     * length per call, src/soxr/__init__.py:182-231).  NULL: every clip has in_frames / out_frames and starts at
+     * clip * clip_stride.  Else n_clips rows of four int64 { in_offset, in_frames, out_offset, out_frames }, offsets in
+     * ELEMENTS from `in` / `out` (clip c, frame f, channel ch is at in + in_offset[c] + f*in_frame_stride +
+     * ch*in_chan_stride; the clip strides are ignored), out_frames[c] <= hipsoxr_plan_out_len(in_frames[c]).  The
+     * table is given twice, in host memory (clip_table) and in device memory (clip_table_dev, same content);
+     * in_frames / out_frames of the job are then the LARGEST per-clip values.  Whole signals only (in_abs0 == 0,
+     * out_k0 == 0).  Unit-stride float columns go out as one launch of the frequency-domain engine; every other
+     * case is served clip by clip, same results. */
+    const int64_t *clip_table;
+    const int64_t *clip_table_dev;
 } hipsoxr_job_t;
 
 /* Enqueue the job on `hip_stream` (a hipStream_t; NULL = default stream). Asynchronous. */
@@ -205,13 +216,6 @@ HIPSOXR_API hipsoxr_plan_t *hipsoxr_stream_plan(hipsoxr_stream_t *);
  * unless set, so equal inputs give equal outputs — and two streams with the same seed dither alike.
  * Give concurrent streams distinct seeds to decorrelate them. */
 HIPSOXR_API hipsoxr_error_t hipsoxr_stream_set_dither_seed(hipsoxr_stream_t *, uint32_t seed);
-
-/* ---- measurement helper (no counterpart in the reference) -------------------------------- */
-/* Plain streaming kernels over device buffers, for the "achievable HBM rate" that bench.py
- * reports beside the roofline: mode 0 copies `bytes` from src to dst, mode 1 only reads src
- * (dst must still point to at least 4 writable bytes).  Asynchronous on `hip_stream`. */
-HIPSOXR_API hipsoxr_error_t hipsoxr_bench_stream(void *dst, const void *src, size_t bytes, int mode,
-                                                 void *hip_stream);
 
 /* ---- one-shot (create + process all + flush + delete), host pointers ---------------------- */
 HIPSOXR_API hipsoxr_error_t hipsoxr_oneshot(double in_rate, double out_rate, unsigned num_channels,

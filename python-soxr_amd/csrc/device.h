@@ -98,7 +98,6 @@ struct Switches {
 const Switches &switches();
 
 // measurement helper: mode 0 = copy src -> dst, 1 = read src only (dst: >= 4 bytes)
-const char *stream_kernel(void *dst, const void *src, size_t bytes, int mode, void *stream);
 
 // frequency-domain engine (fft.hip): whole-signal float32 jobs
 bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &job);

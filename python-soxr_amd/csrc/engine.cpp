@@ -1237,13 +1237,6 @@ hipsoxr_error_t hipsoxr_stream_set_io_ratio(hipsoxr_stream_t *s, double io_ratio
 
 hipsoxr_plan_t *hipsoxr_stream_plan(hipsoxr_stream_t *s) { return s ? s->plan : nullptr; }
 
-hipsoxr_error_t hipsoxr_bench_stream(void *dst, const void *src, size_t bytes, int mode, void *hip_stream)
-{
-    if (!dst || !src) return "null argument";
-    if (device_count() <= 0) return kNoDevice;
-    return stream_kernel(dst, src, bytes, mode, hip_stream);
-}
-
 hipsoxr_error_t hipsoxr_oneshot(double in_rate, double out_rate, unsigned num_channels,
                                 const void *in, size_t ilen, void *out, size_t olen, size_t *odone,
                                 hipsoxr_datatype_t io_type, unsigned long recipe,

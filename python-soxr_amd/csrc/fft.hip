@@ -415,6 +415,7 @@ struct FftArgs {
     uint32_t n_clips, n_channels;
     int64_t ics, ifs, ichs, ocs, ofs, ochs;
     int64_t in_frames, out_frames;
+    const int64_t *clip_tab; // ragged batch (hipsoxr_job_t::clip_table_dev): [n_clips][4] = in offset, in frames, out offset, out frames; k_fft_pair2 only
     int32_t chpair; // paired kernel: 1 = pair neighbouring channels of interleaved data instead of blocks
     int64_t pairs_per_col; // xcd_map: work items (blocks, or pairs of blocks) per channel unit
     int32_t xcd_map;       // interleaved multi-channel data: XCD-aware workgroup ids (see k_fft_pair)
@@ -850,7 +851,15 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     const int64_t pa = 2 * bx * a.hop_periods - a.lead_periods; // first period of block a; block b starts hop_periods later
     const int64_t ina = pa * a.M, outa = pa * a.L;
     const int32_t hop_in = (int32_t)(a.hop_periods * a.M);
-    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    // ragged batch: this clip's own place and length (four scalar loads; the grid spans the longest clip, so a
+    // workgroup beyond its clip's last pair has nothing to do)
+    int64_t clip_in = (int64_t)clip * a.ics, clip_out = (int64_t)clip * a.ocs, in_frames = a.in_frames, out_frames = a.out_frames;
+    if (a.clip_tab) {
+        const int64_t *row = a.clip_tab + 4 * (size_t)clip;
+        clip_in = row[0]; in_frames = row[1]; clip_out = row[2]; out_frames = row[3];
+        if (outa + a.v0 >= out_frames) return;
+    }
+    const IO *xin = (const IO *)a.in + clip_in + (int64_t)ch * a.ichs;
 #if defined(FFT2_ABL) && (FFT2_ABL & 8)
     auto lds_store = [&](int n, C v) { if (v.x == (Real)1234.5) cur[n] = v; };
 #else
@@ -860,7 +869,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
     if (ina >= 0) {
-        const int64_t left = (a.in_frames - ina) * ES; // bytes from block a's first sample to the end of the column
+        const int64_t left = (in_frames - ina) * ES; // bytes from block a's first sample to the end of the column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(xin + ina), 0, (int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left), 0x00020000);
         Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int t) -> C {
@@ -874,7 +883,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
         const int64_t inb = ina + hop_in;
         Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int) -> C {
             const int64_t la = ina + n, lb = inb + n;
-            return C((la >= 0 && la < a.in_frames) ? (Real)xin[la] : (Real)0, (lb >= 0 && lb < a.in_frames) ? (Real)xin[lb] : (Real)0);
+            return C((la >= 0 && la < in_frames) ? (Real)xin[la] : (Real)0, (lb >= 0 && lb < in_frames) ? (Real)xin[lb] : (Real)0);
         }, lds_store, false, tw);
     }
     __syncthreads();
@@ -882,7 +891,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 
     // ---- inverse (see k_fft_pair), last pass into the staging layout -------------------------------
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
-    IO *ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
+    IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
     // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
     const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
     const Real *Hr = PairTabs<Real>::hr(a);
@@ -909,7 +918,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     FFT_STAMP();
 
     // ---- store the run: elements [0, valid) of it exist in the column ----------------------------------
-    const int64_t remain = a.out_frames - (outa + v0);
+    const int64_t remain = out_frames - (outa + v0);
     const int32_t valid = (int32_t)(remain < 0 ? 0 : remain > 2 * (int64_t)hop_out ? 2 * (int64_t)hop_out : remain);
     // 16-byte buffer stores: the descriptor starts at the 16-byte granule that holds run[0] (sh elements before it)
     // and ends with the run, so the hardware range check drops what lies beyond the column (and the trips past the
@@ -1365,6 +1374,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.ics = j.in_clip_stride; a.ifs = j.in_frame_stride; a.ichs = j.in_chan_stride;
                 a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
                 a.in_frames = j.in_frames; a.out_frames = j.out_frames;
+                a.clip_tab = j.clip_table_dev;
                 const int64_t n_blocks = (j.out_frames + g.hop_out - 1) / g.hop_out;
                 if (n_blocks > 2147483647LL) return "job too long for one launch";
                 // interleaved data with an even channel count: pair channels (aligned float2 per frame)
@@ -1418,6 +1428,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }
+                // ragged batches: the unit-stride second-generation kernel reads its clip's row; nothing else does
+                if (j.clip_table && !(v2ok && (f64 || !switches().fft_pair_v1))) return nullptr;
                 if (!kern) return nullptr; // (no first-generation instance of this schedule: the general path takes the job)
 #ifdef FFT2_TRACE
                 size_t trace_n = 0;
@@ -1444,7 +1456,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         }
     }
     // ---- general path: one block per workgroup ---------------------------------------------------
-    if (f64) return nullptr; // float32 only
+    if (f64 || j.clip_table) return nullptr; // float32 only, no ragged batches
     FftGeom g;
     if (const char *err = get(0, 0, &g)) return err;
     if (g.ok) {
@@ -1461,7 +1473,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
     a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
-    a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr;
+    a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr; a.clip_tab = nullptr;
     a.A = g.A; a.B = g.B; a.nA = g.nA; a.nB = g.nB;
     for (int i = 0; i < 8; ++i) { a.radA[i] = g.radA[i]; a.radB[i] = g.radB[i]; }
     a.L = p->L; a.M = p->M;

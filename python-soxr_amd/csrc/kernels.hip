@@ -2260,33 +2260,6 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st,
     return launch_gather<IO, Real>(p, j, st, nullptr, nullptr, cd);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Measurement helpers (bench.py "hbm_ceiling"): what plain streaming kernels reach on this device,
-// so roofline fractions can be read against the achievable rate as well as the 8 TB/s spec.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_stream_copy(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-}
-__global__ void __launch_bounds__(256) k_stream_read(float *__restrict__ sink, const float4 *__restrict__ src, size_t n)
-{
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float4 v = src[i];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x; // never true for the test data; keeps the loads
-}
-const char *stream_kernel(void *dst, const void *src, size_t bytes, int mode, void *stream)
-{
-    const size_t n = bytes / sizeof(float4);
-    const unsigned blocks = 256 * 16; // 16 workgroups per CU, grid-stride
-    if (mode == 0) hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)dst, (const float4 *)src, n);
-    else hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float *)dst, (const float4 *)src, n);
-    HIP_TRY(hipGetLastError());
-    return nullptr;
-}
-
 bool resident_post(const Plan &p, volatile uint64_t *w, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames)
 {
     const __int128 kM = (__int128)out_k0 * p.M;
@@ -2318,6 +2291,40 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     if (cd) cd->n_wgs = 0;
     if (j.out_frames <= 0 || j.n_clips == 0 || j.n_channels == 0) return res ? "resident kernel: empty job" : nullptr;
     if (res && (uint64_t)j.n_clips * j.n_channels > 65535) return "resident kernel: too many columns";
+    // Ragged batch (hipsoxr_job_t::clip_table): one launch of the frequency-domain engine when it can take the job
+    // (the kernel reads its clip's row), else clip by clip through the ordinary path — clips are independent, so the
+    // results are the same either way; bit-exact engines stay bit-exact.
+    if (j.clip_table) {
+        if (vr || res) return "ragged batches: constant-rate device jobs only";
+        if (j.in_abs0 != 0 || j.out_k0 != 0) return "ragged batches: whole signals only (in_abs0 == 0, out_k0 == 0)";
+        if (!j.clip_table_dev) return "ragged batches need the table in device memory too (clip_table_dev)";
+        for (uint32_t c = 0; c < j.n_clips; ++c) {
+            const int64_t *r = j.clip_table + 4 * (size_t)c;
+            if (r[1] < 0 || r[3] < 0 || r[1] > j.in_frames || r[3] > j.out_frames || (uint64_t)r[3] > plan_out_len(*p, (uint64_t)r[1]))
+                return "ragged batches: a clip's frame counts exceed the job's or the plan's output length";
+        }
+        if ((j.kernel == HIPSOXR_KERNEL_AUTO || j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_FFT_F64) &&
+            (uint64_t)j.n_clips * j.n_channels <= 65535 && !switches().no_fft && fft_job_eligible(*p, j)) {
+            if (const char *e = device_bank_ensure(p, engine_prec(j.elem))) return e;
+            bool handled = false;
+            if (const char *e = launch_fft(p, j, stream, &handled)) return e;
+            if (handled) return nullptr;
+        }
+        if (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_FFT_F64) return "FFT engine unavailable for this ragged job (unit-stride float columns of a tabled ratio)";
+        const size_t es = elem_size(j.elem);
+        for (uint32_t c = 0; c < j.n_clips; ++c) {
+            const int64_t *r = j.clip_table + 4 * (size_t)c;
+            if (r[3] == 0) continue;
+            hipsoxr_job_t one = j;
+            one.clip_table = one.clip_table_dev = nullptr;
+            one.n_clips = 1;
+            one.in = (const char *)j.in + r[0] * (int64_t)es;
+            one.out = (char *)j.out + r[2] * (int64_t)es;
+            one.in_frames = r[1]; one.out_frames = r[3];
+            if (const char *e = launch_job(p, one, stream)) return e;
+        }
+        return nullptr;
+    }
     // Kernels index (clip, channel) columns through grid.y (<= 65535).  Wider jobs — the Python surface
     // admits 65536 channels like the reference, src/soxr/__init__.py:22 — are folded into several
     // launches over channel (or clip) ranges; columns are independent, so the result is the same.

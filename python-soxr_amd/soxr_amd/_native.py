@@ -73,7 +73,8 @@ class Job(C.Structure):
                 ("out_clip_stride", C.c_int64), ("out_frame_stride", C.c_int64), ("out_chan_stride", C.c_int64),
                 ("in_abs0", C.c_int64), ("in_frames", C.c_int64),
                 ("out_k0", C.c_int64), ("out_frames", C.c_int64),
-                ("clip_counter", C.c_void_p), ("dither", C.c_uint32), ("dither_seed", C.c_uint32)]
+                ("clip_counter", C.c_void_p), ("dither", C.c_uint32), ("dither_seed", C.c_uint32),
+                ("clip_table", C.c_void_p), ("clip_table_dev", C.c_void_p)]
 
 
 _err = C.c_char_p
@@ -105,7 +106,6 @@ SIGNATURES = {
     "hipsoxr_stream_set_io_ratio": (_err, [C.c_void_p, C.c_double, C.c_size_t]),
     "hipsoxr_stream_plan": (C.c_void_p, [C.c_void_p]),
     "hipsoxr_stream_set_dither_seed": (_err, [C.c_void_p, C.c_uint32]),
-    "hipsoxr_bench_stream": (_err, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "hipsoxr_oneshot": (_err, [C.c_double, C.c_double, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p,
                                C.c_size_t, _P(C.c_size_t), C.c_int, C.c_ulong, C.c_ulong]),
 }

@@ -1,7 +1,8 @@
-"""N > 1 path on CPU: world_size-2 `gloo` processes exercise exactly what bench.py does across
-ranks — contiguous clip sharding with no data-path collective, plus the one collective the path
-has (broadcast of the shared filter bank from rank 0).  The per-clip arithmetic is stood in for by
-the oracle (there is no GPU here); what is under test is the partition / broadcast logic."""
+"""N > 1 path on CPU: world_size-2 `gloo` processes exercise the product's multi-GPU module
+(`soxr_amd.dist`: `shard`, `broadcast_bank`, `rank_info` — what bench.py and a one-process-per-GPU job call) —
+contiguous clip sharding with no data-path collective, plus the one collective the path has (broadcast of the
+shared filter bank from rank 0).  The per-clip arithmetic is stood in for by the oracle (there is no GPU here);
+what is under test is the partition / broadcast logic."""
 import os
 import socket
 import sys
@@ -25,9 +26,8 @@ def _worker(rank, world, port, n_clips, out_dir):
     sys.path.insert(0, os.path.join(ROOT, "python-soxr_amd"))
     import torch
     import torch.distributed as dist
-    import bench
     from oracle import oracle
-    from soxr_amd import device as dev
+    from soxr_amd import device as dev, dist as sdist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -35,9 +35,11 @@ def _worker(rank, world, port, n_clips, out_dir):
     plan = dev.Plan(48000, 44100, "HQ")
     if rank != 0:                       # prove the broadcast is what installs the bank
         plan.set_bank(np.zeros((plan.L, plan.taps)))
-    bench.broadcast_bank(plan, rank, world, torch.device("cpu"))
+    sdist.broadcast_bank(plan)               # default group, backend gloo: the bank travels as a host tensor
     bank = plan.bank()
-    lo, hi = bench.shard(n_clips, world, rank)
+    info = sdist.rank_info(plan)
+    assert info["ranks_seen"] == world and info["banks_identical"] and info["backend"] == "gloo"
+    lo, hi = sdist.shard(n_clips, world, rank)
     opl = oracle.plan(48000, 44100, "HQ")
     outs = {}
     for clip in range(lo, hi):          # each rank resamples only its own clips
@@ -72,13 +74,17 @@ def test_two_rank_sharding_and_bank_broadcast(tmp_path, n_clips, oracle):
 
 
 def test_shard_partition_properties():
-    sys.path.insert(0, ROOT)
-    import bench
+    from soxr_amd import dist as sdist
     for n in (0, 1, 7, 128, 1024, 1025):
         for world in (1, 2, 3, 4, 8):
-            parts = [bench.shard(n, world, r) for r in range(world)]
+            parts = [sdist.shard(n, world, r) for r in range(world)]
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
-    assert bench.shard(1024, 8, 3) == (384, 512)
+    assert sdist.shard(1024, 8, 3) == (384, 512)
+    with pytest.raises(ValueError):
+        sdist.shard(8, 2, 2)
+    sys.path.insert(0, ROOT)
+    import bench                                 # bench.py uses the product's rule, not a copy of it
+    assert bench.shard(1024, 8, 3) == sdist.shard(1024, 8, 3)

@@ -1,0 +1,119 @@
+"""soxr_amd.dist on the GPU: ragged batches as one job (hipsoxr_job_t::clip_table), the one-process / one-thread-per-
+device `resample_batch`, and BASELINE configs[3] WHOLE on one GPU (1024 x 10 s clips — the strong-scaling anchor)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EXACT, FFT, FFT_F64 = 6, 5, 8
+
+
+def _rms(a):
+    return float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+
+
+def test_resample_batch_three_unequal_clips_bit_exact(oracle):
+    """Three clips of unequal length, one call, canonical-order engine: each result equals the oracle's port of that
+    clip alone, bit for bit (ragged jobs outside the frequency-domain engine are served clip by clip)."""
+    from soxr_amd import dist as sdist, device as dev
+    rng = np.random.default_rng(31)
+    clips = [(rng.standard_normal(n) * 0.25).astype(np.float32) for n in (48000, 1234, 100001)]
+    outs = sdist.resample_batch(clips, 48000, 44100, "VHQ", devices=[0], kernel=dev.KERNEL_EXACT)
+    assert len(outs) == 3
+    for x, y in zip(clips, outs):
+        want = oracle.resample(x, 48000, 44100, "VHQ", mode="port")
+        assert isinstance(y, np.ndarray) and y.dtype == np.float32 and y.shape == want.shape
+        assert np.array_equal(y, want)
+    # the same through integer I/O and two channels (clip-by-clip path), incl. an empty and a one-frame clip
+    ci = [(rng.standard_normal((n, 2)) * 4000).astype(np.int16) for n in (5000, 0, 1, 20011)]
+    oi = sdist.resample_batch(ci, 44100, 16000, "HQ", devices=[0], kernel=dev.KERNEL_EXACT)
+    for x, y in zip(ci, oi):
+        want = oracle.resample(x, 44100, 16000, "HQ")
+        assert y.shape == want.shape and np.array_equal(y, want)
+
+
+@pytest.mark.parametrize("dtype,kernel,tol", [(np.float32, 0, 1e-6), (np.float32, FFT_F64, 5e-8), (np.float64, 0, 2e-9)])
+def test_ragged_job_is_one_launch_of_the_fft_engine(oracle, dtype, kernel, tol):
+    """Unit-stride float clips of unequal length: ONE launch of k_fft_pair2 (every workgroup reads its clip's row of
+    the table), results within the engine's bar of the oracle's float64 direct form — first and last outputs of every
+    clip included (the zero extension past each clip's own end is the hardware range check on ITS length)."""
+    import torch
+    from soxr_amd import dist as sdist, device as dev
+    rng = np.random.default_rng(32)
+    lens = [9000, 100000, 1, 52345, 300007, 4704, 0, 77777]
+    clips = [torch.from_numpy((rng.standard_normal(n) * 0.25).astype(dtype)).cuda() for n in lens]
+    plan = dev.Plan(48000, 44100, "VHQ")
+    job = sdist.RaggedJob(plan, clips, kernel=kernel)
+    job.y.fill_(7.0)                                            # anything not written would show
+    job.launch()
+    torch.cuda.synchronize()
+    outs = job.outputs()
+    for n, x, y in zip(lens, clips, outs):
+        ref = oracle.resample(x.cpu().numpy().astype(np.float64), 48000, 44100, "VHQ", mode="ref")
+        y = y.cpu().numpy().astype(np.float64)
+        assert y.shape == ref.shape, n
+        if len(ref):
+            assert _rms(y - ref) <= tol * max(_rms(ref), 0.05), (n, _rms(y - ref) / max(_rms(ref), 0.05))
+            # the head and the tail on their own
+            w = min(len(ref), 300)
+            assert _rms(y[:w] - ref[:w]) <= 4 * tol * 0.25 and _rms(y[-w:] - ref[-w:]) <= 4 * tol * 0.25, n
+    # and close to what each clip gives as a job of its own (a lone clip may be cut into smaller blocks: not bit-equal)
+    for x, y in zip(clips, outs):
+        if x.numel() >= 8192 * 2:
+            alone = dev.resample_tensor(plan, x, kernel=kernel)
+            assert _rms((alone - y).cpu().numpy()) <= 2 * tol * 0.25
+
+
+def test_ragged_job_rejects_bad_tables():
+    import torch
+    from soxr_amd import dist as sdist, device as dev, _native as nat
+    plan = dev.Plan(48000, 44100, "HQ")
+    clips = [torch.zeros(5000, device="cuda"), torch.zeros(7000, device="cuda")]
+    job = sdist.RaggedJob(plan, clips)
+    job._table[1, 3] += 1                                       # more output than the plan allows for this clip
+    with pytest.raises(RuntimeError):
+        job.launch()
+    job._table[1, 3] -= 1
+    job._job.clip_table_dev = None                              # host table without its device copy
+    with pytest.raises(RuntimeError):
+        job.launch()
+    with pytest.raises(ValueError):
+        sdist.RaggedJob(plan, [torch.zeros(10, device="cuda"), torch.zeros((10, 2), device="cuda")])
+
+
+def test_resample_batch_threads_over_devices_and_order():
+    """One thread + stream per device (here: the one GPU listed twice — the code path of an 8-GPU node; results are
+    in the caller's order whatever the partition)."""
+    import torch
+    from soxr_amd import dist as sdist, device as dev
+    rng = np.random.default_rng(33)
+    clips = [(rng.standard_normal(20000 + 997 * i) * 0.25).astype(np.float32) for i in range(7)]
+    one = sdist.resample_batch(clips, 48000, 44100, "VHQ", devices=[0], kernel=dev.KERNEL_EXACT)
+    two = sdist.resample_batch(clips, 48000, 44100, "VHQ", devices=[0, 0], kernel=dev.KERNEL_EXACT)
+    three = sdist.resample_batch([torch.from_numpy(c) for c in clips], 48000, 44100, "VHQ", devices=[0, 0, 0], kernel=dev.KERNEL_EXACT)
+    for a, b, c in zip(one, two, three):
+        assert np.array_equal(a, b) and torch.is_tensor(c) and c.is_cuda and np.array_equal(a, c.cpu().numpy())
+    assert sdist.resample_batch([], 48000, 44100) == []
+
+
+def test_config3_whole_batch_on_one_gpu(oracle):
+    """BASELINE configs[3] whole: 1024 independent 10 s clips, VHQ 48k -> 44.1k, float32, on ONE GPU (3.8 GB of
+    signal; the N = 1 point of the strong-scaling line).  Clip independence (batched == alone, bit for bit, for the
+    same engine) and the 1e-6 bar against the oracle's float64 direct form on windows of three clips."""
+    import torch
+    from soxr_amd import device as dev
+    plan = dev.Plan(48000, 44100, "VHQ")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn((1024, 480000, 1), device="cuda", generator=g) * 0.25
+    y = dev.resample_tensor(plan, x)
+    assert tuple(y.shape) == (1024, 441000, 1)
+    rng = np.random.default_rng(40)
+    opl = oracle.plan(48000, 44100, "VHQ")
+    for clip in (0, 511, 1023):
+        alone = dev.resample_tensor(plan, x[clip, :, 0].contiguous().repeat(128, 1)[:, :, None])  # a 128-clip job: same block size
+        assert torch.equal(alone[5, :, 0], y[clip, :, 0])
+        xc, yc = x[clip, :, 0].cpu().numpy().astype(np.float64), y[clip, :, 0].cpu().numpy().astype(np.float64)
+        for k0 in (0, 441000 - 2000, int(rng.integers(0, 439000))):
+            want = oracle.resample_channel(opl, xc, "ref", k0=k0, n_out=2000)
+            assert _rms(yc[k0:k0 + 2000] - want) <= 1e-6 * max(_rms(want), 0.05)
+    del x, y
+    torch.cuda.empty_cache()

@@ -137,3 +137,26 @@ def test_golden_vectors(oracle, case):
     flat = pl.bank.reshape(-1)
     idx = np.linspace(0, flat.size - 1, len(case["bank_samples"])).astype(np.int64)
     assert np.abs(flat[idx] - np.array(case["bank_samples"])).max() <= 2e-13 * np.abs(flat).max()
+
+
+def _golden_ref():
+    with open(os.path.join(HERE, "golden", "oracle_ref_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", _golden_ref()["cases"], ids=lambda c: c["name"])
+def test_ref_golden_vectors(oracle, case):
+    """The design-independent fixtures (tests/golden/make_golden_ref.py: `ref` mode on the oracle's OWN bank — nothing
+    of the product's plan.cpp enters) are reproduced by the oracle: pins oracle/design.py and the float64 direct form
+    against accidental change.  (1e-12: scipy/numpy builds may differ in the last bits of i0e / sinc.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_ref", os.path.join(HERE, "golden", "make_golden_ref.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    x = mg.make_input(case["dtype"], case["frames"], case["channels"], case["seed"])
+    y = oracle.resample(x.astype(np.float64), case["in_rate"], case["out_rate"], case["quality"], mode="ref")
+    pl = oracle.plan(case["in_rate"], case["out_rate"], case["quality"])
+    assert (pl.L, pl.M, pl.T) == (case["L"], case["M"], case["taps"]) and y.shape[0] == case["out_frames"]
+    idx = np.asarray(case["index"])
+    assert np.array_equal(idx, mg.sample_index(y.shape[0]))
+    assert np.abs(y[idx] - np.asarray(case["values"])).max() <= 1e-12 * max(1.0, case["rms"])
