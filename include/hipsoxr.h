@@ -80,7 +80,10 @@ typedef enum {
                                   per call.  Same output, bit for bit.  The kernel leaves by itself after
                                   HIPSOXR_RESIDENT_IDLE_US (default 1000) without a call; until then device-wide
                                   synchronisations elsewhere in the process wait for it.  Constant-rate
-                                  interleaved streams without HIPSOXR_DEFER.  Also: environment HIPSOXR_RESIDENT. */
+                                  interleaved streams without HIPSOXR_DEFER.  Also: environment HIPSOXR_RESIDENT.
+                                  Without the flag a stream turns this path on BY ITSELF once it has been fed 16 small
+                                  chunks back to back (each within 500 us of the one before), and the kernel retires
+                                  itself on idle as above; environment HIPSOXR_NO_AUTO_RESIDENT disables that. */
 
 /* Element types used by device jobs (layout is given by strides, not by the type). */
 typedef enum { HIPSOXR_F32 = 0, HIPSOXR_F64 = 1, HIPSOXR_I32 = 2, HIPSOXR_I16 = 3 } hipsoxr_elem_t;

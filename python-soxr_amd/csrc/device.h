@@ -71,6 +71,7 @@ struct Switches {
     bool fft_no_pair = false;     // HIPSOXR_FFT_NO_PAIR      one block per workgroup instead of the paired kernel
     bool fft_no_chpair = false;   // HIPSOXR_FFT_NO_CHPAIR    pair blocks even for interleaved even-channel data
     bool fft_no_xcd_map = false;  // HIPSOXR_FFT_NO_XCD_MAP   plain (block, column) workgroup ids for interleaved data
+    bool fft_persist = false;     // HIPSOXR_FFT_PERSIST      48k<->44.1k / 44.1k<->16k float32 jobs on resident workgroups with an item queue (k_fft_pair2p: A/B only, slower)
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
     bool fft_no_tiny = false;     // HIPSOXR_FFT_NO_TINY      never the quarter-size blocks
@@ -81,6 +82,7 @@ struct Switches {
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
     bool no_done_words = false;   // HIPSOXR_NO_DONE_WORDS    streaming calls wait on an event, not on the kernel's completion words
     bool resident = false;        // HIPSOXR_RESIDENT         small-chunk synchronous streams use the resident kernel (as the HIPSOXR_RESIDENT flag)
+    bool no_auto_resident = false; // HIPSOXR_NO_AUTO_RESIDENT streams never turn the resident path on by themselves (16 small back-to-back calls do, by default)
     int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
     bool resident_no_bar = false; // HIPSOXR_RESIDENT_NO_BAR  mailbox words and input stay in pinned host memory even on large-BAR systems
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids

@@ -111,6 +111,13 @@ struct hipsoxr_stream {
     // Resident kernel (HIPSOXR_RESIDENT): synchronous small chunks are handed to a kernel that stays on the GPU
     // between calls, through a mailbox in pinned memory — no HIP call per chunk (see resident_emit)
     bool resident = false;
+    // Low latency by default: a constant-rate interleaved stream that is being fed small chunks back to back turns the
+    // resident path on by itself after kAutoResidentRun such calls in a row (each within half the kernel's idle time of
+    // the one before: a caller pacing 10 ms chunks in real time gains nothing from a kernel that leaves after 1 ms, and
+    // is left alone).  HIPSOXR_NO_AUTO_RESIDENT turns this off; the flag / environment switch turn it on from call 1.
+    bool resident_auto_ok = false;
+    unsigned small_run = 0;
+    std::chrono::steady_clock::time_point last_small;
     struct Resident {
         ResidentBox *box = nullptr;  // pinned
         ResidentCtl *ctl = nullptr;  // device: kCtlSlots arbiter words, one per instance
@@ -159,6 +166,7 @@ struct DeviceGuard {
 // n * 1024 / occ milli-CUs (with a large-LDS plan, one workgroup per CU, 64 workgroups are 64 CUs), and the process
 // keeps at most half the chip resident, so every admitted instance's workgroups really are on the chip together.
 static std::atomic<int64_t> g_resident_mcu{0};
+static const unsigned kAutoResidentRun = 16; // small back-to-back synchronous calls before a stream turns resident by itself
 
 // Retire the stream's resident kernel, if one is running: everything else that uses the HIP stream queues
 // behind it (and would wait until it leaves by itself, HIPSOXR_RESIDENT_IDLE_US later).
@@ -826,7 +834,15 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     ChainDone cd;
     cd.words = nullptr; cd.cap = 0; cd.seq = 0;
     bool served = false;
-    if (s->resident && s->ring_on_host && direct && !v.on && !s->split && s->in_fill > 0 && n <= 2048) {
+    const bool small_call = s->ring_on_host && direct && !v.on && !s->split && s->in_fill > 0 && n <= 2048;
+    if (!s->resident && s->resident_auto_ok) {
+        const auto now = std::chrono::steady_clock::now();
+        const auto gap = std::chrono::microseconds(std::max(50, switches().resident_idle_us) / 2);
+        s->small_run = (small_call && (s->small_run == 0 || now - s->last_small < gap)) ? s->small_run + 1 : 0;
+        s->last_small = now;
+        if (s->small_run >= kAutoResidentRun) s->resident = true;
+    }
+    if (s->resident && small_call) {
         if (const char *e = resident_emit(s, j, &served)) return e;
     }
     if (served) {
@@ -1001,6 +1017,7 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
     s->elem = (int)io & 3; s->split = ((int)io & 4) != 0; s->flags = flags;
     s->defer = (flags & HIPSOXR_DEFER) && !(flags & HIPSOXR_VR) && !s->split;
     s->resident = ((flags & HIPSOXR_RESIDENT) || switches().resident) && !s->defer && !(flags & HIPSOXR_VR) && !s->split;
+    s->resident_auto_ok = !s->resident && !s->defer && !(flags & HIPSOXR_VR) && !s->split && !switches().no_auto_resident;
     if (flags & HIPSOXR_VR) {
         const double io0 = plan->p.in_rate / plan->p.out_rate;
         if (!(io0 > 9.5367431640625e-07) || !(io0 < 1048576.)) { delete s; return "io ratio out of range for variable rate"; }

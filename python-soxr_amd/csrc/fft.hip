@@ -257,20 +257,54 @@ __device__ __forceinline__ void fft_pass(cf *buf, int N, int Ns, const cf *W)
 // PRE: the butterfly's twiddle was fetched earlier (pre_w1, one butterfly per thread) — for small
 // jobs, whose cost is the latency of a single workgroup, every table read that follows a barrier
 // is an exposed L2 round trip; fetched at kernel start they all overlap with the input loads.
-template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, bool PRE = false, typename C, typename Load, typename Store>
-__device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, C pre_w1 = C())
+// EARLY (-DFFT_EARLY_TABLES; measured in round 3 and left off): both table entries of the butterfly's twiddle (w and
+// w^4), and the first inverse pass's filter values, fetched one barrier ahead — after the previous pass's LDS stores
+// were issued, before the barrier in front of this pass — so that their L2 round trip would run behind the store drain
+// and the barrier.  No register is held across a butterfly for it, and it does not pay: the loads' issue delays the
+// wave's arrival at the barrier by as much as their latency was hidden behind the LDS reads before (batch 137 vs
+// 138 us, 60 s clip 12.2 vs 11.7 us on the same box).
+// The thread's index through an opaque move.  In the resident-workgroup kernel (k_fft_pair2p) the item is the body of a
+// loop, and everything that depends only on threadIdx.x and the kernel arguments — per-thread table addresses, LDS
+// indices and offsets of six passes — is loop-invariant: the compiler hoists it all out and keeps it alive across the
+// loop (216 VGPRs and 35 spilled SGPRs where the grid-per-item kernel needs 68; a real function call instead costs
+// the calling convention's alternating caller/callee-saved register blocks: highest VGPR 102).  A volatile asm is
+// not loop-invariant, so index arithmetic that starts from this value stays where it is written.  (The other half is
+// build.sh's -mllvm -disable-machine-licm for this file: the machine-level pass hoists the materialisation of every
+// literal — butterfly constants, scalar offsets — into registers of its own: 112 VGPRs / 17 spilled SGPRs with it,
+// 70 / 0 without; the straight-line kernels of this file do not change.)
+__device__ __forceinline__ int fft_tid()
+{
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+template <typename C> struct TwPre { C w1, w4; };
+template <int N, int Ns, int R, int NT, typename C> __device__ __forceinline__ TwPre<C> tw_fetch(const C *W)
+{
+    constexpr int nb = N / R, wstep = N / (Ns * R);
+    static_assert((nb + NT - 1) / NT == 1, "early twiddles: one butterfly per thread");
+    const int tid = fft_tid(), j = tid < nb ? tid : 0, k = j % Ns;
+    TwPre<C> t;
+    t.w1 = W[k * wstep];
+    t.w4 = R >= 10 ? W[4 * k * wstep] : t.w1;
+    return t;
+}
+template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, bool PRE = false, bool EARLY = false, typename C, typename Load, typename Store>
+__device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, C pre_w1 = C(), TwPre<C> early = TwPre<C>())
 {
     constexpr int nb = N / R, wstep = N / (Ns * R), NB = (nb + NT - 1) / NT;
     static_assert(!PRE || (NB == 1 && R < 10), "prefetched twiddles: one butterfly per thread, radix < 10");
+    static_assert(!EARLY || NB == 1, "early twiddles: one butterfly per thread");
     typedef real_of<C> T;
+    const int tid = fft_tid();
     C u[NB][R];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int j = threadIdx.x + i * NT;
+        const int j = tid + i * NT;
         if (NB * NT == nb || j < nb) {
             const int k = j % Ns;
             C w1 = C((T)1, (T)0);
-            if (Ns > 1) w1 = PRE ? pre_w1 : W[k * wstep]; // issued before the data reads: the latencies overlap
+            if (Ns > 1) w1 = EARLY ? early.w1 : PRE ? pre_w1 : W[k * wstep]; // issued before the data reads: the latencies overlap
 #pragma unroll
             for (int t = 0; t < R; ++t) {
                 if constexpr (std::is_invocable_v<Load, int, int>) u[i][t] = load(j + t * nb, t); // t: input slot
@@ -288,7 +322,7 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, 
                 C pw[R];
                 pw[1] = w1;
                 if constexpr (R >= 10) {
-                    const C w4 = W[4 * k * wstep]; // 4*k*wstep < 4N/R <= N
+                    const C w4 = EARLY ? early.w4 : W[4 * k * wstep]; // 4*k*wstep < 4N/R <= N
 #pragma unroll
                     for (int t = 2; t < R; ++t) {
                         const int a4 = t / 4, b4 = t % 4;
@@ -311,7 +345,7 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, 
     if (SYNC_BEFORE_STORE) __syncthreads(); // in-place: every input of the pass is in registers
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int j = threadIdx.x + i * NT;
+        const int j = tid + i * NT;
         if (NB * NT == nb || j < nb) {
             const int k = j % Ns, o = (j - k) * R + k;
 #pragma unroll
@@ -387,13 +421,25 @@ __device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL C *buf, const C *W, Load 
     if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, swz_store);
     else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, swz_store);
     FFT_STAMP();
+#ifdef FFT_EARLY_TABLES
+    constexpr bool EARLY = true;
+    const TwPre<C> t1 = tw_fetch<N, R0, R1, NT>(W); // (behind this pass's stores, in front of the barrier)
+#else
+    constexpr bool EARLY = false;
+    const TwPre<C> t1 = TwPre<C>();
+#endif
     __syncthreads();
     FFT_STAMP();
-    fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, swz_load, lds_store);
+    fft_pass_ct<N, R0, R1, SIGN, NT, true, false, EARLY>(W, swz_load, lds_store, C(), t1);
     FFT_STAMP();
+#ifdef FFT_EARLY_TABLES
+    const TwPre<C> t2 = tw_fetch<N, R0 * R1, R2, NT>(W);
+#else
+    const TwPre<C> t2 = TwPre<C>();
+#endif
     __syncthreads();
     FFT_STAMP();
-    fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load, last_store);
+    fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC, false, EARLY>(W, lds_load, last_store, C(), t2);
     FFT_STAMP();
 }
 
@@ -415,6 +461,8 @@ struct FftArgs {
     uint32_t n_clips, n_channels;
     int64_t ics, ifs, ichs, ocs, ofs, ochs;
     int64_t in_frames, out_frames;
+    uint32_t *queue;         // k_fft_pair2p: {items handed out beyond the grid's own, workgroups that have left}, zero between launches
+    uint32_t n_items;        // k_fft_pair2p: columns x pairs_per_col
     const int64_t *clip_tab; // ragged batch (hipsoxr_job_t::clip_table_dev): [n_clips][4] = in offset, in frames, out offset, out frames; k_fft_pair2 only
     int32_t chpair; // paired kernel: 1 = pair neighbouring channels of interleaved data instead of blocks
     int64_t pairs_per_col; // xcd_map: work items (blocks, or pairs of blocks) per channel unit
@@ -788,6 +836,12 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair(FftArgs a)
 //     whole 16-byte granules instead of 256 unaligned bytes per instruction (k_fft_pair: write traffic
 //     1.17x the algorithmic bytes with streaming stores).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void *uniform_ptr(void *p) // the same address, provably wave-uniform (two v_readfirstlane)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<void *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v));
+}
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 template <typename Real> __device__ __forceinline__ Real buf_load_real(__amdgpu_buffer_rsrc_t r, int voff, int soff);
@@ -829,13 +883,15 @@ template <> struct PairTabs<double> {
 // arithmetic — what libsoxr's VHQ recipe itself does for float32 clients (reference src/soxr_ext.cpp:74,228 hand the
 // recipe to soxr_quality_spec) — selected by HIPSOXR_KERNEL_FFT_F64.  Loads widen, the staged run and
 // the stores are in the I/O type; everything between is the float64 instance.
-template <typename Spec, typename Real, typename IO = Real>
-__global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
+// One work item = one pair of blocks of one column: item (col, bx).  `staged()` runs in every thread after the run has
+// been staged in LDS and in front of the barrier that publishes it (the persistent kernel posts its next item there).
+// Returns false, having done nothing, when the item lies beyond its clip (ragged batches).
+template <typename Spec, typename Real, typename IO, typename Staged>
+__device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem_raw, uint32_t col, int64_t bx, Staged staged)
 {
     typedef typename PairTabs<Real>::C C;
     typedef typename PairTabs<IO>::V16 V16;
     constexpr int ES = (int)sizeof(IO), EPS = 16 / ES; // element size, elements per 16-byte store
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C *cur = reinterpret_cast<C *>(smem_raw);
     IO *stage = reinterpret_cast<IO *>(smem_raw);
     constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0;
@@ -845,9 +901,8 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     FFT_STAMP();
 #endif
 
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(blockIdx.y % a.n_channels);
-    const uint32_t clip = __builtin_amdgcn_readfirstlane(blockIdx.y / a.n_channels);
-    const int64_t bx = blockIdx.x;
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels);
+    const uint32_t clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
     const int64_t pa = 2 * bx * a.hop_periods - a.lead_periods; // first period of block a; block b starts hop_periods later
     const int64_t ina = pa * a.M, outa = pa * a.L;
     const int32_t hop_in = (int32_t)(a.hop_periods * a.M);
@@ -857,7 +912,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     if (a.clip_tab) {
         const int64_t *row = a.clip_tab + 4 * (size_t)clip;
         clip_in = row[0]; in_frames = row[1]; clip_out = row[2]; out_frames = row[3];
-        if (outa + a.v0 >= out_frames) return;
+        if (outa + a.v0 >= out_frames) return false;
     }
     const IO *xin = (const IO *)a.in + clip_in + (int64_t)ch * a.ichs;
 #if defined(FFT2_ABL) && (FFT2_ABL & 8)
@@ -870,8 +925,10 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
     if (ina >= 0) {
         const int64_t left = (in_frames - ina) * ES; // bytes from block a's first sample to the end of the column
+        // (descriptor words marked wave-uniform: in the resident-workgroup kernel the item comes out of LDS and the
+        //  compiler would otherwise keep the descriptor in VGPRs and wrap every load in a waterfall loop)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(xin + ina), 0, (int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left), 0x00020000);
+            uniform_ptr((void *)(xin + ina)), 0, __builtin_amdgcn_readfirstlane((int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left)), 0x00020000);
         Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int t) -> C {
             const int j4 = (n - t * nbA) * ES; // the butterfly's own offset (one VGPR for all t)
 #if defined(FFT2_ABL) && (FFT2_ABL & 2)
@@ -886,6 +943,21 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
             return C((la >= 0 && la < in_frames) ? (Real)xin[la] : (Real)0, (lb >= 0 && lb < in_frames) ? (Real)xin[lb] : (Real)0);
         }, lds_store, false, tw);
     }
+    // the filter values of the first inverse pass, one barrier early (see TwPre): the butterfly of thread j takes bins
+    // j + t * NB/RB0, t = 0 .. RB0-1, at |frequency| q = min(n, NB - n)
+    const Real *Hr = PairTabs<Real>::hr(a);
+#ifdef FFT_EARLY_TABLES
+    constexpr int RB0 = Spec::RB0, nbB = NB / RB0;
+    Real hpre[RB0];
+    {
+        const int tid = fft_tid(), jb = tid < nbB ? tid : 0;
+#pragma unroll
+        for (int t = 0; t < RB0; ++t) {
+            const int n = jb + t * nbB;
+            hpre[t] = Hr[n > NB / 2 ? NB - n : n];
+        }
+    }
+#endif
     __syncthreads();
     FFT_STAMP();
 
@@ -894,11 +966,16 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
     // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
     const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
-    const Real *Hr = PairTabs<Real>::hr(a);
-    auto h_load = [&](int n, int) -> C { // bin n of the output grid <- bin n or n + NA - NB of the input grid, times (real) H
+    auto h_load = [&](int n, int t) -> C { // bin n of the output grid <- bin n or n + NA - NB of the input grid, times (real) H
         const bool neg = n > NB / 2;
         const int q = neg ? NB - n : n; // |frequency| in bins
+#ifdef FFT_EARLY_TABLES
+        const Real h = hpre[t];
+        (void)q;
+#else
         const Real h = Hr[q];
+        (void)t;
+#endif
         if constexpr (NA >= NB) {
             const C x = cur[neg ? n + (NA - NB) : n];
             return C(x.x * h, x.y * h); // (the Nyquist bin's alias term is dropped with Im H: stop band, < -170 dB)
@@ -914,6 +991,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
             stage[n - v0 + sh + hop_out] = (IO)w.y;
         }
     });
+    staged();
     __syncthreads();
     FFT_STAMP();
 
@@ -926,12 +1004,14 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     // 10.85 us on the 60 s clip against per-granule bounds tests and pointer stores, nothing on the batch).  The
     // first granule's sh leading elements belong to the previous run: that one granule goes element by element.
     {
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(ybase - sh), 0, (valid + sh) * ES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((void *)(ybase - sh)), 0,
+                                                                             __builtin_amdgcn_readfirstlane((valid + sh) * ES), 0x00020000);
         constexpr int QMAX = (2 * (NB - 1) + EPS - 1 + EPS) / EPS; // 2 hop_out < 2 NB elements, + sh
         constexpr int LQ = (int)((NA > NB ? NA : NB) * sizeof(C) / 16); // 16-byte granules of the LDS buffer
+        const int tid_out = fft_tid();
 #pragma unroll
         for (int it = 0; it < (QMAX + NT - 1) / NT; ++it) {
-            const int q = (int)threadIdx.x + it * NT;
+            const int q = tid_out + it * NT;
             const V16 v = *reinterpret_cast<const V16 *>(stage + EPS * (q < LQ ? q : LQ - 1));
 #if defined(FFT2_ABL) && (FFT2_ABL & 4)
             if (v.x != (IO)1234.5) continue;
@@ -954,6 +1034,60 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
     g_tri = 15;
     FFT_STAMP();
 #endif
+    return true;
+}
+
+template <typename Spec, typename Real, typename IO = Real>
+__global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    pair2_item<Spec, Real, IO>(a, smem_raw, blockIdx.y, blockIdx.x, [] {});
+}
+
+// The same work items served by RESIDENT workgroups (round 3 experiment, opt-in: HIPSOXR_FFT_PERSIST; slower than the
+// grid-per-item kernel, see launch_fft).  A per-CU timeline of the grid-per-item kernel on the
+// batch workload (tools/trace_pair2.py) showed a CU holding 3.1 of its 4 workgroup slots on average: a freed slot
+// waits a median of 1500 cycles, 8700 at the 90th percentile, for the dispatcher's next workgroup, every workgroup
+// re-reads its arguments, and the launch ends with a drain of one whole workgroup lifetime.  Here the grid is what the
+// chip holds (launcher: LDS-limited workgroups per CU x CUs) and every workgroup pulls items from a queue: its first
+// item is its own id, every further one comes from one device-scope atomicAdd, asked for by thread 0 at the START of
+// the item it precedes (the round trip hides behind the transforms) and published to the others through the top word
+// of the LDS buffer, which is free once the run has been staged.  Items are (column, pair) in column-major order, so a
+// workgroup's consecutive items are neighbours in memory more often than not.  The last workgroup out resets the queue
+// (the next launch on the same HIP stream finds it zeroed; queues are per stream: launch_fft).
+template <typename Spec, typename Real, typename IO = Real>
+__global__ void __launch_bounds__(Spec::NT) k_fft_pair2p(FftArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr size_t LDS = (size_t)(Spec::NA > Spec::NB ? Spec::NA : Spec::NB) * sizeof(typename PairTabs<Real>::C);
+    uint32_t *top = reinterpret_cast<uint32_t *>(smem_raw) + (LDS / 4 - 2);
+    const uint32_t n_items = a.n_items;
+    uint32_t item = blockIdx.x;
+    while (item < n_items) {
+        uint32_t nxt = 0;
+        if (threadIdx.x == 0) nxt = gridDim.x + atomicAdd(a.queue, 1u);
+        // (the arguments through an opaque pointer to the kernel-argument segment: read inside the loop, they are
+        //  forty scalar loads per item; hoisted out of it, forty SGPRs held across it — 101 in all, and at 97-112 SGPRs
+        //  the hardware admits one workgroup per CU fewer than the occupancy query answers, MI355X guide)
+        typedef const FftArgs __attribute__((address_space(4))) *KArgs; // (typed as constant memory: scalar loads)
+        KArgs kc = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kc));
+        const FftArgs *ka = (const FftArgs *)kc;
+        const uint32_t ppc = (uint32_t)ka->pairs_per_col;
+        const uint32_t col = __builtin_amdgcn_readfirstlane(item / ppc), bx = __builtin_amdgcn_readfirstlane(item % ppc);
+        const bool did = pair2_item<Spec, Real, IO>(*ka, smem_raw, col, (int64_t)bx, [top, nxt] { if (threadIdx.x == 0) *top = nxt; });
+        if (!did) { // (uniform: an item beyond its clip's last pair)
+            if (threadIdx.x == 0) *top = nxt;
+            __syncthreads();
+        }
+        item = __builtin_amdgcn_readfirstlane(*top);
+        __syncthreads(); // the staged run and the top word have been read: the next item's first pass may store
+    }
+    if (threadIdx.x == 0 && atomicAdd(a.queue + 1, 1u) == gridDim.x - 1) { // last one out
+        a.queue[1] = 0;
+        __threadfence();
+        a.queue[0] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1135,6 +1269,27 @@ static bool factor_radices(int n, std::vector<int> &rad)
 static std::mutex g_fft_mu;
 static std::vector<std::pair<std::pair<const Plan *, int>, FftGeom>> g_fft; // key: (plan, geometry variant)
 
+// Work queues of the resident-workgroup kernel: two zeroed words per (device, HIP stream).  Launches on one stream run
+// one after the other and the last workgroup of each re-zeroes the words, so one queue per stream is enough; launches
+// on different streams may overlap and never share one.  (A stream handle recycled by the runtime finds its words
+// zeroed.)  Never freed: 8 bytes per stream the process has launched on.
+static std::mutex g_queue_mu;
+static std::vector<std::pair<std::pair<int, void *>, uint32_t *>> g_queues;
+static const char *fft_queue_for(void *stream, uint32_t **out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_queue_mu);
+    for (auto &e : g_queues)
+        if (e.first.first == dev && e.first.second == stream) { *out = e.second; return nullptr; }
+    uint32_t *q = nullptr;
+    HIP_TRY(hipMalloc((void **)&q, 16));
+    HIP_TRY(hipMemset(q, 0, 16));
+    g_queues.push_back({{dev, stream}, q});
+    *out = q;
+    return nullptr;
+}
+
 void fft_release(const Plan *p)
 {
     std::lock_guard<std::mutex> lk(g_fft_mu);
@@ -1265,18 +1420,20 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         int64_t L, M; int k; int small; /* 0: full-size blocks, 1: half-size (small jobs), 2: quarter-size (smaller still) */
         void (*kern)(FftArgs); unsigned nt; void (*kern2)(FftArgs); void (*kern2d)(FftArgs);
         void (*kern2fd)(FftArgs);                    // float32 I/O on float64 arithmetic (HIPSOXR_KERNEL_FFT_F64)
+        void (*kern2p)(FftArgs);                     // float32, resident workgroups pulling items from a queue (large jobs)
         void (*kcp)(FftArgs); void (*kcpd)(FftArgs); // channel-pair mode (interleaved data), float32 / float64
         void (*kst)(FftArgs); void (*kstd)(FftArgs); // strided columns, two blocks per transform
     };
 // (the first-generation kernel is instantiated only where the A/B tools use it — the 44.1k <-> 48k and 44.1k <-> 16k
 //  families: HIPSOXR_PAIR_V1; elsewhere a job the second-generation kernels cannot take goes to k_fft_block)
-#define HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, V1) \
+#define HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, V1, P2P) \
     {L, M, k, small, V1, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>, \
-     k_fft_pair2<PairOf<NA, NB, NT>, double, float>, \
+     k_fft_pair2<PairOf<NA, NB, NT>, double, float>, P2P, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, true>, k_fft_strided2<PairOf<NA, NB, NT>, double, true>, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>}
-#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, nullptr)
-#define HIPSOXR_PAIR_V1(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, (k_fft_pair<PairOf<NA, NB, NT>>))
+// (the first-generation kernel and the resident-workgroup experiment k_fft_pair2p exist for these families only)
+#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, nullptr, nullptr)
+#define HIPSOXR_PAIR_V1(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, (k_fft_pair<PairOf<NA, NB, NT>>), (k_fft_pair2p<PairOf<NA, NB, NT>, float>))
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
         HIPSOXR_PAIR_V1(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR_V1(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
@@ -1354,7 +1511,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             // tables on the first-generation kernel (7.1 vs 9.0 us for one workgroup).  Against the second-generation
             // three-pass kernel it no longer wins anywhere (0.5 s .. 20 s clips: equal within 0.2 us; 30 s: 10.6 vs
             // 9.4 us): kept behind HIPSOXR_FFT_SMALL_4PASS for A/B only.
-            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && switches().fft_small_4pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
                 if (wgs < 400 && !f64) use = &low_latency;
@@ -1423,10 +1580,44 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }
                 if (wide32 && !v2ok) return nullptr; // (float32 on float64 arithmetic: unit-stride columns only)
+                dim3 launch_grid = grid;
+                a.queue = nullptr; a.n_items = 0;
                 if (v2ok && (f64 || !switches().fft_pair_v1)) {
                     kern = io64 ? use->kern2d : wide32 ? use->kern2fd : use->kern2;
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    // HIPSOXR_FFT_PERSIST (experiment, measured in round 3 and NOT the default): resident workgroups pulling
+                    // items from a queue (k_fft_pair2p).  Four workgroups per CU for the whole launch instead of the 3.1 the
+                    // dispatcher sustains — and 7 % SLOWER on the batch (140.5 vs 130.8 us per launch, same box): a CU's
+                    // throughput does not grow with its fourth resident workgroup.  DESIGN.md §5.2.
+                    const int64_t n_items = (int64_t)grid.x * grid.y;
+                    if (!f64 && use->kern2p && switches().fft_persist && !switches().dbg_trace && n_items <= 0x7fffffffLL &&
+                        (2 * (size_t)g.hop_out + 4) * esz + 24 <= lds) {
+                        static std::mutex occ_mu;
+                        static std::vector<std::pair<const void *, int>> occ_cache; // (kernel, workgroups per CU) — per process, one device type
+                        int per_cu = 0, cus = 0, dev = 0;
+                        {
+                            std::lock_guard<std::mutex> lk(occ_mu);
+                            for (auto &e : occ_cache) if (e.first == (const void *)use->kern2p) per_cu = e.second;
+                            if (!per_cu) {
+                                if (lds > 64 * 1024)
+                                    HIP_TRY(hipFuncSetAttribute((const void *)use->kern2p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)use->kern2p, (int)use->nt, lds));
+                                if (per_cu < 1) per_cu = 1;
+                                occ_cache.push_back({(const void *)use->kern2p, per_cu});
+                            }
+                        }
+                        HIP_TRY(hipGetDevice(&dev));
+                        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                        const int64_t slots = (int64_t)per_cu * cus;
+                        if (n_items >= 1) {
+                            if (const char *err = fft_queue_for(stream, &a.queue)) return err;
+                            a.n_items = (uint32_t)n_items;
+                            a.pairs_per_col = grid.x;
+                            launch_grid = dim3((unsigned)std::min<int64_t>(n_items, slots), 1, 1);
+                            kern = use->kern2p;
+                        }
+                    }
                 }
                 // ragged batches: the unit-stride second-generation kernel reads its clip's row; nothing else does
                 if (j.clip_table && !(v2ok && (f64 || !switches().fft_pair_v1))) return nullptr;
@@ -1439,7 +1630,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     HIP_TRY(hipMemset(a.trace, 0, trace_n * 8));
                 }
 #endif
-                hipLaunchKernelGGL(kern, grid, dim3(use->nt), lds, (hipStream_t)stream, a);
+                hipLaunchKernelGGL(kern, launch_grid, dim3(use->nt), lds, (hipStream_t)stream, a);
                 HIP_TRY(hipGetLastError());
 #ifdef FFT2_TRACE
                 if (a.trace) { // debugging aid only: synchronous dump of the per-wave time stamps
@@ -1473,7 +1664,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
     a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
-    a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr; a.clip_tab = nullptr;
+    a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr; a.clip_tab = nullptr; a.queue = nullptr; a.n_items = 0;
     a.A = g.A; a.B = g.B; a.nA = g.nA; a.nB = g.nB;
     for (int i = 0; i < 8; ++i) { a.radA[i] = g.radA[i]; a.radB[i] = g.radB[i]; }
     a.L = p->L; a.M = p->M;

@@ -96,7 +96,9 @@ class RaggedJob:
     `[total_frames, channels]`, the per-clip table of `hipsoxr_job_t::clip_table` built once (host and device copy),
     `launch()` = one C call.  `outputs()` returns per-clip views of the packed result."""
 
-    def __init__(self, plan, clips, kernel=_n.KERNEL_AUTO, stream=None):
+    def __init__(self, plan, clips, kernel=_n.KERNEL_AUTO, stream=None, dither=None):
+        """dither: TPDF dither on int16 output (None = on for int16, as `soxr_amd.resample` and libsoxr do; keyed by
+        channel and output index within each clip, so a clip's result does not depend on its neighbours)."""
         import torch
         if not clips:
             raise ValueError("no clips")
@@ -122,6 +124,8 @@ class RaggedJob:
         j.out_frame_stride, j.out_chan_stride = ch, 1
         j.in_abs0, j.in_frames, j.out_k0, j.out_frames = 0, max(n_in), 0, max(n_out)
         j.clip_table, j.clip_table_dev = self._table.ctypes.data, self._table_dev.data_ptr()
+        j.dither = int(self.x.dtype == torch.int16 if dither is None else bool(dither))
+        j.dither_seed = 0
         self._job, self._ref, self._plan = j, _C.byref(j), plan
         self._stream = stream if stream is not None else torch.cuda.current_stream(device).cuda_stream
         self._any = max(n_out) > 0
