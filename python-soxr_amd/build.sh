@@ -25,13 +25,14 @@ mkdir -p "$OBJ"
 "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/engine.cpp" -o "$OBJ/engine.o" & P2=$!
 "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/kernels.hip" -o "$OBJ/kernels.o" & P3=$!
 "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/soxr_abi.cpp" -o "$OBJ/soxr_abi.o" & P5=$!
-# (fft.hip in two translation units: see "Two translation units" there)
+# (fft.hip in three translation units: see "Three translation units" there)
 # (-disable-machine-licm: see fft_tid() in fft.hip — the resident-workgroup kernel's loop body must keep its literals inside the loop)
 FFTFLAGS="-ffp-contract=fast -fno-slp-vectorize -mllvm -disable-machine-licm"
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=0 -c "$SRC/fft.hip" -o "$OBJ/fft.o" & P4=$!
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=1 -c "$SRC/fft.hip" -o "$OBJ/fft1.o" & P6=$!
-wait $P1; wait $P2; wait $P3; wait $P4; wait $P5; wait $P6   # set -e: any failed compile aborts here
-OBJS="$OBJ/plan.o $OBJ/engine.o $OBJ/kernels.o $OBJ/fft.o $OBJ/fft1.o $OBJ/soxr_abi.o"
+"$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=2 -c "$SRC/fft.hip" -o "$OBJ/fft2.o" & P7=$!
+wait $P1; wait $P2; wait $P3; wait $P4; wait $P5; wait $P6; wait $P7   # set -e: any failed compile aborts here
+OBJS="$OBJ/plan.o $OBJ/engine.o $OBJ/kernels.o $OBJ/fft.o $OBJ/fft1.o $OBJ/fft2.o $OBJ/soxr_abi.o"
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT"
 # The same engine under libsoxr's name: what `find_library(SOXR_LIBRARY NAMES soxr)` of the
 # reference's USE_SYSTEM_LIBSOXR build picks up (reference CMakeLists.txt:83-93).

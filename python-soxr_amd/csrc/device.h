@@ -78,6 +78,7 @@ struct Switches {
     bool fft_small_4pass = false; // HIPSOXR_FFT_SMALL_4PASS  small 48k->44.1k jobs on round 1's four-pass low-latency schedule (first-generation kernel)
     bool fft_pair_v1 = false;     // HIPSOXR_FFT_PAIR_V1      unit-stride jobs on k_fft_pair instead of k_fft_pair2
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
+    bool no_mfma64 = false;       // HIPSOXR_NO_MFMA64        float64 engine (float64 / int32 I/O) on the vector ALU (k_tile) instead of v_mfma_f64
     bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
     bool no_done_words = false;   // HIPSOXR_NO_DONE_WORDS    streaming calls wait on an event, not on the kernel's completion words
@@ -93,7 +94,9 @@ struct Switches {
     int dbg_nrt = 0, dbg_nw = 0;  // HIPSOXR_DEBUG_NRT / _NW  tiles / waves per workgroup
     int dbg_split = 0;            // HIPSOXR_DEBUG_SPLIT      grid.z unit split
     int dbg_chain_no = 0;         // HIPSOXR_DEBUG_CHAIN_NO   outputs per workgroup of k_chain (power of two <= 32)
+    int dbg_stagger = 0;          // HIPSOXR_DEBUG_STAGGER    k_fft_pair2p: start offset in cycles between the workgroup slots of a CU
     size_t dbg_lds = 0;           // HIPSOXR_DEBUG_LDS        extra dynamic LDS (occupancy experiments)
+    size_t dbg_mfma64_lds = 0;    // HIPSOXR_DEBUG_MFMA64_LDS LDS budget (bytes) that picks the float64 MFMA kernel's slab: 64, 32 or 16 periods
     size_t dbg_fft_lds = 0;       // HIPSOXR_DEBUG_FFT_LDS    the same for k_fft_block
     const char *dbg_trace = nullptr; // HIPSOXR_DEBUG_TRACE   path for per-wave s_memtime stamps (k_tile_mfma_p)
 };

@@ -463,6 +463,7 @@ struct FftArgs {
     int64_t in_frames, out_frames;
     uint32_t *queue;         // k_fft_pair2p: {items handed out beyond the grid's own, workgroups that have left}, zero between launches
     uint32_t n_items;        // k_fft_pair2p: columns x pairs_per_col
+    int32_t stagger;         // k_fft_pair2p: HIPSOXR_DEBUG_STAGGER
     const int64_t *clip_tab; // ragged batch (hipsoxr_job_t::clip_table_dev): [n_clips][4] = in offset, in frames, out offset, out frames; k_fft_pair2 only
     int32_t chpair; // paired kernel: 1 = pair neighbouring channels of interleaved data instead of blocks
     int64_t pairs_per_col; // xcd_map: work items (blocks, or pairs of blocks) per channel unit
@@ -1063,6 +1064,13 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_pair2p(FftArgs a)
     uint32_t *top = reinterpret_cast<uint32_t *>(smem_raw) + (LDS / 4 - 2);
     const uint32_t n_items = a.n_items;
     uint32_t item = blockIdx.x;
+    // Phase stagger (HIPSOXR_DEBUG_STAGGER, cycles): resident workgroups all start at once and, with items of equal
+    // cost, stay in step for the whole launch — every workgroup of a CU loads at the same time, then computes at the same
+    // time.  Workgroup b waits (b / CUs) * stagger cycles once, so that a CU's slots run a fraction of an item apart.
+    if (a.stagger) {
+        const long long until = __builtin_amdgcn_s_memtime() + (long long)(blockIdx.x >> 8) * a.stagger;
+        while ((long long)__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
     while (item < n_items) {
         uint32_t nxt = 0;
         if (threadIdx.x == 0) nxt = gridDim.x + atomicAdd(a.queue, 1u);
@@ -1212,12 +1220,14 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two translation units.  Every schedule of the table below is 6 kernels (k_fft_pair2 and k_fft_strided2 x 2, each in
-// float32 and float64); compiled in one piece they are the build's critical path (4 minutes).  build.sh compiles this
-// file twice: -DFFT_PART=0 = everything except the kernels of the schedules listed here (declared extern), and
-// -DFFT_PART=1 = the templates above plus exactly those kernels, no host code.  Without FFT_PART: one piece.
+// Three translation units.  Every schedule of the table below is 7 kernels (k_fft_pair2 in float32, float64 and
+// float32-on-float64, k_fft_strided2 x 2 in float32 and float64); compiled in one piece they are the build's critical
+// path (5 minutes).  build.sh compiles this file three times: -DFFT_PART=0 = everything except the kernels of the
+// schedules listed here (declared extern), -DFFT_PART=1 / =2 = the templates above plus exactly the kernels of one of
+// the two lists, no host code.  Without FFT_PART: one piece.
 // ---------------------------------------------------------------------------------------------
-#define HIPSOXR_PART1_SPECS(X) X(4096, 2048, 256) X(2048, 4096, 256) X(2048, 1024, 256) X(1024, 2048, 256) X(5376, 1792, 384) X(1792, 5376, 384) X(5376, 3584, 384) X(3584, 5376, 384) X(2688, 896, 384) X(896, 2688, 384) X(2688, 1792, 384) X(1792, 2688, 384) X(5120, 1280, 320) X(1280, 5120, 320) X(5376, 896, 384) X(896, 5376, 384) X(7056, 5120, 448) X(5120, 7056, 448) X(4704, 2560, 384) X(2560, 4704, 384) X(5120, 2352, 384) X(2352, 5120, 384) X(7056, 1280, 448) X(1280, 7056, 448) X(5120, 1176, 320) X(1176, 5120, 320) X(3528, 5120, 384) X(5120, 3528, 384) X(4704, 1280, 384) X(1280, 4704, 384) X(3840, 5120, 384) X(5120, 3840, 384)
+#define HIPSOXR_PART1_SPECS(X) X(4096, 2048, 256) X(2048, 4096, 256) X(2048, 1024, 256) X(1024, 2048, 256) X(5376, 1792, 384) X(1792, 5376, 384) X(5376, 3584, 384) X(3584, 5376, 384) X(2688, 896, 384) X(896, 2688, 384) X(2688, 1792, 384) X(1792, 2688, 384) X(5120, 1280, 320) X(1280, 5120, 320) X(5376, 896, 384) X(896, 5376, 384)
+#define HIPSOXR_PART2_SPECS(X) X(7056, 5120, 448) X(5120, 7056, 448) X(4704, 2560, 384) X(2560, 4704, 384) X(5120, 2352, 384) X(2352, 5120, 384) X(7056, 1280, 448) X(1280, 7056, 448) X(5120, 1176, 320) X(1176, 5120, 320) X(3528, 5120, 384) X(5120, 3528, 384) X(4704, 1280, 384) X(1280, 4704, 384) X(3840, 5120, 384) X(5120, 3840, 384)
 #define HIPSOXR_INST(NA, NB, NT)                                                                        \
     HIPSOXR_EXTERN template __global__ void k_fft_pair2<PairOf<NA, NB, NT>, float>(FftArgs);             \
     HIPSOXR_EXTERN template __global__ void k_fft_pair2<PairOf<NA, NB, NT>, double>(FftArgs);            \
@@ -1229,12 +1239,16 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
 #if defined(FFT_PART) && FFT_PART == 0
 #define HIPSOXR_EXTERN extern
 HIPSOXR_PART1_SPECS(HIPSOXR_INST)
+HIPSOXR_PART2_SPECS(HIPSOXR_INST)
 #elif defined(FFT_PART) && FFT_PART == 1
 #define HIPSOXR_EXTERN
 HIPSOXR_PART1_SPECS(HIPSOXR_INST)
+#elif defined(FFT_PART) && FFT_PART == 2
+#define HIPSOXR_EXTERN
+HIPSOXR_PART2_SPECS(HIPSOXR_INST)
 #endif
 
-#if !defined(FFT_PART) || FFT_PART != 1
+#if !defined(FFT_PART) || FFT_PART == 0
 // ---------------------------------------------------------------------------------------------
 // host: geometry, tables
 // ---------------------------------------------------------------------------------------------
@@ -1581,7 +1595,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 }
                 if (wide32 && !v2ok) return nullptr; // (float32 on float64 arithmetic: unit-stride columns only)
                 dim3 launch_grid = grid;
-                a.queue = nullptr; a.n_items = 0;
+                a.queue = nullptr; a.n_items = 0; a.stagger = switches().dbg_stagger;
                 if (v2ok && (f64 || !switches().fft_pair_v1)) {
                     kern = io64 ? use->kern2d : wide32 ? use->kern2fd : use->kern2;
                     if (lds > 64 * 1024)
@@ -1664,7 +1678,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
     a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
-    a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr; a.clip_tab = nullptr; a.queue = nullptr; a.n_items = 0;
+    a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr; a.clip_tab = nullptr; a.queue = nullptr; a.n_items = 0; a.stagger = 0;
     a.A = g.A; a.B = g.B; a.nA = g.nA; a.nB = g.nB;
     for (int i = 0; i < 8; ++i) { a.radA[i] = g.radA[i]; a.radB[i] = g.radB[i]; }
     a.L = p->L; a.M = p->M;

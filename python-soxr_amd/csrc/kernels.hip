@@ -61,8 +61,8 @@ const Switches &switches()
         w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_persist = on("HIPSOXR_FFT_PERSIST"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY"); w.fft_small_4pass = on("HIPSOXR_FFT_SMALL_4PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
-        w.no_planes = on("HIPSOXR_NO_PLANES");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.no_auto_resident = on("HIPSOXR_NO_AUTO_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
+        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_stagger = num("HIPSOXR_DEBUG_STAGGER"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.no_auto_resident = on("HIPSOXR_NO_AUTO_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
@@ -1180,12 +1180,30 @@ __global__ void __launch_bounds__(1024) k_tile(TileArgs a)
 // Operand layouts (16x16x4): A lane l = C'[row l&15][k = l>>4]; B lane l = x[period l&15][k = l>>4];
 // D lane l, reg v = D[row 4*(l>>4)+v][period l&15].
 // ---------------------------------------------------------------------------------------------
+// Real = double (round 3): the float64 engine (float64 / int32 I/O) on v_mfma_f64_16x16x4_f64.  The hardware evaluates it
+// as the same k-ordered fma chain, one rounding per product — bitwise equal to std::fma chains on 51 200 random elements
+// of 8 chained instructions (tools/ubench/mfma_f64_order.hip; the descending chain, pairwise sums and fma trees all
+// differ) — so the canonical order holds and the oracle's port_f64 is reproduced bit for bit.  Two differences from
+// the f32 form: the accumulator layout (lane l, register v = row (l >> 4) + 4 v, MI355X guide §3, where the f32 form
+// has row 4 (l >> 4) + v) and the slab (8 bytes per sample: NG = 4, 2 or 1 groups of 16 periods, whatever fits LDS).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <typename Real> struct MfmaOf;
+template <> struct MfmaOf<float> {
+    typedef f32x4 Acc;
+    static __device__ __forceinline__ Acc mac(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int kq, int v) { return 4 * kq + v; }
+};
+template <> struct MfmaOf<double> {
+    typedef f64x4 Acc;
+    static __device__ __forceinline__ Acc mac(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int kq, int v) { return kq + 4 * v; }
+};
 
-template <typename IO>
+template <typename IO, typename Real = float, int NG = 4>
 __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
 {
-    typedef float Real;
+    typedef typename MfmaOf<Real>::Acc Acc;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Real *xs = reinterpret_cast<Real *>(smem_raw);
 
@@ -1193,7 +1211,7 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
     // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
     // address derived from them) on the scalar side
     const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    const int64_t bw = a.b_first + (int64_t)blockIdx.x * 64;
+    const int64_t bw = a.b_first + (int64_t)blockIdx.x * (16 * NG);
     const int32_t Mc = (int32_t)a.Mc, pad = a.pad, S = Mc + pad;
 
     if (!(a.dbg & 1)) stage_slab<IO, Real, false>(a, xs, clip, ch, bw);
@@ -1206,7 +1224,7 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
     const int32_t n_chunks = a.I_h >> 2;
     const Real *xrow = xs + j * S; // period j of group 0; group g adds 16*g*S
 
-    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
+    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 16 * NG) * a.Lc <= a.out_k0 + a.out_frames;
     IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
 
     for (int rt_ = wave < n_waves ? wave + n_waves * (int)blockIdx.z : a.n_rt; rt_ < a.n_rt; rt_ += n_waves * (int)gridDim.z) { // (gridDim.z: see k_tile)
@@ -1216,9 +1234,9 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
         const size_t half_stride = (size_t)(a.I_h + 16) * 16; // + 4 chunks of prefetch slack
         const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane;
         const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane;
-        f32x4 accL[4], accR[4];
+        Acc accL[NG], accR[NG];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { accL[g] = (f32x4){0, 0, 0, 0}; accR[g] = (f32x4){0, 0, 0, 0}; }
+        for (int g = 0; g < NG; ++g) { accL[g] = (Acc){0, 0, 0, 0}; accR[g] = (Acc){0, 0, 0, 0}; }
 
         // The coefficient operand of the next group of G chunks is fetched into registers while
         // the current group's 4*G MFMAs run (one VGPR per chunk).  The prefetch pointer is made
@@ -1236,18 +1254,16 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
                 poff += G * 64;
                 asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
 #pragma unroll
-                for (int u = 0; u < G; ++u) an[u] = (a.dbg & 4) ? 1.0f : tL[poff + u * 64];
+                for (int u = 0; u < G; ++u) an[u] = (a.dbg & 4) ? (Real)1 : tL[poff + u * 64];
                 __builtin_amdgcn_sched_barrier(0); // the prefetch is issued BEFORE this group's MFMAs
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const Real *px = xrow + off;
-                    Real b0, b1, b2, b3;
-                    if (a.dbg & 2) { b0 = b1 = b2 = b3 = ac[u]; }
-                    else { b0 = px[0]; b1 = px[16 * S]; b2 = px[32 * S]; b3 = px[48 * S]; }
-                    accL[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b0, accL[0], 0, 0, 0);
-                    accL[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b1, accL[1], 0, 0, 0);
-                    accL[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b2, accL[2], 0, 0, 0);
-                    accL[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b3, accL[3], 0, 0, 0);
+                    Real b[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) b[g] = (a.dbg & 2) ? ac[u] : px[16 * g * S];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) accL[g] = MfmaOf<Real>::mac(ac[u], b[g], accL[g]);
                     e += 4; off += 4;
                     if (e >= next) { off += pad; next += Mc; }
                 }
@@ -1268,18 +1284,16 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
                 poff += G * 64;
                 asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
 #pragma unroll
-                for (int u = 0; u < G; ++u) an[u] = (a.dbg & 4) ? 1.0f : tR[poff + u * 64];
+                for (int u = 0; u < G; ++u) an[u] = (a.dbg & 4) ? (Real)1 : tR[poff + u * 64];
                 __builtin_amdgcn_sched_barrier(0); // the prefetch is issued BEFORE this group's MFMAs
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const Real *px = xrow + off;
-                    Real b0, b1, b2, b3;
-                    if (a.dbg & 2) { b0 = b1 = b2 = b3 = ac[u]; }
-                    else { b0 = px[0]; b1 = px[16 * S]; b2 = px[32 * S]; b3 = px[48 * S]; }
-                    accR[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b0, accR[0], 0, 0, 0);
-                    accR[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b1, accR[1], 0, 0, 0);
-                    accR[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b2, accR[2], 0, 0, 0);
-                    accR[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b3, accR[3], 0, 0, 0);
+                    Real b[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) b[g] = (a.dbg & 2) ? ac[u] : px[16 * g * S];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) accR[g] = MfmaOf<Real>::mac(ac[u], b[g], accR[g]);
                     e -= 4; off -= 4;
                     if (e < lo) { off -= pad; lo -= Mc; }
                 }
@@ -1287,24 +1301,27 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
                 for (int u = 0; u < G; ++u) ac[u] = an[u];
             }
         }
-        // lane holds rows r0 + 4*kq + v (v = 0..3) of periods bw + 16g + j
-        const int32_t r0 = rt * 16 + 4 * kq;
-        if ((a.dbg & 8) && accL[0][0] != 12345.f) continue;
+        // lane holds rows rt*16 + row(kq, v) (v = 0..3; f32: 4 kq + v, f64: kq + 4 v) of periods bw + 16g + j
+        const int32_t rbase = rt * 16;
+        if ((a.dbg & 8) && accL[0][0] != (Real)12345) continue;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NG; ++g) {
             const int64_t b = bw + 16 * g + j;
-            const int64_t k0 = b * a.Lc + r0;
-            IO *const yt = ybase + (k0 - a.out_k0) * a.ofs;
-            if (interior && r0 + 4 <= a.Lc) {
+            const int64_t kb = b * a.Lc + rbase;
+            IO *const yt = ybase + (kb - a.out_k0) * a.ofs;
+            if (interior && rbase + 16 <= a.Lc) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    store_out<Real>(yt + v * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, k0 + v);
+                for (int v = 0; v < 4; ++v) {
+                    const int r = MfmaOf<Real>::row(kq, v);
+                    store_out<Real>(yt + r * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, kb + r);
+                }
             } else {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int64_t idx = k0 + v - a.out_k0;
-                    if (r0 + v < a.Lc && idx >= 0 && idx < a.out_frames)
-                        store_out<Real>(yt + v * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, k0 + v);
+                    const int r = MfmaOf<Real>::row(kq, v);
+                    const int64_t idx = kb + r - a.out_k0;
+                    if (rbase + r < a.Lc && idx >= 0 && idx < a.out_frames)
+                        store_out<Real>(yt + r * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, kb + r);
                 }
             }
         }
@@ -1731,7 +1748,13 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab, int var
     for (;;) {
         g.x_count = ((g.pb - 1) * Mc + (i_max - i_min + 1) + 3) / 4 * 4; // whole quads ((pb-1)*Mc may be odd)
         g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / Mc + 1) + 8) * sizeof(Real);
-        if (g.lds_bytes <= 160 * 1024 || variant != 0 || g.pb == 16) break;
+        // (variant 1 in float64 — k_tile_mfma<IO, double, NG> — runs NG = pb / 16 groups of 16 periods: 4, 2 or 1)
+        // Slab of the float64 MFMA kernel: a 64-period slab only when small (two or more workgroups per CU must fit: a lone
+        // workgroup cannot hide its own staging — 48k -> 44.1k int32 60 s: 105 us on 83 KB slabs, 90 us on 42 KB ones),
+        // else 32 periods up to 120 KB (44.1k -> 16k: 72 us on 116 KB against 84 us on 59 KB), else 16.
+        const size_t limit = (variant == 1 && sizeof(Real) == 8)
+                                 ? (switches().dbg_mfma64_lds ? switches().dbg_mfma64_lds : g.pb == 64 ? 48 * 1024 : 120 * 1024) : 160 * 1024;
+        if (g.lds_bytes <= limit || (variant != 0 && sizeof(Real) == 4) || g.pb == 16) break;
         g.pb /= 2;
     }
     g.e0.resize((size_t)g.n_rt * 2);
@@ -1793,6 +1816,17 @@ static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out, TileG
         d.RT = g.RT; d.n_rt = g.n_rt; d.I_h = g.I_h;
     }
     *geom_out = g;
+    if (sizeof(Real) == 8 && geom_m_out && !switches().no_mfma64) { // float64 engine on v_mfma_f64_16x16x4_f64 (k_tile_mfma<IO, double, NG>)
+        std::vector<Real> tabm;
+        TileGeom gm = build_tile_tables<Real>(*p, &tabm, 1);
+        if (gm.ok) {
+            HIP_TRY(hipMalloc(&d.tile_tab_m, tabm.size() * sizeof(Real)));
+            HIP_TRY(hipMemcpy(d.tile_tab_m, tabm.data(), tabm.size() * sizeof(Real), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void **)&d.tile_i0_m, gm.e0.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy(d.tile_i0_m, gm.e0.data(), gm.e0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        *geom_m_out = gm;
+    }
     if (sizeof(Real) == 4 && geom_m_out) {
         std::vector<float> tabm;
         TileGeom gm = build_mfma_planes(*p, &tabm);
@@ -1830,7 +1864,7 @@ const char *device_bank_ensure(Plan *p, int prec)
     if (device_count() <= 0) return "no HIP device available (hipsoxr has no CPU fallback)";
     if (p->device < 0 && hipGetDevice(&cur) == hipSuccess) p->device = cur; // tables are built on first use, here
     TileGeom g, gm;
-    const char *e = prec == 0 ? bank_upload<float>(p, d, &g, &gm) : bank_upload<double>(p, d, &g, nullptr);
+    const char *e = prec == 0 ? bank_upload<float>(p, d, &g, &gm) : bank_upload<double>(p, d, &g, &gm);
     if (e) return e;
     {
         std::lock_guard<std::mutex> lk2(g_geom_mu);
@@ -2129,6 +2163,8 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     if constexpr (sizeof(Real) == 4) {
         if (g.variant == 1) kern = k_tile_mfma<IO>;
         if (g.variant == 2) kern = k_tile_mfma_p<IO>;
+    } else {
+        if (g.variant == 1) kern = g.pb == 64 ? k_tile_mfma<IO, double, 4> : g.pb == 32 ? k_tile_mfma<IO, double, 2> : k_tile_mfma<IO, double, 1>;
     }
     a.rowR = g.rowR; a.plane = g.plane;
     dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
@@ -2228,7 +2264,7 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st,
 {
     if (res) return launch_gather<IO, Real>(p, j, st, vr, res);
     const int prec = sizeof(Real) == 4 ? 0 : 1;
-    TileGeom gv, gm; // VALU-tile and MFMA-tile geometries (the latter exists for the f32 engine only)
+    TileGeom gv, gm; // VALU-tile and MFMA-tile geometries (f32: planes / k_tile_mfma; f64: k_tile_mfma<IO, double, NG>)
     {
         std::lock_guard<std::mutex> lk(g_geom_mu);
         if (TileGeom *gp = geom_find(p, prec, 0)) gv = *gp;
