@@ -94,6 +94,7 @@ struct Switches {
     int dbg_nrt = 0, dbg_nw = 0;  // HIPSOXR_DEBUG_NRT / _NW  tiles / waves per workgroup
     int dbg_split = 0;            // HIPSOXR_DEBUG_SPLIT      grid.z unit split
     int dbg_chain_no = 0;         // HIPSOXR_DEBUG_CHAIN_NO   outputs per workgroup of k_chain (power of two <= 32)
+    int dbg_walk = 0;             // HIPSOXR_DEBUG_WALK       blocks walked per workgroup by the channel-pair kernel (1 = never walk; default 3 for large jobs)
     int dbg_stagger = 0;          // HIPSOXR_DEBUG_STAGGER    k_fft_pair2p: start offset in cycles between the workgroup slots of a CU
     size_t dbg_lds = 0;           // HIPSOXR_DEBUG_LDS        extra dynamic LDS (occupancy experiments)
     size_t dbg_mfma64_lds = 0;    // HIPSOXR_DEBUG_MFMA64_LDS LDS budget (bytes) that picks the float64 MFMA kernel's slab: 64, 32 or 16 periods

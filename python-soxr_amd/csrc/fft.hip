@@ -464,6 +464,8 @@ struct FftArgs {
     uint32_t *queue;         // k_fft_pair2p: {items handed out beyond the grid's own, workgroups that have left}, zero between launches
     uint32_t n_items;        // k_fft_pair2p: columns x pairs_per_col
     int32_t stagger;         // k_fft_pair2p: HIPSOXR_DEBUG_STAGGER
+    int32_t walk;            // k_fft_strided2<.., K > 0>: consecutive blocks per workgroup
+    int64_t n_blocks_col;    // ... blocks per column
     const int64_t *clip_tab; // ragged batch (hipsoxr_job_t::clip_table_dev): [n_clips][4] = in offset, in frames, out offset, out frames; k_fft_pair2 only
     int32_t chpair; // paired kernel: 1 = pair neighbouring channels of interleaved data instead of blocks
     int64_t pairs_per_col; // xcd_map: work items (blocks, or pairs of blocks) per channel unit
@@ -673,7 +675,7 @@ HIPSOXR_SCHED(7056, 21, 16, 21, false);
 HIPSOXR_SCHED(5376, 21, 16, 16, false);
 HIPSOXR_SCHED(5120, 16, 16, 20, true);
 HIPSOXR_SCHED(4704, 21, 16, 14, false);
-HIPSOXR_SCHED(4410, 21, 14, 15, false);
+HIPSOXR_SCHED(4410, 15, 14, 21, false); // (first radix 15: 4410 / 15 = 294 divides the 3528-frame hop of the 44.1k -> 16k blocks — k_fft_strided2's walk)
 HIPSOXR_SCHED(4096, 16, 16, 16, true);
 HIPSOXR_SCHED(3840, 16, 16, 15, true);
 HIPSOXR_SCHED(3584, 14, 16, 16, false);
@@ -1134,14 +1136,21 @@ template <> struct CpIo<double> {
 // CP = true: channel pairs (above).  CP = false: strided columns that cannot be paired by channel (odd channel counts
 // of interleaved data, a channel slice with a frame stride): two consecutive blocks of ONE column are paired, as in
 // k_fft_pair2, each element a 4/8-byte buffer load or store at the column's frame stride.
-template <typename Spec, typename Real, bool CP>
+// K > 0 (round 3, channel pairs): a workgroup WALKS a.walk consecutive blocks of its channel pair and keeps the K
+// butterfly inputs per thread that the next block shares with this one in registers.  Blocks overlap by N - hop input
+// frames (882 of 4410 at 44.1k -> 16k: every block re-read 25 % of its input, 1.19x the algorithmic traffic for the
+// whole job); when the first-pass butterfly stride N/R0 divides the hop (4410 = 15 * 294, hop 3528 = 12 * 294) the
+// next block's inputs t = 0 .. K-1 of thread j ARE this block's inputs R0-K .. R0-1 of the same thread, so the walk
+// costs 2 K registers and no LDS.  The launcher checks the geometry; K = 0 is the plain kernel.
+template <typename Spec, typename Real, bool CP, int K = 0>
 __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
 {
     typedef typename PairTabs<Real>::C C;
     constexpr int ES = (int)sizeof(Real);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C *cur = reinterpret_cast<C *>(smem_raw);
-    constexpr int NA = Spec::NA, NB = Spec::NB, nbA = NA / Spec::RA0;
+    constexpr int NA = Spec::NA, NB = Spec::NB, R0 = Spec::RA0, nbA = NA / R0;
+    static_assert(K == 0 || (CP && K < R0), "walking: channel-pair mode");
 #ifdef FFT2_TRACE
     unsigned long long *g_tr = nullptr;
     int g_tri = 0;
@@ -1153,33 +1162,49 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
     const bool xm = a.xcd_map != 0;
     const uint32_t cu = __builtin_amdgcn_readfirstlane(xm ? slot % units : blockIdx.y % units);
     const uint32_t clip = __builtin_amdgcn_readfirstlane(xm ? blockIdx.y : blockIdx.y / units);
-    const int64_t bx = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane(xm ? (slot / units) * 8 + xcd : blockIdx.x);
-    if (bx >= a.pairs_per_col) return; // grid.x is padded to a multiple of 8 items per unit
+    const int64_t item = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane(xm ? (slot / units) * 8 + xcd : blockIdx.x);
+    if (item >= a.pairs_per_col) return; // grid.x is padded to a multiple of 8 items per unit
     const uint32_t ch = CP ? 2 * cu : cu;
-    const int64_t pa = (CP ? 1 : 2) * bx * a.hop_periods - a.lead_periods; // first period of the (first) block
-    const int64_t ina = pa * a.M, outa = pa * a.L;
     const int32_t hop_in = (int32_t)(a.hop_periods * a.M), hop_out = a.hop_out;
     const Real *xin = (const Real *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
     const int32_t ifb = (int32_t)a.ifs * ES, ofb = (int32_t)a.ofs * ES; // bytes per frame (launcher: 2 N * frame < 2^30)
     auto lds_store = [&](int n, C v) { cur[n] = v; };
     typename Spec::Tw tw;
+    const Real *Hr = PairTabs<Real>::hr(a);
+    const int32_t v0 = a.v0, v1 = a.v0 + hop_out;
+    const int walk = K > 0 ? a.walk : 1;
+    C keep[K > 0 ? K : 1]; // this block's last K first-pass inputs = the next block's first K
+    for (int w = 0; w < walk; ++w) {
+    const int64_t bx = K > 0 ? item * walk + w : item;
+    if (K > 0 && bx >= a.n_blocks_col) break;
+    const int64_t pa = (CP ? 1 : 2) * bx * a.hop_periods - a.lead_periods; // first period of the (first) block
+    const int64_t ina = pa * a.M, outa = pa * a.L;
+    C nxt[K > 0 ? K : 1];
 
     // ---- forward: z[n] = x_c[n] + i x_{c+1}[n]  (CP)  or  x_a[n] + i x_b[n]  (two blocks), first pass straight from HBM
     if (ina >= 0) {
         const int64_t left = (a.in_frames - ina) * (int64_t)ifb; // bytes from the block's first frame to the end of the column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(xin + ina * a.ifs), 0, (int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left), 0x00020000);
+            uniform_ptr((void *)(xin + ina * a.ifs)), 0, __builtin_amdgcn_readfirstlane((int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left)), 0x00020000);
         const int32_t stepb = nbA * ifb; // one butterfly input further: N/R0 frames
         Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int t) -> C {
-            if constexpr (CP) return CpIo<Real>::load(rs, (n - t * nbA) * ifb, t * stepb);
+            if constexpr (CP) {
+                C v;
+                if (K > 0 && t < K && w > 0) v = keep[t < K ? t : 0];
+                else v = CpIo<Real>::load(rs, (n - t * nbA) * ifb, t * stepb);
+                if (K > 0 && t >= R0 - K) nxt[t >= R0 - K ? t - (R0 - K) : 0] = v;
+                return v;
+            }
             else return C(buf_load_real<Real>(rs, (n - t * nbA) * ifb, t * stepb), buf_load_real<Real>(rs, (n - t * nbA) * ifb, t * stepb + hop_in * ifb));
         }, lds_store, false, tw);
     } else { // the first block of a column reaches before its start: explicit zero-extension
-        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int) -> C {
+        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int t) -> C {
             const int64_t l = ina + n, lb = l + hop_in;
             if constexpr (CP) {
-                if (l < 0 || l >= a.in_frames) return C((Real)0, (Real)0);
-                return C(xin[l * a.ifs], xin[l * a.ifs + 1]);
+                C v = C((Real)0, (Real)0);
+                if (l >= 0 && l < a.in_frames) v = C(xin[l * a.ifs], xin[l * a.ifs + 1]);
+                if (K > 0 && t >= R0 - K) nxt[t >= R0 - K ? t - (R0 - K) : 0] = v;
+                return v;
             } else {
                 return C((l >= 0 && l < a.in_frames) ? xin[l * a.ifs] : (Real)0, (lb >= 0 && lb < a.in_frames) ? xin[lb * a.ifs] : (Real)0);
             }
@@ -1188,12 +1213,10 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
     __syncthreads();
 
     // ---- inverse (see k_fft_pair2), outputs straight to HBM -----------------------------------------
-    const int32_t v0 = a.v0, v1 = a.v0 + hop_out;
     Real *ybase = (Real *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0) * a.ofs; // outa + v0 >= 0
     const int64_t oleft = (a.out_frames - (outa + v0)) * (int64_t)ofb;
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)ybase, 0, (int)(oleft < 0 ? 0 : oleft > 0x40000000 ? 0x40000000 : oleft), 0x00020000);
-    const Real *Hr = PairTabs<Real>::hr(a);
+        uniform_ptr((void *)ybase), 0, __builtin_amdgcn_readfirstlane((int)(oleft < 0 ? 0 : oleft > 0x40000000 ? 0x40000000 : oleft)), 0x00020000);
     auto h_load = [&](int n, int) -> C {
         const bool neg = n > NB / 2;
         const int q = neg ? NB - n : n; // |frequency| in bins
@@ -1207,16 +1230,22 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
             return in_band ? C(x.x * h, x.y * h) : C((Real)0, (Real)0);
         }
     };
-    Spec::inv(FFT_STAMP_ARGS cur, PairTabs<Real>::wb(a), h_load, [&](int n, C w) {
+    Spec::inv(FFT_STAMP_ARGS cur, PairTabs<Real>::wb(a), h_load, [&](int n, C wv) {
         if (n >= v0 && n < v1) {
             if constexpr (CP) {
-                CpIo<Real>::store(w, ro, (n - v0) * ofb); // frame outa + n holds (y_c, y_{c+1})
+                CpIo<Real>::store(wv, ro, (n - v0) * ofb); // frame outa + n holds (y_c, y_{c+1})
             } else {
-                buf_store_real(w.x, ro, (n - v0) * ofb);             // block a
-                buf_store_real(w.y, ro, (n - v0 + hop_out) * ofb);   // block b: hop_out frames further
+                buf_store_real(wv.x, ro, (n - v0) * ofb);             // block a
+                buf_store_real(wv.y, ro, (n - v0 + hop_out) * ofb);   // block b: hop_out frames further
             }
         }
     }, true, tw);
+    if constexpr (K > 0) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) keep[i] = nxt[i];
+        __syncthreads(); // the last inverse pass has read the buffer: the next block's first pass may store into it
+    }
+    } // walk
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1416,6 +1445,13 @@ bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &j)
            j.out_k0 == 0 && (uint64_t)j.out_frames <= plan_out_len(p, (uint64_t)j.in_frames);
 }
 
+// the walking instance of the channel-pair kernel exists where the geometry admits it (k_fft_strided2, K > 0)
+template <int NA, int NB, int NT, typename Real> static constexpr void (*walk_kernel())(FftArgs)
+{
+    if constexpr (NA == 4410 && NB == 1600) return k_fft_strided2<PairOf<NA, NB, NT>, Real, true, 3>;
+    else return nullptr;
+}
+
 const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *handled)
 {
     *handled = false;
@@ -1437,6 +1473,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         void (*kern2p)(FftArgs);                     // float32, resident workgroups pulling items from a queue (large jobs)
         void (*kcp)(FftArgs); void (*kcpd)(FftArgs); // channel-pair mode (interleaved data), float32 / float64
         void (*kst)(FftArgs); void (*kstd)(FftArgs); // strided columns, two blocks per transform
+        void (*kcpw)(FftArgs); void (*kcpwd)(FftArgs); int walk_k; // channel pairs, walking (k_fft_strided2<.., K>): 44.1k -> 16k only
     };
 // (the first-generation kernel is instantiated only where the A/B tools use it — the 44.1k <-> 48k and 44.1k <-> 16k
 //  families: HIPSOXR_PAIR_V1; elsewhere a job the second-generation kernels cannot take goes to k_fft_block)
@@ -1444,7 +1481,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     {L, M, k, small, V1, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>, \
      k_fft_pair2<PairOf<NA, NB, NT>, double, float>, P2P, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, true>, k_fft_strided2<PairOf<NA, NB, NT>, double, true>, \
-     k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>}
+     k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>, \
+     walk_kernel<NA, NB, NT, float>(), walk_kernel<NA, NB, NT, double>(), (NA == 4410 && NB == 1600) ? 3 : 0}
 // (the first-generation kernel and the resident-workgroup experiment k_fft_pair2p exist for these families only)
 #define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, nullptr, nullptr)
 #define HIPSOXR_PAIR_V1(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, (k_fft_pair<PairOf<NA, NB, NT>>), (k_fft_pair2p<PairOf<NA, NB, NT>, float>))
@@ -1525,7 +1563,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             // tables on the first-generation kernel (7.1 vs 9.0 us for one workgroup).  Against the second-generation
             // three-pass kernel it no longer wins anywhere (0.5 s .. 20 s clips: equal within 0.2 us; 30 s: 10.6 vs
             // 9.4 us): kept behind HIPSOXR_FFT_SMALL_4PASS for A/B only.
-            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            static const PairEntry low_latency = {147, 160, 16, true, k_fft_pair<Pair2560x2352L>, Pair2560x2352L::NT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             if (use == sml && sml && sml->kern == (void (*)(FftArgs))k_fft_pair<Pair2560x2352> && switches().fft_small_4pass) {
                 const int64_t wgs = ((j.out_frames + g.hop_out - 1) / g.hop_out + 1) / 2 * (int64_t)cols_p;
                 if (wgs < 400 && !f64) use = &low_latency;
@@ -1588,13 +1626,31 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 const bool st2ok = !wide32 && !a.chpair && !v2ok && (f64 ? use->kstd : use->kst) != nullptr && !switches().fft_pair_v1 &&
                                    2 * (int64_t)std::max(g.N_in, g.N_out) * std::max(j.in_frame_stride, j.out_frame_stride) * (int64_t)esz < (1LL << 30);
                 if (f64 && !v2ok && !cp2ok && !st2ok) return nullptr; // (no float64 instance of the first-generation kernel: exact engine)
+                a.walk = 1; a.n_blocks_col = n_blocks;
+                unsigned launch_grid_x = 0; // (non-zero: the walking kernel's own item count)
                 if (cp2ok || st2ok) {
                     kern = cp2ok ? (f64 ? use->kcpd : use->kcp) : (f64 ? use->kstd : use->kst);
+                    // HIPSOXR_DEBUG_WALK=W (experiment, measured in round 3 and NOT the default): every workgroup of a channel
+                    // pair walks W consecutive blocks and keeps the shared input in registers (k_fft_strided2, K > 0): HBM reads
+                    // drop by the re-read share of the overlap, and configs[2] gets SLOWER — 47.0 us plain, 53.7 us at W = 3
+                    // (50.1 at 4, 57 at 2 and 6; same box): 81 instead of 61 VGPRs (five waves per SIMD instead of six) and a third
+                    // of the workgroups, three times as long.  The launch is not bound by HBM traffic.  DESIGN.md §5.2.
+                    void (*kw)(FftArgs) = f64 ? use->kcpwd : use->kcpw;
+                    const int radA0 = g.N_in == 4410 ? 15 : 0; // (first radix of the forward schedule the walking instance was built on)
+                    int want = switches().dbg_walk ? switches().dbg_walk : 1;
+                    if (cp2ok && kw && want > 1 && radA0 && (int64_t)use->walk_k * (g.N_in / radA0) == (int64_t)g.N_in - (int64_t)g.hop_periods * p->M) {
+                        kern = kw;
+                        a.walk = want;
+                        const int64_t witems = (n_blocks + want - 1) / want, witems8 = (witems + 7) / 8 * 8;
+                        a.pairs_per_col = witems;
+                        launch_grid_x = (unsigned)(witems8 * units);
+                    }
                     if (lds > 64 * 1024)
                         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 }
                 if (wide32 && !v2ok) return nullptr; // (float32 on float64 arithmetic: unit-stride columns only)
                 dim3 launch_grid = grid;
+                if (launch_grid_x) launch_grid.x = launch_grid_x;
                 a.queue = nullptr; a.n_items = 0; a.stagger = switches().dbg_stagger;
                 if (v2ok && (f64 || !switches().fft_pair_v1)) {
                     kern = io64 ? use->kern2d : wide32 ? use->kern2fd : use->kern2;
@@ -1679,6 +1735,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
     a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
     a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr; a.clip_tab = nullptr; a.queue = nullptr; a.n_items = 0; a.stagger = 0;
+    a.walk = 1; a.n_blocks_col = 0;
     a.A = g.A; a.B = g.B; a.nA = g.nA; a.nB = g.nB;
     for (int i = 0; i < 8; ++i) { a.radA[i] = g.radA[i]; a.radB[i] = g.radB[i]; }
     a.L = p->L; a.M = p->M;
