@@ -26,8 +26,9 @@ mkdir -p "$OBJ"
 "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/kernels.hip" -o "$OBJ/kernels.o" & P3=$!
 "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/soxr_abi.cpp" -o "$OBJ/soxr_abi.o" & P5=$!
 # (fft.hip in three translation units: see "Three translation units" there)
-# (-disable-machine-licm: see fft_tid() in fft.hip — the resident-workgroup kernel's loop body must keep its literals inside the loop)
-FFTFLAGS="-ffp-contract=fast -fno-slp-vectorize -mllvm -disable-machine-licm"
+# (experiment builds — the looping kernels k_fft_pair2p / k_fft_strided2<.., K > 0>, measured slower and left out of the product —
+#  are made with HIPSOXR_VARIANT=exp HIPSOXR_EXTRA_FLAGS="-DFFT_EXPERIMENTS -mllvm -disable-machine-licm": see fft_tid() in fft.hip)
+FFTFLAGS="-ffp-contract=fast -fno-slp-vectorize"
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=0 -c "$SRC/fft.hip" -o "$OBJ/fft.o" & P4=$!
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=1 -c "$SRC/fft.hip" -o "$OBJ/fft1.o" & P6=$!
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=2 -c "$SRC/fft.hip" -o "$OBJ/fft2.o" & P7=$!

@@ -269,13 +269,17 @@ __device__ __forceinline__ void fft_pass(cf *buf, int N, int Ns, const cf *W)
 // loop (216 VGPRs and 35 spilled SGPRs where the grid-per-item kernel needs 68; a real function call instead costs
 // the calling convention's alternating caller/callee-saved register blocks: highest VGPR 102).  A volatile asm is
 // not loop-invariant, so index arithmetic that starts from this value stays where it is written.  (The other half is
-// build.sh's -mllvm -disable-machine-licm for this file: the machine-level pass hoists the materialisation of every
-// literal — butterfly constants, scalar offsets — into registers of its own: 112 VGPRs / 17 spilled SGPRs with it,
-// 70 / 0 without; the straight-line kernels of this file do not change.)
+// -mllvm -disable-machine-licm: the machine-level pass hoists the materialisation of every literal — butterfly
+// constants, scalar offsets — into registers of its own: 112 VGPRs / 17 spilled SGPRs with it, 70 / 0 without.)
+// Both only in EXPERIMENT builds — HIPSOXR_EXTRA_FLAGS="-DFFT_EXPERIMENTS -mllvm -disable-machine-licm" build.sh — which
+// are also the only builds that contain the two looping kernels (k_fft_pair2p, k_fft_strided2<.., K > 0>): both were
+// measured slower than what they replace, and the opaque index costs the plain kernels 5-7 % more VALU instructions.
 __device__ __forceinline__ int fft_tid()
 {
     int t = (int)threadIdx.x;
+#ifdef FFT_EXPERIMENTS // (costs 5-7 % more VALU instructions in the plain kernels: common subexpressions are no longer shared)
     asm volatile("" : "+v"(t));
+#endif
     return t;
 }
 template <typename C> struct TwPre { C w1, w4; };
@@ -1448,8 +1452,10 @@ bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &j)
 // the walking instance of the channel-pair kernel exists where the geometry admits it (k_fft_strided2, K > 0)
 template <int NA, int NB, int NT, typename Real> static constexpr void (*walk_kernel())(FftArgs)
 {
+#ifdef FFT_EXPERIMENTS
     if constexpr (NA == 4410 && NB == 1600) return k_fft_strided2<PairOf<NA, NB, NT>, Real, true, 3>;
-    else return nullptr;
+#endif
+    return nullptr;
 }
 
 const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *handled)
@@ -1485,7 +1491,11 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
      walk_kernel<NA, NB, NT, float>(), walk_kernel<NA, NB, NT, double>(), (NA == 4410 && NB == 1600) ? 3 : 0}
 // (the first-generation kernel and the resident-workgroup experiment k_fft_pair2p exist for these families only)
 #define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, nullptr, nullptr)
+#ifdef FFT_EXPERIMENTS
 #define HIPSOXR_PAIR_V1(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, (k_fft_pair<PairOf<NA, NB, NT>>), (k_fft_pair2p<PairOf<NA, NB, NT>, float>))
+#else
+#define HIPSOXR_PAIR_V1(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, (k_fft_pair<PairOf<NA, NB, NT>>), nullptr)
+#endif
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
         HIPSOXR_PAIR_V1(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR_V1(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k

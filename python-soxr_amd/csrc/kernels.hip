@@ -61,7 +61,7 @@ const Switches &switches()
         w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_persist = on("HIPSOXR_FFT_PERSIST"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY"); w.fft_small_4pass = on("HIPSOXR_FFT_SMALL_4PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
-        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS");
+        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_stagger = num("HIPSOXR_DEBUG_STAGGER"); w.dbg_walk = num("HIPSOXR_DEBUG_WALK"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.no_auto_resident = on("HIPSOXR_NO_AUTO_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
@@ -1426,8 +1426,8 @@ __device__ __forceinline__ void mfma_half_chain(f32x4 (&acc)[2], const float4 *t
 // common case) take a path with no bounds tests, no division (the (row, column) of a thread's next
 // quad advances incrementally) and 32-bit offsets from a wave-uniform base; loads are issued in
 // batches of UNR before any is consumed.
-template <typename IO>
-__device__ __forceinline__ void stage_planes(const TileArgs &a, float *xs, uint32_t clip, uint32_t ch,
+template <typename IO, typename Real = float>
+__device__ __forceinline__ void stage_planes(const TileArgs &a, Real *xs, uint32_t clip, uint32_t ch,
                                              int64_t bw)
 {
     typedef IO IO4 __attribute__((ext_vector_type(4)));
@@ -1452,10 +1452,10 @@ __device__ __forceinline__ void stage_planes(const TileArgs &a, float *xs, uint3
             for (int u = 0; u < UNR; ++u) {
                 if (q + u * stride < n4) {
                     const int32_t m = row * R + colq;
-                    xs[m] = (float)v[u].x;
-                    xs[m + PLANE] = (float)v[u].y;
-                    xs[m + 2 * PLANE] = (float)v[u].z;
-                    xs[m + 3 * PLANE] = (float)v[u].w;
+                    xs[m] = (Real)v[u].x;
+                    xs[m + PLANE] = (Real)v[u].y;
+                    xs[m + 2 * PLANE] = (Real)v[u].z;
+                    xs[m + 3 * PLANE] = (Real)v[u].w;
                 }
                 row += drow; colq += dcol;
                 if (colq >= Mq) { colq -= Mq; ++row; }
@@ -1471,10 +1471,10 @@ __device__ __forceinline__ void stage_planes(const TileArgs &a, float *xs, uint3
             if (l + 2 >= 0 && l + 2 < a.in_frames) v.z = xin[(l + 2) * a.ifs];
             if (l + 3 >= 0 && l + 3 < a.in_frames) v.w = xin[(l + 3) * a.ifs];
             const int32_t row = q0 / Mq, m = row * R + (q0 - row * Mq);
-            xs[m] = (float)v.x;
-            xs[m + PLANE] = (float)v.y;
-            xs[m + 2 * PLANE] = (float)v.z;
-            xs[m + 3 * PLANE] = (float)v.w;
+            xs[m] = (Real)v.x;
+            xs[m + PLANE] = (Real)v.y;
+            xs[m + 2 * PLANE] = (Real)v.z;
+            xs[m + 3 * PLANE] = (Real)v.w;
         }
     }
 }
@@ -1576,6 +1576,148 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_tile_mfma64_p — the float64 engine (float64 / int32 I/O) in the planar form (round 3), for input periods that are
+// a multiple of 16.  Same idea as k_tile_mfma_p: the slab k-de-interleaved into four LDS planes, so that every offset
+// inside a half-chain is a wave-uniform scalar and the vector ALU — which costs the matrix pipe ~4 cycles per
+// instruction while it runs beside it — does nothing but issue MFMAs: k_tile_mfma<IO, double, NG> spends ten VALU
+// instructions per v_mfma_f64 on per-lane index bookkeeping (rocprofv3: 11.3 M VALU against 1.08 M MFMA per launch)
+// and reaches 18 TFLOP/s of the 78 the pipe sustains (tools/ubench/mfma_f64_rate.hip).  What differs from the f32 form:
+//   * v_mfma_f64_16x16x4_f64 takes 64 cycles, twice the f32 form: a slab is 32 periods (8 bytes per sample: 51 KB at
+//     48k -> 44.1k, three workgroups per CU), a work unit is one row tile across all 32 periods (2 accumulators);
+//   * a 16-byte access carries TWO samples: a group of 16 inputs is two ds_read_b128 per 16 periods and two
+//     global_load_dwordx4 of coefficients per lane, both one group (8 MFMAs = 512 pipe cycles) ahead of use;
+//   * the accumulator layout is row (lane >> 4) + 4 v (MfmaOf<double>::row).
+// Canonical order as everywhere: groups ascending (left) / descending (right), chunks and k inside them likewise.
+// ---------------------------------------------------------------------------------------------
+// NG = 2: one unit = a row tile across the slab's 32 periods (two accumulators share every coefficient load);
+// NG = 1: a unit is a row tile across 16 periods — twice as many, half as long: the four waves of a workgroup then
+// share 2 n_rt units evenly where n_rt is not a multiple of four (147 phases = 10 tiles: 3/3/2/2 -> 5/5/5/5).
+template <bool RIGHT, int NG>
+__device__ __forceinline__ void mfma64_half_chain(f64x4 (&acc)[NG], const double *t, const double *xb, int32_t e0, int32_t n_groups,
+                                                  int32_t Mc, int32_t R, int32_t padR)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    int32_t rem = e0 % Mc, fo = (e0 / Mc) * R + (rem >> 2); // wave-uniform plane offset of the next B read
+    auto ldb = [&](d2 (&b)[2 * NG]) { // period j (and j + 16), four consecutive chunk columns each
+        const double *px = xb + fo;
+        b[0] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(px, 16));
+        b[1] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(px + 2, 16));
+        if (NG == 2) {
+            b[2 * (NG - 1)] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(px + 16 * R, 16));
+            b[2 * (NG - 1) + 1] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(px + 16 * R + 2, 16));
+        }
+        if (!RIGHT) { fo += 4; rem += 16; if (rem == Mc) { rem = 0; fo += padR; } }
+        else { fo -= 4; rem -= 16; if (rem < 0) { rem += Mc; fo -= padR; } }
+    };
+    auto lda = [&](d2 (&av)[2], int32_t off) { // this lane's coefficients of the group's four chunks
+        av[0] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(t + off, 16));
+        av[1] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(t + off + 2, 16));
+    };
+    d2 ac[2], an[2], bc[2 * NG], bn[2 * NG];
+    lda(ac, 0);
+    ldb(bc);
+    int32_t poff = 0; // table offset (doubles) of the group whose coefficients are in flight (wave-uniform)
+    for (int32_t grp = 0; grp < n_groups; ++grp) {
+        poff += 256;
+        asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
+        lda(an, poff);                 // (the table carries four groups of slack)
+        ldb(bn);                       // (the slab carries a row of slack at either end)
+        __builtin_amdgcn_sched_barrier(0); // next group's operands are requested BEFORE this group's MFMAs
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double av = c < 2 ? ac[0][c] : ac[1][c - 2];
+            const int m = RIGHT ? 3 - c : c; // right half-chain: chunk c is plane column 3 - c (descending input index)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const double bv = m < 2 ? bc[2 * g][m] : bc[2 * g + 1][m - 2];
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[g], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ac[i] = an[i];
+#pragma unroll
+        for (int i = 0; i < 2 * NG; ++i) bc[i] = bn[i];
+    }
+}
+
+// PB = periods per slab: 32, or 16 for jobs of few slabs (half the LDS, twice the workgroups: 563 slabs of 32 periods on
+// 256 CUs leave a fifth of them with three workgroups and the rest with two — the launch waits for the fifth).
+template <typename IO, int NG, int PB>
+__global__ void __launch_bounds__(640) k_tile_mfma64_p(TileArgs a)
+{
+    typedef double Real;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int32_t Mc = (int32_t)a.Mc, R = a.rowR, PLANE = a.plane, padR = R - Mc / 4;
+    Real *xs = reinterpret_cast<Real *>(smem_raw) + R; // one row of slack below (pipelined reads run one group past the end)
+
+    const uint32_t col = blockIdx.y;
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
+    uint32_t bxi = blockIdx.x, bz = blockIdx.z, nz = gridDim.z;
+    if (a.xz) { // XCD-aware ids of a unit split (see k_tile_mfma_p)
+        const uint32_t slot = blockIdx.x >> 3;
+        nz = (uint32_t)a.xz;
+        bz = __builtin_amdgcn_readfirstlane(slot % nz);
+        bxi = __builtin_amdgcn_readfirstlane((slot / nz) * 8 + (blockIdx.x & 7u));
+        if (bxi >= (uint32_t)a.nx) return; // grid.x is padded to a multiple of 8 slabs
+    }
+    const int64_t bw = a.b_first + (int64_t)bxi * PB;
+    const int64_t k_end = a.out_k0 + a.out_frames;
+
+    stage_planes<IO, Real>(a, xs, clip, ch, bw);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int kq = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = a.n_waves;
+    const int32_t n_groups = a.I_h >> 4;
+    const size_t half_stride = (size_t)(n_groups + 4) * 256; // doubles per half table (+4 groups of prefetch slack)
+    const Real *xL = xs + kq * PLANE + j * R;        // left : lane k reads plane k
+    const Real *xR = xs + (3 - kq) * PLANE + j * R;  // right: lane k reads plane 3-k
+    IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
+    const bool interior = bw * a.Lc >= a.out_k0 && (bw + PB) * a.Lc <= k_end;
+
+    constexpr int UPT = PB / (16 * NG); // units per row tile
+    for (int u_ = wave + n_waves * (int)bz; u_ < UPT * a.n_rt; u_ += n_waves * (int)nz) { // unit = row tile x 16 NG periods
+        const int unit = __builtin_amdgcn_readfirstlane(u_);
+        const int rt = unit / UPT, ph = unit % UPT; // periods 16 ph ..
+        const int32_t wL = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]), wR = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
+        const int32_t eL0 = wL & 0xffffff, eR0 = wR & 0xffffff; // multiples of 16
+        const int32_t gL = wL >> 24, gR = wR >> 24;             // groups this tile's half-chains need (build_mfma_planes)
+        const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane * 4;
+        const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane * 4;
+        f64x4 accL[NG], accR[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { accL[g] = (f64x4){0, 0, 0, 0}; accR[g] = (f64x4){0, 0, 0, 0}; }
+        mfma64_half_chain<false, NG>(accL, tL, xL + ph * 16 * R, eL0, gL, Mc, R, padR);
+        mfma64_half_chain<true, NG>(accR, tR, xR + ph * 16 * R, eR0, gR, Mc, R, padR);
+
+        const int32_t rbase = rt * 16; // this lane: rows rbase + kq + 4 v, periods bw + 16 g + j
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int64_t b = bw + 16 * (g + ph) + j;
+            const int64_t kb = b * a.Lc + rbase;
+            IO *const yt = ybase + (kb - a.out_k0) * a.ofs;
+            if (interior && rbase + 16 <= a.Lc) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = kq + 4 * v;
+                    store_out<Real>(yt + r * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, kb + r);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = kq + 4 * v;
+                    const int64_t idx = kb + r - a.out_k0;
+                    if (rbase + r < a.Lc && idx >= 0 && idx < a.out_frames)
+                        store_out<Real>(yt + r * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, kb + r);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: device tables
 // ---------------------------------------------------------------------------------------------
 #define HIP_TRY(expr)                                                    \
@@ -1602,6 +1744,7 @@ struct TileGeom {
     int64_t Lc = 0, Mc = 0;
     size_t lds_bytes = 0;
     int32_t rowR = 0, plane = 0; // variant 2 (k_tile_mfma_p)
+    int32_t span = 0;            // variant 2: inputs one period's tiles reach over (i_max - i_min + 1): x_count = (pb - 1) Mc + span
     std::vector<int32_t> e0;
     bool ok = false;
 };
@@ -1611,10 +1754,15 @@ static inline int32_t floor16(int32_t v) { return v >= 0 ? (v / 16) * 16 : -(((-
 // Geometry + coefficient table of k_tile_mfma_p (f32 engine, Mc % 16 == 0).
 // Table: [n_rt][2][n_groups + 4][64 lanes][4 chunks]; lane (row j = l & 15, k = l >> 4), chunk c:
 //   left : C'[row][i0L + 16*grp + 4*c + k]        right: C'[row][i1R - (16*grp + 4*c + k)]
-static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
+// Real = double (k_tile_mfma64_p): the same table in float64, a slab of 32 periods (pb) instead of 64 — 8 bytes per
+// sample — and plane rows of R doubles with R == 2 (mod 4): the 16 rows of a ds_read_b128 group then start in 16
+// different 16-byte bank groups.
+template <typename Real>
+static TileGeom build_mfma_planes(const Plan &p, std::vector<Real> *tab)
 {
     TileGeom g;
     g.variant = 2;
+    g.pb = sizeof(Real) == 4 ? 64 : 32;
     const int64_t L = p.L, M = p.M;
     const int32_t T = p.T, H = T / 2;
     g.RT = 16;
@@ -1643,13 +1791,15 @@ static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
         i_max = std::max(i_max, std::max(i0L[rt] + I_h - 1, i1R[rt]));
     }
     g.i_min = i_min; // multiples of 16 by construction
-    g.x_count = 63 * Mc + (i_max - i_min + 1);
+    g.span = i_max - i_min + 1;
+    g.x_count = (g.pb - 1) * Mc + g.span;
     g.rowR = Mc / 4;
-    while ((g.rowR % 8) != 4) ++g.rowR; // R/4 odd -> conflict-free ds_read_b128 across the 16 periods
+    if (sizeof(Real) == 4) while ((g.rowR % 8) != 4) ++g.rowR; // R/4 odd -> conflict-free ds_read_b128 across the 16 periods
+    else while ((g.rowR % 4) != 2) ++g.rowR;                    // float64: R/2 odd
     g.pad = g.rowR - Mc / 4;
     const int32_t rows_total = (g.x_count + Mc - 1) / Mc + 3; // + slack rows: pipelined reads overrun by one group
     g.plane = (rows_total * g.rowR + 63) / 64 * 64;
-    g.lds_bytes = ((size_t)g.plane * 4 + g.rowR) * sizeof(float);
+    g.lds_bytes = ((size_t)g.plane * 4 + g.rowR) * sizeof(Real);
     // Groups a tile's half-chain really needs (bits 24..31 of its e0 word): the table rows are I_h long for every
     // tile — the longest span over all tiles, rounded to 16, from a start rounded down to 16 — but the groups past a
     // tile's own last tap hold only zero coefficients, and fma(0, x, acc) == acc: they are not issued (10-11 of 12
@@ -1665,7 +1815,7 @@ static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
     g.ok = true;
     if (tab) {
         const int ng = I_h / 16;
-        tab->assign((size_t)g.n_rt * 2 * (ng + 4) * 256, 0.f);
+        tab->assign((size_t)g.n_rt * 2 * (ng + 4) * 256, (Real)0);
         for (int rt = 0; rt < g.n_rt; ++rt)
             for (int rr = 0; rr < 16; ++rr) {
                 int64_t r = (int64_t)rt * 16 + rr;
@@ -1676,9 +1826,9 @@ static TileGeom build_mfma_planes(const Plan &p, std::vector<float> *tab)
                     const int grp = ii / 16, cc = (ii % 16) / 4, k = ii % 4, lane = k * 16 + rr;
                     const size_t at = ((size_t)grp * 64 + lane) * 4 + cc;
                     int32_t jl = i0L[rt] + ii - nr;
-                    if (jl >= 0 && jl < H) (*tab)[(size_t)(rt * 2 + 0) * (ng + 4) * 256 + at] = (float)cp[jl];
+                    if (jl >= 0 && jl < H) (*tab)[(size_t)(rt * 2 + 0) * (ng + 4) * 256 + at] = (Real)cp[jl];
                     int32_t jr = i1R[rt] - ii - nr;
-                    if (jr >= H && jr < T) (*tab)[(size_t)(rt * 2 + 1) * (ng + 4) * 256 + at] = (float)cp[jr];
+                    if (jr >= H && jr < T) (*tab)[(size_t)(rt * 2 + 1) * (ng + 4) * 256 + at] = (Real)cp[jr];
                 }
             }
     }
@@ -1818,7 +1968,8 @@ static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out, TileG
     *geom_out = g;
     if (sizeof(Real) == 8 && geom_m_out && !switches().no_mfma64) { // float64 engine on v_mfma_f64_16x16x4_f64 (k_tile_mfma<IO, double, NG>)
         std::vector<Real> tabm;
-        TileGeom gm = build_tile_tables<Real>(*p, &tabm, 1);
+        TileGeom gm = build_mfma_planes<Real>(*p, &tabm); // k_tile_mfma64_p where the period admits planes, else k_tile_mfma<IO, double, NG>
+        if (!gm.ok || switches().no_planes) gm = build_tile_tables<Real>(*p, &tabm, 1);
         if (gm.ok) {
             HIP_TRY(hipMalloc(&d.tile_tab_m, tabm.size() * sizeof(Real)));
             HIP_TRY(hipMemcpy(d.tile_tab_m, tabm.data(), tabm.size() * sizeof(Real), hipMemcpyHostToDevice));
@@ -1829,7 +1980,7 @@ static const char *bank_upload(Plan *p, DeviceBank &d, TileGeom *geom_out, TileG
     }
     if (sizeof(Real) == 4 && geom_m_out) {
         std::vector<float> tabm;
-        TileGeom gm = build_mfma_planes(*p, &tabm);
+        TileGeom gm = build_mfma_planes<float>(*p, &tabm);
         if (!gm.ok || switches().no_planes) gm = build_tile_tables<float>(*p, &tabm, 1);
         if (gm.ok) {
             HIP_TRY(hipMalloc(&d.tile_tab_m, tabm.size() * sizeof(Real)));
@@ -2119,9 +2270,24 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
 }
 
 template <typename IO, typename Real>
-static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const TileGeom &g)
+static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const TileGeom &g_in)
 {
     const DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
+    // float64 planar kernel: a job of few 32-period slabs runs on 16-period ones (k_tile_mfma64_p<.., PB>) — same
+    // tables, half the slab: the geometry's LDS figures are re-derived here
+    TileGeom g = g_in;
+    int f64_pb = 32;
+    if (sizeof(Real) == 8 && g.variant == 2) {
+        const int64_t slabs32 = ((j.out_k0 + j.out_frames - 1) / g.Lc - j.out_k0 / g.Lc + 32) / 32 * (int64_t)j.n_clips * j.n_channels;
+        if ((slabs32 < 6 * 256 || switches().dbg_mfma64_pb == 16) && switches().dbg_mfma64_pb != 32) {
+            f64_pb = 16;
+            g.pb = 16;
+            g.x_count = (g.pb - 1) * (int32_t)g.Mc + g.span;
+            const int32_t rows_total = (g.x_count + (int32_t)g.Mc - 1) / (int32_t)g.Mc + 3;
+            g.plane = (rows_total * g.rowR + 63) / 64 * 64;
+            g.lds_bytes = ((size_t)g.plane * 4 + g.rowR) * sizeof(Real);
+        }
+    }
     TileArgs a;
     a.in = j.in; a.out = j.out;
     a.tab = g.variant >= 1 ? d.tile_tab_m : d.tile_tab;
@@ -2151,7 +2317,9 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         }
         nw = best;
     }
-    if (g.variant == 2) nw = 4; // k_tile_mfma_p: one wave per SIMD, 2*n_rt units dealt round-robin
+    if (g.variant == 2) nw = 4; // k_tile_mfma_p / k_tile_mfma64_p: one wave per SIMD, the slab's units dealt round-robin
+    // (f32: tile x half of 64 periods; float64: tile x all periods of the slab — or tile x 16 periods, HIPSOXR_DEBUG_MFMA64_SPLIT)
+    const int units_per_slab = sizeof(Real) == 4 ? 2 * g.n_rt : (f64_pb == 32 && switches().dbg_mfma64_split) ? 2 * g.n_rt : g.n_rt;
     if (switches().dbg_nrt) { a.n_rt = switches().dbg_nrt; nw = a.n_rt; }
     if (switches().dbg_nw) nw = switches().dbg_nw;
     a.n_waves = nw;
@@ -2165,6 +2333,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         if (g.variant == 2) kern = k_tile_mfma_p<IO>;
     } else {
         if (g.variant == 1) kern = g.pb == 64 ? k_tile_mfma<IO, double, 4> : g.pb == 32 ? k_tile_mfma<IO, double, 2> : k_tile_mfma<IO, double, 1>;
+        if (g.variant == 2) kern = f64_pb == 16 ? k_tile_mfma64_p<IO, 1, 16> : switches().dbg_mfma64_split ? k_tile_mfma64_p<IO, 1, 32> : k_tile_mfma64_p<IO, 2, 32>;
     }
     a.rowR = g.rowR; a.plane = g.plane;
     dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
@@ -2173,7 +2342,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         // ceil(2*n_rt/4) workgroups so that every CU gets an equal share (3 resident per CU)
         const int64_t wgs = n_blocks * (int64_t)cols;
         // (from two workgroups per CU on, splitting only adds staging: measured 80 vs 92 us on a 60 s stereo clip)
-        int split = wgs >= 512 ? 1 : (int)std::min<int64_t>((2 * g.n_rt + 3) / 4, (2 * 3 * 256) / std::max<int64_t>(wgs, 1));
+        int split = wgs >= 512 ? 1 : (int)std::min<int64_t>((units_per_slab + 3) / 4, (2 * 3 * 256) / std::max<int64_t>(wgs, 1));
         if (switches().dbg_split) split = switches().dbg_split;
         grid.z = (unsigned)std::max(1, split);
         a.xz = 0; a.nx = (int32_t)n_blocks;

@@ -1,16 +1,22 @@
 #!/bin/bash
-# rocprofv3 passes over bench.py: kernel trace + stats, then PMC passes (counters in their own runs).
+# rocprofv3 passes over bench.py: kernel trace + stats, then PMC passes (counters in their own runs: gpurun refuses --pmc
+# combined with other trace domains).  Round 3: the traffic record is made by tools/make_traffic.py from pmc1/pmc3/pmc4;
+# pmc5/6 repeat the traffic passes on configs[2] with the walking channel-pair kernel (HIPSOXR_DEBUG_WALK=3).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd $R
-ARGS="${BENCH_ARGS:---steps 20 --warmup 3 --no-cpu --windows 5}"
+ARGS="${BENCH_ARGS:---steps 20 --warmup 3 --no-cpu --windows 6 --sustained-s 0.5}"
+SHORT="--steps 3 --warmup 1 --no-cpu --windows 2 --no-sustained"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc1 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu --windows 2 > $OUT/pmc1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc2 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu --windows 2 > $OUT/pmc2.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu --windows 2 > $OUT/pmc3.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- python bench.py --steps 3 --warmup 1 --no-cpu --windows 2 > $OUT/pmc4.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python bench.py $SHORT > $OUT/pmc1.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- python bench.py $SHORT > $OUT/pmc3.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- python bench.py $SHORT > $OUT/pmc4.log 2>&1
+HIPSOXR_DEBUG_WALK=3 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc5 -o p -- python tools/run_workload.py c2 5 > $OUT/pmc5.log 2>&1
+HIPSOXR_DEBUG_WALK=3 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc6 -o p -- python tools/run_workload.py c2 5 > $OUT/pmc6.log 2>&1
 python tools/pmc_summary.py $OUT/trace/*.db $OUT/pmc*/*.db > $OUT/summary.txt 2>&1
 grep -h '"metric"' $OUT/bench_trace.log > $OUT/bench_line.json
-cat $OUT/summary.txt
+python tools/make_traffic.py $OUT $OUT/traffic.json > $OUT/traffic.log 2>&1
+grep -v "at::native\|rocclr\|k_chain" $OUT/summary.txt | cut -c1-220 | head -150
+cat $OUT/traffic.json
