@@ -47,6 +47,15 @@
 #define __syncthreads() ((void)0)
 #endif
 
+// Build-time switches of this file (A/B experiments; DESIGN.md §5.2 has the measurements):
+//   FFT_BARRIER_LATE      the in-place barrier of a pass behind its butterflies (rounds 1-2) instead of behind its LDS reads
+//   FFT_STORE_INTERLEAVE  radix-16 passes issue their LDS stores between the four final radix-4 butterflies (slower: +3 %)
+//   FFT_EARLY_TABLES      twiddle / filter table loads one barrier ahead (no gain)
+//   FFT_EXPERIMENTS       the looping kernels k_fft_pair2p and k_fft_strided2<.., K > 0> (both slower than what they replace)
+#ifndef FFT_BARRIER_LATE
+#define FFT_BARRIER_EARLY 1
+#endif
+
 namespace hipsoxr {
 
 #define HIP_TRY(expr)                                       \
@@ -122,6 +131,33 @@ template <int SIGN, typename C> __device__ __forceinline__ void dft16(C *u)
         C v0 = x[0][b], v1 = x[1][b], v2 = x[2][b], v3 = x[3][b];
         dft4<SIGN>(v0, v1, v2, v3);
         u[b] = v0; u[b + 4] = v1; u[b + 8] = v2; u[b + 12] = v3;
+    }
+}
+// dft16 whose outputs go to `sink(m, X[m])` as soon as each of the four final radix-4 butterflies has produced its four
+// — the caller's LDS stores are then issued between the butterflies (a scheduling barrier pins them there) and the
+// store path works beside the vector ALU instead of in a burst of sixteen behind it.
+template <int SIGN, typename C, typename Sink> __device__ __forceinline__ void dft16_sink(C *u, Sink sink)
+{
+    typedef real_of<C> T;
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, h = (T)0.70710678118654752440, sg = (T)SIGN;
+    C x[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        C v0 = u[a], v1 = u[a + 4], v2 = u[a + 8], v3 = u[a + 12];
+        dft4<SIGN>(v0, v1, v2, v3);
+        x[a][0] = v0; x[a][1] = v1; x[a][2] = v2; x[a][3] = v3;
+    }
+    const C w1 = C(c1, sg * s1), w2 = C(h, sg * h), w3 = C(s1, sg * c1);
+    const C w4 = C((T)0, sg), w6 = C(-h, sg * h), w9 = C(-c1, -sg * s1);
+    x[1][1] = cmul(x[1][1], w1); x[1][2] = cmul(x[1][2], w2); x[1][3] = cmul(x[1][3], w3);
+    x[2][1] = cmul(x[2][1], w2); x[2][2] = cmul(x[2][2], w4); x[2][3] = cmul(x[2][3], w6);
+    x[3][1] = cmul(x[3][1], w3); x[3][2] = cmul(x[3][2], w6); x[3][3] = cmul(x[3][3], w9);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        C v0 = x[0][b], v1 = x[1][b], v2 = x[2][b], v3 = x[3][b];
+        dft4<SIGN>(v0, v1, v2, v3);
+        sink(b, v0); sink(b + 4, v1); sink(b + 8, v2); sink(b + 12, v3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // odd prime radix via the conjugate-pair form: X[m], X[R-m] = A_m +- SIGN*i*B_m
@@ -302,11 +338,38 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, 
     typedef real_of<C> T;
     const int tid = fft_tid();
     C u[NB][R];
+#ifdef FFT_BARRIER_EARLY
+    // The in-place barrier straight behind the pass's LDS reads instead of behind its butterflies (round 3): what the
+    // barrier has to guarantee is that every thread HOLDS its inputs, not that it has finished computing; waves reach
+    // it after one LDS round trip instead of after their butterflies, and the skew of the butterflies is absorbed by
+    // the barrier in front of the next pass alone.  configs[2] 47.4 -> 45.5 us, batch and clip unchanged, 3 VGPRs fewer.
+    C w1s[NB], w4s[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int j = tid + i * NT;
+        w1s[i] = C((T)1, (T)0); w4s[i] = w1s[i];
+        if (NB * NT == nb || j < nb) {
+            const int k = j % Ns;
+            if (Ns > 1) w1s[i] = EARLY ? early.w1 : PRE ? pre_w1 : W[k * wstep];
+            if (Ns > 1 && R >= 10) w4s[i] = EARLY ? early.w4 : W[4 * k * wstep];
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                if constexpr (std::is_invocable_v<Load, int, int>) u[i][t] = load(j + t * nb, t);
+                else u[i][t] = load(j + t * nb);
+            }
+        }
+    }
+    if (SYNC_BEFORE_STORE) __syncthreads(); // in-place: every input of the pass is in registers
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int j = tid + i * NT;
         if (NB * NT == nb || j < nb) {
             const int k = j % Ns;
+#ifdef FFT_BARRIER_EARLY
+            const C w1 = w1s[i];
+            (void)k;
+#else
             C w1 = C((T)1, (T)0);
             if (Ns > 1) w1 = EARLY ? early.w1 : PRE ? pre_w1 : W[k * wstep]; // issued before the data reads: the latencies overlap
 #pragma unroll
@@ -314,6 +377,7 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, 
                 if constexpr (std::is_invocable_v<Load, int, int>) u[i][t] = load(j + t * nb, t); // t: input slot
                 else u[i][t] = load(j + t * nb);
             }
+#endif
 #if defined(FFT2_ABL) && (FFT2_ABL & 32)
             if (false) {
 #else
@@ -326,7 +390,11 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, 
                 C pw[R];
                 pw[1] = w1;
                 if constexpr (R >= 10) {
+#ifdef FFT_BARRIER_EARLY
+                    const C w4 = w4s[i];
+#else
                     const C w4 = EARLY ? early.w4 : W[4 * k * wstep]; // 4*k*wstep < 4N/R <= N
+#endif
 #pragma unroll
                     for (int t = 2; t < R; ++t) {
                         const int a4 = t / 4, b4 = t % 4;
@@ -341,16 +409,28 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, 
 #pragma unroll
                 for (int t = 1; t < R; ++t) u[i][t] = cmul(u[i][t], pw[t]);
             }
+#if defined(FFT_BARRIER_EARLY) && defined(FFT_STORE_INTERLEAVE)
+            if constexpr (R == 16) {
+                const int o16 = (j - k) * R + k;
+                dft16_sink<SIGN>(u[i], [&](int t, C v) { store(o16 + t * Ns, v); });
+                continue; // (stored)
+            }
+#endif
 #if !(defined(FFT2_ABL) && (FFT2_ABL & 16))
             dft_r<R, SIGN>(u[i]);
 #endif
         }
     }
+#ifndef FFT_BARRIER_EARLY
     if (SYNC_BEFORE_STORE) __syncthreads(); // in-place: every input of the pass is in registers
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int j = tid + i * NT;
         if (NB * NT == nb || j < nb) {
+#if defined(FFT_BARRIER_EARLY) && defined(FFT_STORE_INTERLEAVE)
+            if constexpr (R == 16) continue; // (stored from inside the butterfly)
+#endif
             const int k = j % Ns, o = (j - k) * R + k;
 #pragma unroll
             for (int t = 0; t < R; ++t) store(o + t * Ns, u[i][t]);
@@ -679,7 +759,11 @@ HIPSOXR_SCHED(7056, 21, 16, 21, false);
 HIPSOXR_SCHED(5376, 21, 16, 16, false);
 HIPSOXR_SCHED(5120, 16, 16, 20, true);
 HIPSOXR_SCHED(4704, 21, 16, 14, false);
+#ifdef FFT_EXPERIMENTS
 HIPSOXR_SCHED(4410, 15, 14, 21, false); // (first radix 15: 4410 / 15 = 294 divides the 3528-frame hop of the 44.1k -> 16k blocks — k_fft_strided2's walk)
+#else
+HIPSOXR_SCHED(4410, 21, 14, 15, false); // (the order the product runs: configs[2] 47 us, against 52 us with the radix-15 pass first)
+#endif
 HIPSOXR_SCHED(4096, 16, 16, 16, true);
 HIPSOXR_SCHED(3840, 16, 16, 15, true);
 HIPSOXR_SCHED(3584, 14, 16, 16, false);

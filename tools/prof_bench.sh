@@ -18,5 +18,7 @@ HIPSOXR_DEBUG_WALK=3 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc6 -o p
 python tools/pmc_summary.py $OUT/trace/*.db $OUT/pmc*/*.db > $OUT/summary.txt 2>&1
 grep -h '"metric"' $OUT/bench_trace.log > $OUT/bench_line.json
 python tools/make_traffic.py $OUT $OUT/traffic.json > $OUT/traffic.log 2>&1
+# the rocpd databases are tens of MB each; gpurun copies back at most 64 MiB: keep the summaries only
+find $OUT -name "*.db" -delete
 grep -v "at::native\|rocclr\|k_chain" $OUT/summary.txt | cut -c1-220 | head -150
 cat $OUT/traffic.json
