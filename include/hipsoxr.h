@@ -79,8 +79,9 @@ typedef enum {
                                   through a mailbox in pinned memory: no HIP call per chunk, ~3x lower latency
                                   per call.  Same output, bit for bit.  The kernel leaves by itself after
                                   HIPSOXR_RESIDENT_IDLE_US (default 1000) without a call; until then device-wide
-                                  synchronisations elsewhere in the process wait for it.  Constant-rate
-                                  interleaved streams without HIPSOXR_DEFER.  Also: environment HIPSOXR_RESIDENT.
+                                  synchronisations elsewhere in the process wait for it.  Interleaved streams,
+                                  constant or variable rate (a variable-rate message carries its own Q64.64
+                                  clock), without HIPSOXR_DEFER.  Also: environment HIPSOXR_RESIDENT.
                                   Without the flag a stream turns this path on BY ITSELF once it has been fed 16 small
                                   chunks back to back (each within 500 us of the one before), and the kernel retires
                                   itself on idle as above; environment HIPSOXR_NO_AUTO_RESIDENT disables that. */

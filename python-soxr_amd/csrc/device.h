@@ -28,7 +28,8 @@ struct VrPos {
 // and what a launch of an instance needs.
 static constexpr unsigned kResidentMaxWgs = 64;
 struct ResidentBox {
-    uint64_t w[8];                  // line 0: host -> device (tagged words, see k_chain_resident)
+    uint64_t w[16];                 // lines 0-1: host -> device (tagged words, see k_chain_resident): 5 of them for a constant-rate
+                                    // message, 14 with a variable-rate clock (three 128-bit numbers in 48-bit pieces); w[15] = leave
     uint32_t exited, pad[15];       // line 1: device -> host: the instance that has left
     uint32_t done[kResidentMaxWgs]; // lines 2..5: device -> host: last message finished, per workgroup
 };
@@ -57,7 +58,8 @@ struct ChainDone { uint32_t *words; uint32_t cap, seq; uint32_t n_wgs = 0; };
 const char *launch_job(Plan *p, const hipsoxr_job_t &job, void *stream, const VrPos *vr = nullptr, ResidentLaunch *res = nullptr,
                        ChainDone *cd = nullptr);
 // hand message `seq` to the instance: outputs [out_k0, out_k0 + out_frames) from ring frames [in_abs0, in_abs0 + in_frames)
-bool resident_post(const Plan &p, volatile uint64_t *words, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames);
+bool resident_post(const Plan &p, volatile uint64_t *words, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames,
+                   const VrPos *vr = nullptr);
 void resident_leave(volatile uint64_t *words, uint32_t epoch);
 
 int device_count();

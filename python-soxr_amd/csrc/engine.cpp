@@ -670,7 +670,7 @@ static const char *stream_emit(hipsoxr_stream *s, void *out, size_t olen, size_t
 // Returns nullptr with *served = false when this call has to take the ordinary path.
 static const size_t kCtlSlots = 1024;
 static const uint32_t kDoneWords = 64; // (larger launches: an event — 200 workgroups reporting one by one took 10 us longer than it)
-static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool *served)
+static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool *served, const VrPos *vp = nullptr)
 {
     hipsoxr_stream::Resident &r = s->res;
     *served = false;
@@ -684,9 +684,9 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
         r.words = r.box->w;
         hipDeviceProp_t pr;
         if (!switches().resident_no_bar && hipGetDeviceProperties(&pr, s->device) == hipSuccess && pr.isLargeBar &&
-            hipExtMallocWithFlags(&r.words_dev, 64, hipDeviceMallocFinegrained) == hipSuccess) {
+            hipExtMallocWithFlags(&r.words_dev, 128, hipDeviceMallocFinegrained) == hipSuccess) {
             r.words = (volatile uint64_t *)r.words_dev;
-            for (int i = 0; i < 8; ++i) r.words[i] = 0;
+            for (int i = 0; i < 16; ++i) r.words[i] = 0;
             __builtin_ia32_sfence();
         }
     }
@@ -719,7 +719,7 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
         hipsoxr_job_t cap = jr; // room for chunks a quarter longer than this one
         cap.out_frames = std::max<int64_t>(64, j.out_frames + j.out_frames / 4 + 2);
         rl.used_mcu = g_resident_mcu.load(); // (the launcher knows occupancy and CU count: it refuses what does not fit)
-        if (const char *e = launch_job(&s->plan->p, cap, s->st, nullptr, &rl)) {
+        if (const char *e = launch_job(&s->plan->p, cap, s->st, vp, &rl)) { // (vp: only says "variable rate" here — every message carries its own clock)
             if (rl.over_budget) return ""; // over the budget: the ordinary path, this time
             (void)e; // not a job the resident form serves: the ordinary path does
             ++r.failed;
@@ -734,7 +734,7 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
         if (j.out_frames > r.max_out) { resident_stop(s); ++r.failed; return nullptr; }
     }
     const uint32_t seq = r.seq + 1;
-    if (!resident_post(s->plan->p, r.words, seq, j.in_abs0, j.in_frames, j.out_k0, j.out_frames)) { resident_stop(s); return nullptr; }
+    if (!resident_post(s->plan->p, r.words, seq, j.in_abs0, j.in_frames, j.out_k0, j.out_frames, vp)) { resident_stop(s); return nullptr; }
     r.seq = seq;
     volatile uint32_t *done = r.box->done, *exited = &r.box->exited;
     const auto t0 = std::chrono::steady_clock::now();
@@ -834,7 +834,13 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     ChainDone cd;
     cd.words = nullptr; cd.cap = 0; cd.seq = 0;
     bool served = false;
-    const bool small_call = s->ring_on_host && direct && !v.on && !s->split && s->in_fill > 0 && n <= 2048;
+    const bool small_call = s->ring_on_host && direct && !s->split && s->in_fill > 0 && n <= 2048;
+    VrPos vp = {0, 0, 0, 0, 0, 0};
+    if (v.on) { // this launch's (or message's) clock: position and step at the first output, step increment while a slew lasts
+        const i128 T0 = v.pos(s->k_done), S0 = v.step(s->k_done), D = s->k_done < v.k_s + v.n_slew ? v.delta : 0;
+        vp = VrPos{(uint64_t)((u128)T0 >> 64), (uint64_t)(u128)T0, (uint64_t)((u128)S0 >> 64), (uint64_t)(u128)S0,
+                   (uint64_t)((u128)D >> 64), (uint64_t)(u128)D};
+    }
     if (!s->resident && s->resident_auto_ok) {
         const auto now = std::chrono::steady_clock::now();
         const auto gap = std::chrono::microseconds(std::max(50, switches().resident_idle_us) / 2);
@@ -843,7 +849,7 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
         if (s->small_run >= kAutoResidentRun) s->resident = true;
     }
     if (s->resident && small_call) {
-        if (const char *e = resident_emit(s, j, &served)) return e;
+        if (const char *e = resident_emit(s, j, &served, v.on ? &vp : nullptr)) return e;
     }
     if (served) {
         std::memcpy(out, s->h_out, out_bytes);
@@ -856,9 +862,6 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
         std::memset(s->h_done, 0, kDoneWords * sizeof(uint32_t));
     cd.words = s->h_done; cd.cap = s->h_done && direct ? kDoneWords : 0; cd.seq = ++s->done_seq;
     if (v.on) {
-        const i128 T0 = v.pos(s->k_done), S0 = v.step(s->k_done), D = s->k_done < v.k_s + v.n_slew ? v.delta : 0;
-        VrPos vp = {(uint64_t)((u128)T0 >> 64), (uint64_t)(u128)T0, (uint64_t)((u128)S0 >> 64), (uint64_t)(u128)S0,
-                    (uint64_t)((u128)D >> 64), (uint64_t)(u128)D};
         if (const char *e = launch_job(&s->plan->p, j, s->st, &vp, nullptr, cd.cap ? &cd : nullptr)) return e;
     } else {
         if (const char *e = launch_job(&s->plan->p, j, s->st, nullptr, nullptr, cd.cap ? &cd : nullptr)) return e;
@@ -1016,8 +1019,8 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
     s->plan = plan; s->own_plan = own; s->ch = ch;
     s->elem = (int)io & 3; s->split = ((int)io & 4) != 0; s->flags = flags;
     s->defer = (flags & HIPSOXR_DEFER) && !(flags & HIPSOXR_VR) && !s->split;
-    s->resident = ((flags & HIPSOXR_RESIDENT) || switches().resident) && !s->defer && !(flags & HIPSOXR_VR) && !s->split;
-    s->resident_auto_ok = !s->resident && !s->defer && !(flags & HIPSOXR_VR) && !s->split && !switches().no_auto_resident;
+    s->resident = ((flags & HIPSOXR_RESIDENT) || switches().resident) && !s->defer && !s->split;
+    s->resident_auto_ok = !s->resident && !s->defer && !s->split && !switches().no_auto_resident;
     if (flags & HIPSOXR_VR) {
         const double io0 = plan->p.in_rate / plan->p.out_rate;
         if (!(io0 > 9.5367431640625e-07) || !(io0 < 1048576.)) { delete s; return "io ratio out of range for variable rate"; }

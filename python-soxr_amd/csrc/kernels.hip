@@ -579,7 +579,7 @@ struct ChainArgs {
 };
 
 // what changes from one launch (or one message to the resident form, below) to the next
-struct ChainMsg { int64_t in_abs0, in_frames, out_k0, out_frames, d0, p0; };
+struct ChainMsg { int64_t in_abs0, in_frames, out_k0, out_frames, d0, p0; uint64_t t_hi, t_lo, s_hi, s_lo, d_hi, d_lo; /* MODE 2: the Q64.64 clock of this launch / message */ };
 
 #ifndef HIPSOXR_RPW
 #define HIPSOXR_RPW 2
@@ -601,6 +601,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &
     InterpArgs ia = ca.ia;
     GatherArgs &a = ia.g;
     a.in_abs0 = m.in_abs0; a.in_frames = m.in_frames; a.out_k0 = m.out_k0; a.out_frames = m.out_frames; a.d0 = m.d0; a.p0 = m.p0;
+    if (MODE == 2) { ia.t_hi = m.t_hi; ia.t_lo = m.t_lo; ia.s_hi = m.s_hi; ia.s_lo = m.s_lo; ia.d_hi = m.d_hi; ia.d_lo = m.d_lo; }
     constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
     constexpr int V = 16 / (int)sizeof(Real);      // taps per 16-byte coefficient read: 4 (f32) or 2 (f64)
     const int32_t T = a.T, H = T / 2, NO = ca.NO, RS = T + V; // RS: row stride (rows 16-byte aligned, banks rotate by V per row)
@@ -791,7 +792,7 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const GatherArgs &g = ca.ia.g;
-    const ChainMsg m = {g.in_abs0, g.in_frames, g.out_k0, g.out_frames, g.d0, g.p0};
+    const ChainMsg m = {g.in_abs0, g.in_frames, g.out_k0, g.out_frames, g.d0, g.p0, ca.ia.t_hi, ca.ia.t_lo, ca.ia.s_hi, ca.ia.s_lo, ca.ia.d_hi, ca.ia.d_lo};
     chain_body<IO, Real, MODE>(ca, m, blockIdx.x, blockIdx.y, smem_raw);
     if (ca.done_words) {
         __threadfence_system();
@@ -847,7 +848,8 @@ template <typename IO, typename Real, int MODE>
 __global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ uint64_t s_w[8];
+    __shared__ uint64_t s_w[16];
+    constexpr int NW = MODE == 2 ? 14 : 5; // message words (the variable-rate clock rides in words 5..13); word 15 = leave
     __shared__ unsigned long long s_old;
     __shared__ int s_state;
     const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
@@ -860,15 +862,15 @@ __global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
             int state;
             uint64_t v = 0;
             for (;;) {
-                if (lane < 6) v = __hip_atomic_load(&ra.words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const bool ok = lane >= 5 || (v >> 48) == want;
-                const uint64_t leave = __shfl(v, 5, 64);
+                if (lane < 16) v = __hip_atomic_load(&ra.words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const bool ok = lane >= NW || (v >> 48) == want;
+                const uint64_t leave = __shfl(v, 15, 64);
                 if (__all(ok)) { state = 1; break; }
                 if (leave == (uint64_t)ra.epoch) { state = 2; break; }
                 if (wall_clock64() - t_idle > ra.idle_ticks) { state = 3; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
-            if (lane < 5) s_w[lane] = v & kResidentMask48;
+            if (lane < NW) s_w[lane] = v & kResidentMask48;
             if (lane == 0) {
                 // too long without a message: try to seal the instance (the arbiter, see above)
                 if (state == 3) s_old = atomicCAS(&ra.ctl->dec, n, n | kResidentSeal);
@@ -906,6 +908,15 @@ __global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
             m.in_abs0 = (int64_t)uni(s_w[0]); m.out_k0 = (int64_t)uni(s_w[1]); m.d0 = (int64_t)uni(s_w[2]);
             m.p0 = (int64_t)(w3 & 0xffffffu); m.in_frames = (int64_t)(w3 >> 24);
             m.out_frames = (int64_t)w4;
+            m.t_hi = m.t_lo = m.s_hi = m.s_lo = m.d_hi = m.d_lo = 0;
+            if (MODE == 2) { // three 128-bit numbers, each as 48 + 48 + 32 bits (low piece first)
+                auto u128 = [&](int i, uint64_t &hi, uint64_t &lo) {
+                    const uint64_t a0 = uni(s_w[i]), a1 = uni(s_w[i + 1]), a2 = uni(s_w[i + 2]);
+                    lo = a0 | (a1 << 48);
+                    hi = (a1 >> 16) | (a2 << 32);
+                };
+                u128(5, m.t_hi, m.t_lo); u128(8, m.s_hi, m.s_lo); u128(11, m.d_hi, m.d_lo);
+            }
         }
         if ((int64_t)blockIdx.x * ra.ca.NO < m.out_frames) {
             chain_body<IO, Real, MODE>(ra.ca, m, blockIdx.x, blockIdx.y, smem_raw,
@@ -2145,9 +2156,8 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     ck = k_chain<IO, Real, 0>;
                 }
                 if (res) { // the resident form: same staging, same chains, fed by messages (k_chain_resident)
-                    if (vr) return "resident kernel: constant rate only";
-                    if (p->L >= (1 << 24)) return "resident kernel: ratio numerator too large";
-                    void (*rk)(ResidentArgs) = p->phases ? k_chain_resident<IO, Real, 1> : k_chain_resident<IO, Real, 0>;
+                    if (p->L >= (1 << 24) && !vr) return "resident kernel: ratio numerator too large";
+                    void (*rk)(ResidentArgs) = vr ? k_chain_resident<IO, Real, 2> : p->phases ? k_chain_resident<IO, Real, 1> : k_chain_resident<IO, Real, 0>;
                     const unsigned gx = (unsigned)((nf + NO - 1) / NO), gy = (unsigned)((uint64_t)j.n_clips * j.n_channels);
                     // every workgroup must be on the chip at once (they wait for each other): a quarter of the slots at most
                     int occ = 0, dev = 0, cus = 0;
@@ -2465,9 +2475,10 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st,
     return launch_gather<IO, Real>(p, j, st, nullptr, nullptr, cd);
 }
 
-bool resident_post(const Plan &p, volatile uint64_t *w, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames)
+bool resident_post(const Plan &p, volatile uint64_t *w, uint32_t seq, int64_t in_abs0, int64_t in_frames, int64_t out_k0, int64_t out_frames,
+                   const VrPos *vr)
 {
-    const __int128 kM = (__int128)out_k0 * p.M;
+    const __int128 kM = vr ? (__int128)0 : (__int128)out_k0 * p.M; // (variable rate: positions come from the message's own clock)
     const int64_t d0 = (int64_t)(kM / p.L), p0 = (int64_t)(kM % p.L);
     const uint64_t lim = 1ULL << 48;
     if ((uint64_t)in_abs0 >= lim || (uint64_t)out_k0 >= lim || (uint64_t)d0 >= lim || (uint64_t)in_frames >= (1u << 24) ||
@@ -2482,12 +2493,20 @@ bool resident_post(const Plan &p, volatile uint64_t *w, uint32_t seq, int64_t in
     w[2] = tag | (uint64_t)d0;
     w[3] = tag | ((uint64_t)in_frames << 24) | (uint64_t)p0;
     w[4] = tag | (uint64_t)out_frames;
+    if (vr) { // the variable-rate clock of this message: position, step, step increment (Q64.64), 48 + 48 + 32 bits each
+        auto put = [&](int i, uint64_t hi, uint64_t lo) {
+            w[i] = tag | (lo & kResidentMask48);
+            w[i + 1] = tag | ((lo >> 48) | ((hi & 0xffffffffULL) << 16));
+            w[i + 2] = tag | (hi >> 32);
+        };
+        put(5, vr->t_hi, vr->t_lo); put(8, vr->s_hi, vr->s_lo); put(11, vr->d_hi, vr->d_lo);
+    }
     __builtin_ia32_sfence();
     return true;
 }
 void resident_leave(volatile uint64_t *w, uint32_t epoch)
 {
-    w[5] = (uint64_t)epoch;
+    w[15] = (uint64_t)epoch;
     __builtin_ia32_sfence();
 }
 

@@ -158,7 +158,9 @@ class ResampleStream:
                                     mailbox in pinned memory: no HIP call per chunk (10 ms chunks: ~12 us per
                                     call instead of ~31 us).  Output identical, frames surface in the same
                                     call.  The kernel leaves by itself 1 ms after the last call
-                                    (HIPSOXR_RESIDENT_IDLE_US).  Constant-rate streams, not with `deferred`.
+                                    (HIPSOXR_RESIDENT_IDLE_US).  Interleaved streams (constant or variable rate), not with
+                                    `deferred`.  Without the flag a stream turns this path on by itself after 16 small
+                                    back-to-back calls.
     dither_seed : int               (extension) seed of the int16 TPDF dither.  libsoxr seeds randomly per
                                     handle; here dither is a deterministic function of (seed, channel,
                                     output index), default seed 0 — pass distinct seeds to decorrelate
@@ -176,7 +178,7 @@ class ResampleStream:
         self._ratio = float(out_rate) / float(in_rate)
         self._h = _C.c_void_p()
         flags = ((_n.VR if vr else 0) | (_n.DEFER if deferred and not vr else 0)
-                 | (_n.RESIDENT if resident and not vr and not deferred else 0))
+                 | (_n.RESIDENT if resident and not deferred else 0))
         _n.check(_n.lib.hipsoxr_stream_create(float(in_rate), float(out_rate), self._channels,
                                               elem, recipe, flags, _C.byref(self._h)))
         if dither_seed:

@@ -73,6 +73,34 @@ def test_configs4_variable_rate_int16_44k1_to_16k_chunked(soxr, oracle, chunk):
     assert rs.num_clips() == 0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.int16, np.float64])
+@pytest.mark.parametrize("chunk", [100, 441, 1500])
+def test_vr_stream_through_the_resident_kernel(soxr, oracle, dtype, chunk):
+    """Variable-rate streams on the resident kernel (round 3: every message carries its own Q64.64 clock — position, step,
+    step increment — in nine more tagged words): the same frames in the same calls as the oracle driven by the independent
+    clock of tests/vr_sim.py, across ratio changes with and without a slew, a change while a slew is running, and idle
+    gaps longer than the kernel's idle time (the instance leaves and the next call starts another)."""
+    import time
+    rng = np.random.default_rng(7 + chunk)
+    x = _signal(rng, 30000, dtype)
+    rs = soxr.ResampleStream(44100, 16000, 1, dtype=dtype, quality="VHQ", vr=True, resident=True)
+    sim = VrSim(oracle, 44100, 16000, "VHQ", dtype)
+    changes = {3: (44100, 22050, 300), 5: (5, 2, 0), 9: (44100, 30000, 1000), 10: (44100, 16000, 50)}
+    for c, i in enumerate(range(0, len(x), chunk)):
+        last = i + chunk >= len(x)
+        if c in changes:
+            a, b, slew = changes[c]
+            rs.set_io_ratio(a, b, slew)
+            sim.set_io_ratio(a / b, slew)
+        if c == 7:
+            time.sleep(0.005)                                   # the idle instance leaves (1 ms)
+        y = rs.resample_chunk(x[i:i + chunk], last=last)
+        want = sim.feed(x[i:i + chunk], last=last)
+        assert y.dtype == np.dtype(dtype) and len(y) == len(want), f"call {c}"
+        assert np.array_equal(y, want), f"call {c}"
+    assert rs.delay() < 2
+
+
 def test_vr_multichannel_and_chunking_of_calls(soxr, oracle):
     """Channels share the clock; cutting the same input into different process calls between the
     same ratio changes gives the same samples."""
