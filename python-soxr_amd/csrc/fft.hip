@@ -51,6 +51,7 @@
 //   FFT_BARRIER_LATE      the in-place barrier of a pass behind its butterflies (rounds 1-2) instead of behind its LDS reads
 //   FFT_STORE_INTERLEAVE  radix-16 passes issue their LDS stores between the four final radix-4 butterflies (slower: +3 %)
 //   FFT_EARLY_TABLES      twiddle / filter table loads one barrier ahead (no gain)
+//   FFT_LDS_DMA           k_fft_pair2 (float32): the input blocks land in LDS by `buffer_load_dwordx4 ... lds`, first pass from LDS
 //   FFT_EXPERIMENTS       the looping kernels k_fft_pair2p and k_fft_strided2<.., K > 0> (both slower than what they replace)
 #ifndef FFT_BARRIER_LATE
 #define FFT_BARRIER_EARLY 1
@@ -1014,7 +1015,37 @@ __device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem
     typename Spec::Tw tw;
 
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
-    if (ina >= 0) {
+#ifdef FFT_LDS_DMA
+    // Experiment (round 3, measured slower — profiles/r03_ab_experiments.txt): the two blocks land in LDS by DMA
+    // (`buffer_load_dwordx4 ... lds`, 1 KB per wave instruction: 40 instead of 160 x 6 vector-memory instructions per
+    // pair, no VGPR destinations), x_a in floats [0, NA), x_b in [NA, 2 NA); one barrier; the first pass then reads
+    // its operands from LDS and stores in place behind a barrier of its own.
+    constexpr bool kDma = sizeof(IO) == 4 && sizeof(Real) == 4 && NA % 256 == 0;
+#else
+    constexpr bool kDma = false;
+#endif
+    if (kDma && ina >= 0) {
+#ifdef FFT_LDS_DMA
+        const int64_t left = (in_frames - ina) * ES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr((void *)(xin + ina)), 0, __builtin_amdgcn_readfirstlane((int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left)), 0x00020000);
+        Real *land = reinterpret_cast<Real *>(smem_raw);
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+        constexpr int CH = NA / 256, NWV = NT / 64;
+#pragma unroll
+        for (int r = 0; r < (2 * CH + NWV - 1) / NWV; ++r) {
+            const int c = wave + r * NWV; // wave-uniform chunk of 256 floats
+            if (c < 2 * CH) {
+                const int blk = c >= CH ? 1 : 0, cc = c - blk * CH;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(land + blk * NA + cc * 256), 16,
+                                                         lane * 16 + cc * 1024, blk * hop_in * ES, 0, 0);
+            }
+        }
+        __syncthreads();
+        FFT_STAMP();
+        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int n, int) -> C { return C(land[n], land[NA + n]); }, lds_store, true, tw);
+#endif
+    } else if (ina >= 0) {
         const int64_t left = (in_frames - ina) * ES; // bytes from block a's first sample to the end of the column
         // (descriptor words marked wave-uniform: in the resident-workgroup kernel the item comes out of LDS and the
         //  compiler would otherwise keep the descriptor in VGPRs and wrap every load in a waterfall loop)
