@@ -99,6 +99,8 @@ struct Switches {
     int dbg_walk = 0;             // HIPSOXR_DEBUG_WALK       blocks walked per workgroup by the channel-pair kernel (1 = never walk; default 3 for large jobs)
     int dbg_stagger = 0;          // HIPSOXR_DEBUG_STAGGER    k_fft_pair2p: start offset in cycles between the workgroup slots of a CU
     size_t dbg_lds = 0;           // HIPSOXR_DEBUG_LDS        extra dynamic LDS (occupancy experiments)
+    bool dbg_slab32 = false;       // HIPSOXR_DEBUG_SLAB32     k_tile_mfma_p: 32-period slabs whatever the job size (A/B)
+    bool dbg_slab64 = false;       // HIPSOXR_DEBUG_SLAB64     k_tile_mfma_p: 64-period slabs for small jobs too (round-2 behaviour; A/B)
     int dbg_mfma64_pb = 0;         // HIPSOXR_DEBUG_MFMA64_PB  k_tile_mfma64_p: periods per slab, 16 or 32 (default: 16 below 1536 slabs of 32)
     bool dbg_mfma64_split = false; // HIPSOXR_DEBUG_MFMA64_SPLIT k_tile_mfma64_p: units of 16 periods even where 4 divides the tile count
     size_t dbg_mfma64_lds = 0;    // HIPSOXR_DEBUG_MFMA64_LDS LDS budget (bytes) that picks the float64 MFMA kernel's slab: 64, 32 or 16 periods

@@ -61,7 +61,7 @@ const Switches &switches()
         w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_persist = on("HIPSOXR_FFT_PERSIST"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY"); w.fft_small_4pass = on("HIPSOXR_FFT_SMALL_4PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
-        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB");
+        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_stagger = num("HIPSOXR_DEBUG_STAGGER"); w.dbg_walk = num("HIPSOXR_DEBUG_WALK"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.no_auto_resident = on("HIPSOXR_NO_AUTO_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
@@ -1510,7 +1510,7 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
         bxi = __builtin_amdgcn_readfirstlane((slot / nz) * 8 + (blockIdx.x & 7u));
         if (bxi >= (uint32_t)a.nx) return; // grid.x is padded to a multiple of 8 slabs
     }
-    const int64_t bw = a.b_first + (int64_t)bxi * 64;
+    const int64_t bw = a.b_first + (int64_t)bxi * a.pb; // slabs of 64 periods; of 32 for jobs of few slabs (launch_tile)
     const int64_t k_end = a.out_k0 + a.out_frames;
     unsigned long long *tr = a.trace ? a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 : nullptr;
     int tri = 0;
@@ -1531,15 +1531,17 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
     const Real *xL = xs + kq * PLANE + j * R;        // left : lane k reads plane k
     const Real *xR = xs + (3 - kq) * PLANE + j * R;  // right: lane k reads plane 3-k
     IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
-    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= k_end;
+    const bool interior = bw * a.Lc >= a.out_k0 && (bw + a.pb) * a.Lc <= k_end;
+    const int hp = a.pb >> 5; // units per row tile: halves of a 64-period slab, or the one 32-period slab
+    // (rotating which waves take the odd units of a split slab with the slab index changes nothing: measured)
 
     // Work unit = (tile, half of the 64 periods).  A workgroup runs 4 waves — exactly one per SIMD,
     // because 10-wave workgroups land 3/3/2/2 on the SIMDs and leave 17 % of the matrix pipe idle
     // (tools/ubench/mfma_loop.hip) — and its 2*n_rt equal units are dealt round-robin.
     // Small jobs additionally split a slab's units over gridDim.z workgroups (each stages the slab).
-    for (int u_ = wave + n_waves * (int)bz; u_ < 2 * a.n_rt; u_ += n_waves * (int)nz) {
+    for (int u_ = wave + n_waves * (int)bz; u_ < hp * a.n_rt; u_ += n_waves * (int)nz) {
         const int unit = __builtin_amdgcn_readfirstlane(u_);
-        const int rt = unit >> 1, ph = unit & 1; // periods 32*ph .. 32*ph + 31
+        const int rt = hp == 2 ? unit >> 1 : unit, ph = hp == 2 ? unit & 1 : 0; // periods 32*ph .. 32*ph + 31
         const int32_t wL = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]), wR = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
         const int32_t eL0 = wL & 0xffffff, eR0 = wR & 0xffffff; // multiples of 16
         const int32_t gL = (a.dbg & 16) ? n_groups : wL >> 24, gR = (a.dbg & 16) ? n_groups : wR >> 24; // groups this tile's half-chains need (build_mfma_planes; HIPSOXR_DEBUG_FLAGS 16: all of them)
@@ -2298,6 +2300,46 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
             g.lds_bytes = ((size_t)g.plane * 4 + g.rowR) * sizeof(Real);
         }
     }
+    // float32 planar kernel: slab size and unit split by job size.  A slab of 64 periods (41 KB of LDS, three workgroups
+    // per CU) has 2 n_rt units (row tile x 32 periods), one of 32 periods (20 KB, seven per CU) n_rt; either runs as ONE
+    // workgroup (four waves, the units dealt round-robin) or SPLIT over ceil(units / 4) workgroups of one unit per wave,
+    // each staging the slab for itself.  What a job of few slabs costs is decided by how many workgroups deep the CUs
+    // are stacked ("layers": the dispatcher fills 256 CUs evenly only in whole layers) times what one workgroup does
+    // serially, plus staging; the constants are fitted to tools/slab_ab.sh sweeps (10 .. 6016 slabs, 48k -> 44.1k VHQ,
+    // profiles/r03_ab_experiments.txt), in units of one unit's MFMA time:
+    //     cost = c0 + layers x (units per wave) x k;   (pb, one unit per wave): c0, k = 32: 1.43, 1.21 | 64: 1.9, 1.43
+    //                                                  (pb, several)          :         32: 1.77, 1.10 | 64: 2.8, 1.21
+    // e.g. 47 slabs (a 10 s clip): 64/split (235 workgroups, one layer); 20: 32/split (120 workgroups staging half as
+    // much); 376: 32/whole (752 workgroups, 3 layers of 3 units: 35 us where round 2's 64/4 took 51); from 512 slabs of
+    // 64 on the whole-slab form is the rule again (12 waves per CU stream coefficients for 20 units each).
+    int f32_split = 0;
+    if (sizeof(Real) == 4 && g.variant == 2 && !switches().dbg_slab64) {
+        const int64_t periods = (j.out_k0 + j.out_frames - 1) / g.Lc - j.out_k0 / g.Lc + 1, cols_ = (int64_t)j.n_clips * j.n_channels;
+        const int64_t slabs64 = (periods + 63) / 64 * cols_, slabs32 = (periods + 31) / 32 * cols_;
+        int best_pb = 64, best_split = 1;
+        if (slabs64 < 2048 || switches().dbg_slab32) {
+            double best = 1e300;
+            for (int pb = switches().dbg_slab32 ? 32 : 64; pb >= 32; pb -= 32) {
+                const int units = (pb / 32) * g.n_rt, full = (units + 3) / 4;
+                for (int split : {1, full}) {
+                    const int upw = (units + 4 * split - 1) / (4 * split);
+                    const int64_t layers = ((pb == 64 ? slabs64 : slabs32) * split + 255) / 256;
+                    const double c0 = pb == 32 ? (upw == 1 ? 1.43 : 1.77) : (upw == 1 ? 1.9 : 2.8);
+                    const double k = pb == 32 ? (upw == 1 ? 1.21 : 1.10) : (upw == 1 ? 1.43 : 1.21);
+                    const double cost = c0 + (double)layers * upw * k;
+                    if (cost < best) { best = cost; best_pb = pb; best_split = split; }
+                }
+            }
+        }
+        f32_split = best_split;
+        if (best_pb == 32) {
+            g.pb = 32;
+            g.x_count = (g.pb - 1) * (int32_t)g.Mc + g.span;
+            const int32_t rows_total = (g.x_count + (int32_t)g.Mc - 1) / (int32_t)g.Mc + 3;
+            g.plane = (rows_total * g.rowR + 63) / 64 * 64;
+            g.lds_bytes = ((size_t)g.plane * 4 + g.rowR) * sizeof(Real);
+        }
+    }
     TileArgs a;
     a.in = j.in; a.out = j.out;
     a.tab = g.variant >= 1 ? d.tile_tab_m : d.tile_tab;
@@ -2329,7 +2371,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     }
     if (g.variant == 2) nw = 4; // k_tile_mfma_p / k_tile_mfma64_p: one wave per SIMD, the slab's units dealt round-robin
     // (f32: tile x half of 64 periods; float64: tile x all periods of the slab — or tile x 16 periods, HIPSOXR_DEBUG_MFMA64_SPLIT)
-    const int units_per_slab = sizeof(Real) == 4 ? 2 * g.n_rt : (f64_pb == 32 && switches().dbg_mfma64_split) ? 2 * g.n_rt : g.n_rt;
+    const int units_per_slab = sizeof(Real) == 4 ? (g.pb / 32) * g.n_rt : (f64_pb == 32 && switches().dbg_mfma64_split) ? 2 * g.n_rt : g.n_rt;
     if (switches().dbg_nrt) { a.n_rt = switches().dbg_nrt; nw = a.n_rt; }
     if (switches().dbg_nw) nw = switches().dbg_nw;
     a.n_waves = nw;
@@ -2353,6 +2395,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         const int64_t wgs = n_blocks * (int64_t)cols;
         // (from two workgroups per CU on, splitting only adds staging: measured 80 vs 92 us on a 60 s stereo clip)
         int split = wgs >= 512 ? 1 : (int)std::min<int64_t>((units_per_slab + 3) / 4, (2 * 3 * 256) / std::max<int64_t>(wgs, 1));
+        if (f32_split) split = f32_split; // (float32: chosen with the slab size above)
         if (switches().dbg_split) split = switches().dbg_split;
         grid.z = (unsigned)std::max(1, split);
         a.xz = 0; a.nx = (int32_t)n_blocks;
