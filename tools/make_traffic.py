@@ -58,6 +58,18 @@ def main(prof_dir, out_path):
         traffic = int((2 * f + w) * 1024)
         rec["workloads"][wl] = {"kernel": sub, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": traffic, "algorithmic_bytes": algo,
                                 "ratio": round(traffic / algo, 4), "valu_wave_insts": v}
+    # configs[2] with the walking channel-pair kernel (experiment build, HIPSOXR_DEBUG_WALK=3): passes pmc5 / pmc6
+    try:
+        p5, p6 = counters(_db(prof_dir, "pmc5")), counters(_db(prof_dir, "pmc6"))
+        sub, algo = "k_fft_strided2<hipsoxr::PairSpec<4410, 1600", WORKLOADS["configs2"][2]
+        f, w = pick(p5, sub, "FETCH_SIZE"), pick(p6, sub, "WRITE_SIZE")
+        if f is not None and w is not None:
+            traffic = int((2 * f + w) * 1024)
+            rec["workloads"]["configs2_walk3"] = {"kernel": sub + " (K = 3, -DFFT_EXPERIMENTS build, HIPSOXR_DEBUG_WALK=3)", "FETCH_SIZE_KiB": f,
+                                                  "WRITE_SIZE_KiB": w, "traffic_bytes": traffic, "algorithmic_bytes": algo,
+                                                  "ratio": round(traffic / algo, 4), "valu_wave_insts": None}
+    except SystemExit:
+        pass
     with open(out_path, "w") as fo:
         json.dump(rec, fo, indent=1)
     print(json.dumps(rec, indent=1))

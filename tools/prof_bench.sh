@@ -13,8 +13,10 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py $ARGS
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python bench.py $SHORT > $OUT/pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- python bench.py $SHORT > $OUT/pmc3.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- python bench.py $SHORT > $OUT/pmc4.log 2>&1
-HIPSOXR_DEBUG_WALK=3 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc5 -o p -- python tools/run_workload.py c2 5 > $OUT/pmc5.log 2>&1
-HIPSOXR_DEBUG_WALK=3 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc6 -o p -- python tools/run_workload.py c2 5 > $OUT/pmc6.log 2>&1
+if [ -f $R/python-soxr_amd/_variants/exp/libhipsoxr.so ]; then # (the walking kernel exists only in -DFFT_EXPERIMENTS builds)
+HIPSOXR_DEBUG_WALK=3 tools/with_variant.sh exp rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc5 -o p -- python tools/run_workload.py c2 5 > $OUT/pmc5.log 2>&1
+HIPSOXR_DEBUG_WALK=3 tools/with_variant.sh exp rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc6 -o p -- python tools/run_workload.py c2 5 > $OUT/pmc6.log 2>&1
+fi
 python tools/pmc_summary.py $OUT/trace/*.db $OUT/pmc*/*.db > $OUT/summary.txt 2>&1
 grep -h '"metric"' $OUT/bench_trace.log > $OUT/bench_line.json
 python tools/make_traffic.py $OUT $OUT/traffic.json > $OUT/traffic.log 2>&1
