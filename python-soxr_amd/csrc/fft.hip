@@ -52,6 +52,7 @@
 //   FFT_STORE_INTERLEAVE  radix-16 passes issue their LDS stores between the four final radix-4 butterflies (slower: +3 %)
 //   FFT_EARLY_TABLES      twiddle / filter table loads one barrier ahead (no gain)
 //   FFT_LDS_DMA           k_fft_pair2 (float32): the input blocks land in LDS by `buffer_load_dwordx4 ... lds`, first pass from LDS
+//   FFT_DIF               k_fft_pair2 (float32, N_in >= N_out): wave-local schedule, 6 workgroup barriers per pair instead of 11 (slower: see dif_local)
 //   FFT_EXPERIMENTS       the looping kernels k_fft_pair2p and k_fft_strided2<.., K > 0> (both slower than what they replace)
 #ifndef FFT_BARRIER_LATE
 #define FFT_BARRIER_EARLY 1
@@ -551,6 +552,7 @@ struct FftArgs {
     int32_t stagger;         // k_fft_pair2p: HIPSOXR_DEBUG_STAGGER
     int32_t walk;            // k_fft_strided2<.., K > 0>: consecutive blocks per workgroup
     int64_t n_blocks_col;    // ... blocks per column
+    const void *HP;          // k_fft_pair2 -DFFT_DIF: per output-grid bin n: [N_out] H (real), then [N_out] LDS byte offsets of the input-grid bin it takes
     const int64_t *clip_tab; // ragged batch (hipsoxr_job_t::clip_table_dev): [n_clips][4] = in offset, in frames, out offset, out frames; k_fft_pair2 only
     int32_t chpair; // paired kernel: 1 = pair neighbouring channels of interleaved data instead of blocks
     int64_t pairs_per_col; // xcd_map: work items (blocks, or pairs of blocks) per channel unit
@@ -717,7 +719,10 @@ template <int NA_, int NB_, int NT_, int A0, int A1, int A2, bool ASWZ, int B0, 
 struct PairSpec {
     static constexpr int NA = NA_, NB = NB_, NT = NT_;
     static constexpr bool prefetch = false;
-    static constexpr int RB0 = B0, RA0 = A0;
+    static constexpr int RB0 = B0, RA0 = A0, RA1 = A1, RA2 = A2, RB1 = B1, RB2 = B2;
+    // the wave-local schedule (k_fft_pair2 under -DFFT_DIF, see dif_local) needs every sub-transform inside one wave
+    static constexpr bool dif = (64 / (A1 > A2 ? A1 : A2)) * (NT / 64) >= A0 && (64 / (B1 > B2 ? B1 : B2)) * (NT / 64) >= B0 &&
+                                A1 * A2 <= NT && B1 * B2 <= NT;
     struct Tw {};
     template <typename C, typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st, bool in_lds, const Tw &)
     { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ>(FFT_STAMP_ARGS b, W, ld, st, in_lds); }
@@ -754,32 +759,30 @@ typedef PairSpec4<2560, 2352, 512, 5, 8, 8, 8, 6, 7, 7, 8> Pair2560x2352L; // lo
 // Three-pass schedule of each transform length in use (first radix 21: conflict-free as it is;
 // first radix 16: swizzled layout between pass 1 and 2).
 template <int N> struct Sched;
-#define HIPSOXR_SCHED(N, r0, r1, r2, swz) \
-    template <> struct Sched<N> { static constexpr int R0 = r0, R1 = r1, R2 = r2; static constexpr bool SWZ = swz; }
-HIPSOXR_SCHED(7056, 21, 16, 21, false);
-HIPSOXR_SCHED(5376, 21, 16, 16, false);
-HIPSOXR_SCHED(5120, 16, 16, 20, true);
-HIPSOXR_SCHED(4704, 21, 16, 14, false);
 #ifdef FFT_EXPERIMENTS
-HIPSOXR_SCHED(4410, 15, 14, 21, false); // (first radix 15: 4410 / 15 = 294 divides the 3528-frame hop of the 44.1k -> 16k blocks — k_fft_strided2's walk)
+#define HIPSOXR_SCHED_4410(X) X(4410, 15, 14, 21, false) // (first radix 15: 4410 / 15 = 294 divides the 3528-frame hop of the 44.1k -> 16k blocks — k_fft_strided2's walk)
 #else
-HIPSOXR_SCHED(4410, 21, 14, 15, false); // (the order the product runs: configs[2] 47 us, against 52 us with the radix-15 pass first)
+#define HIPSOXR_SCHED_4410(X) X(4410, 21, 14, 15, false) // (the order the product runs: configs[2] 47 us, against 52 us with the radix-15 pass first)
 #endif
-HIPSOXR_SCHED(4096, 16, 16, 16, true);
-HIPSOXR_SCHED(3840, 16, 16, 15, true);
-HIPSOXR_SCHED(3584, 14, 16, 16, false);
-HIPSOXR_SCHED(3528, 21, 12, 14, false);
-HIPSOXR_SCHED(2688, 21, 16, 8, false);
-HIPSOXR_SCHED(2560, 16, 16, 10, true);
-HIPSOXR_SCHED(2352, 21, 16, 7, false);
-HIPSOXR_SCHED(2048, 16, 16, 8, true);
-HIPSOXR_SCHED(1792, 7, 16, 16, false);
-HIPSOXR_SCHED(1024, 16, 8, 8, true);
-HIPSOXR_SCHED(1600, 16, 10, 10, true);
-HIPSOXR_SCHED(1280, 5, 16, 16, false);
-HIPSOXR_SCHED(1176, 21, 8, 7, false);
-HIPSOXR_SCHED(896, 7, 16, 8, false);
+#define HIPSOXR_SCHED_LIST(X)                                                                                        \
+    X(7056, 21, 16, 21, false) X(5376, 21, 16, 16, false) X(5120, 16, 16, 20, true) X(4704, 21, 16, 14, false)       \
+    HIPSOXR_SCHED_4410(X) X(4096, 16, 16, 16, true) X(3840, 16, 16, 15, true) X(3584, 14, 16, 16, false)             \
+    X(3528, 21, 12, 14, false) X(2688, 21, 16, 8, false) X(2560, 16, 16, 10, true) X(2352, 21, 16, 7, false)         \
+    X(2048, 16, 16, 8, true) X(1792, 7, 16, 16, false) X(1024, 16, 8, 8, true) X(1600, 16, 10, 10, true)             \
+    X(1280, 5, 16, 16, false) X(1176, 21, 8, 7, false) X(896, 7, 16, 8, false)
+#define HIPSOXR_SCHED(N, r0, r1, r2, swz) \
+    template <> struct Sched<N> { static constexpr int R0 = r0, R1 = r1, R2 = r2; static constexpr bool SWZ = swz; };
+HIPSOXR_SCHED_LIST(HIPSOXR_SCHED)
 #undef HIPSOXR_SCHED
+static bool sched_of(int n, int *r0, int *r1, int *r2) // the same table at run time (host: fft_build's tables for -DFFT_DIF)
+{
+    switch (n) {
+#define HIPSOXR_SCHED(N, a0, a1, a2, swz) case N: *r0 = a0; *r1 = a1; *r2 = a2; return true;
+        HIPSOXR_SCHED_LIST(HIPSOXR_SCHED)
+#undef HIPSOXR_SCHED
+    default: return false;
+    }
+}
 template <int NA, int NB, int NT>
 using PairOf = PairSpec<NA, NB, NT, Sched<NA>::R0, Sched<NA>::R1, Sched<NA>::R2, Sched<NA>::SWZ, Sched<NB>::R0, Sched<NB>::R1,
                         Sched<NB>::R2, Sched<NB>::SWZ>;
@@ -954,6 +957,140 @@ __device__ __forceinline__ void buf_store_real(double v, __amdgpu_buffer_rsrc_t 
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), r, voff, 0, 0);
 }
 // per-precision views of the kernel arguments
+#ifdef FFT_DIF
+// ---------------------------------------------------------------------------------------------
+// Wave-local schedule (round 3 experiment, -DFFT_DIF).  The three Stockham passes of fft_ct3 are three all-to-all
+// exchanges through LDS, each fenced by workgroup barriers (11 per block pair; the batch launch's waves spend 49 % of
+// their cycles parked at them).  Decimation in FREQUENCY instead: the first pass (radix R0 over elements S = R1 R2
+// apart, one butterfly per thread, its inputs straight from HBM or — inverse — from the spectrum) leaves R0 independent
+// S-point transforms, each contiguous in LDS.  A sub-transform is given to GL = max(R1, R2) lanes of ONE wave, so its
+// two remaining passes exchange data only between lanes of that wave: no workgroup barrier, only the LDS queue's own
+// ordering — waves drift apart and one wave's butterflies overlap another's LDS traffic.  6 barriers per pair.
+//   first pass : thread j < S: u[t] = in[j + S t]; DFT_R0; L[k0 S + j] = u[k0]
+//   sub-transform k0, lane n < R2: u[t] = Ls[n + R2 t] W_N^((n + R2 t) k0); DFT_R1; u[k1] *= W_S^(n k1); Ls[k1 R2 + n] = u[k1]
+//                     lane k1 < R1: u[n] = Ls[k1 R2 + n]; DFT_R2 -> u[k2] = X[R0 (R1 k2 + k1) + k0]
+// The forward transform leaves bin (k0, k1, k2) at L[k0 S + ((k1 + k0) % R1) R2 + k2] — rows rotated by k0, so that the
+// inverse's first pass (consecutive lanes = consecutive bins = consecutive k0) does not read 16 lanes from one bank —
+// and the inverse's first pass finds it through a table (FftArgs::HP: filter value and byte offset per output-grid bin:
+// one 8-byte load instead of the |frequency| index arithmetic).
+// ---------------------------------------------------------------------------------------------
+template <int R, typename C> __device__ __forceinline__ void tw_apply(C *u, C w1, C w4) // u[k] *= w1^k (w4 = w1^4 from the table, see fft_pass_ct)
+{
+    C pw[R];
+    pw[1] = w1;
+    if constexpr (R >= 10) {
+#pragma unroll
+        for (int t = 2; t < R; ++t) {
+            const int a4 = t / 4, b4 = t % 4;
+            if (a4 == 0) pw[t] = cmul(pw[t - 1], w1);
+            else if (b4 == 0) pw[t] = a4 == 1 ? w4 : (a4 % 2 == 0 ? cmul(pw[t / 2], pw[t / 2]) : cmul(pw[t - 4], w4));
+            else pw[t] = cmul(pw[4 * a4], pw[b4]);
+        }
+    } else {
+#pragma unroll
+        for (int t = 2; t < R; ++t) pw[t] = (t & 1) ? cmul(pw[t - 1], w1) : cmul(pw[t / 2], pw[t / 2]);
+    }
+#pragma unroll
+    for (int t = 1; t < R; ++t) u[t] = cmul(u[t], pw[t]);
+}
+template <int N, int R0, int S, int SIGN, int NT, bool SYNC, typename C, typename Load>
+__device__ __forceinline__ void dif_first(C *L, const C *W, Load load)
+{
+    static_assert(R0 * S == N && S <= NT, "first pass: one butterfly per thread");
+    const int j = fft_tid();
+    const bool act = S == NT || j < S;
+    C u[R0];
+    (void)W;
+    if (act) {
+#pragma unroll
+        for (int t = 0; t < R0; ++t) u[t] = load(j + S * t, t);
+    }
+    if (SYNC) __syncthreads(); // in place: every thread holds its inputs
+    if (act) {
+        dft_r<R0, SIGN>(u); // (its twiddles W_N^(j k0) wait for the sub-transform's loads: outputs go straight to LDS)
+#pragma unroll
+        for (int k = 0; k < R0; ++k) L[k * S + j] = u[k];
+    }
+}
+// the two wave-local passes; `out(k0, k1, k2, value)` takes the results (LASTSYNC: behind a workgroup barrier — they go
+// to places other waves still read).  Table values are fetched by dif_local_pre, which the caller runs IN FRONT of the
+// workgroup barrier before the sub-transforms (the first pass's registers are free by then: the loads fly while the
+// workgroup gathers).  Rows of R2 = 0 (mod 4) points start 8 rows apart in the same bank: such rows swap neighbouring
+// columns in their upper half (column c of row r at c ^ ((r >> 3) & 1); dif_col) — two lane bases, no index arithmetic.
+template <int R0, int R1, int R2, int NT> struct DifLane {
+    static constexpr int GL = R1 > R2 ? R1 : R2, GPW = 64 / GL;
+    int li, g;
+    bool act;
+    __device__ __forceinline__ DifLane()
+    {
+        const int tid = fft_tid(), lane = tid & 63, wave = tid >> 6;
+        const int gl = lane / GL;
+        li = lane - gl * GL;
+        g = wave * GPW + gl;
+        act = gl < GPW && g < R0;
+    }
+};
+template <int R2> __host__ __device__ constexpr bool dif_swz() { return R2 % 4 == 0; }
+template <typename C, int R1> struct DifPre { C f[R1]; C w1, w4; };
+template <int N, int R0, int R1, int R2, int NT, typename C>
+__device__ __forceinline__ void dif_local_pre(const C *W, DifPre<C, R1> &p)
+{
+    const DifLane<R0, R1, R2, NT> ln;
+    if (ln.act && ln.li < R2) {
+        // the first pass's twiddle of element n' = li + R2 t of sub-transform g: W_N^(n' g), straight from the table
+        // (n' g < S R0 = N: no reduction)
+        const C *Wg = W + ln.li * ln.g;
+#pragma unroll
+        for (int t = 0; t < R1; ++t) p.f[t] = Wg[(R2 * t) * ln.g];
+        p.w1 = W[R0 * ln.li];
+        p.w4 = R1 >= 10 ? W[4 * R0 * ln.li] : p.w1;
+    }
+}
+template <int N, int R0, int R1, int R2, int SIGN, int NT, bool LASTSYNC, typename C, typename Out>
+__device__ __forceinline__ void dif_local(C *L, const DifPre<C, R1> &p, Out out)
+{
+    constexpr int S = R1 * R2;
+    constexpr bool XS = dif_swz<R2>();
+    static_assert(R0 * S == N && DifLane<R0, R1, R2, NT>::GPW * (NT / 64) >= R0, "sub-transforms per wave");
+    const DifLane<R0, R1, R2, NT> ln;
+    const int li = ln.li, g = ln.g;
+    C *Ls = L + g * S;
+    {
+        C u[R1];
+        if (ln.act && li < R2) {
+#pragma unroll
+            for (int t = 0; t < R1; ++t) u[t] = Ls[li + R2 * t]; // (first-pass layout: no swizzle)
+#pragma unroll
+            for (int t = 0; t < R1; ++t) u[t] = cmul(u[t], p.f[t]);
+            dft_r<R1, SIGN>(u);
+            tw_apply<R1>(u, p.w1, p.w4);
+            C *lo = Ls + li, *hi = Ls + (XS ? li ^ 1 : li);
+#pragma unroll
+            for (int k = 0; k < R1; ++k) (((k >> 3) & 1) ? hi : lo)[k * R2] = u[k];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        C u[R2];
+        const bool a3 = ln.act && li < R1;
+        if (a3) {
+            const int sx = XS ? (li >> 3) & 1 : 0;
+            const C *ev = Ls + li * R2 + sx, *od = Ls + li * R2 - sx;
+#pragma unroll
+            for (int n = 0; n < R2; ++n) u[n] = ((n & 1) ? od : ev)[n];
+            dft_r<R2, SIGN>(u);
+        }
+        if (LASTSYNC) __syncthreads();
+        if (a3) {
+#pragma unroll
+            for (int k = 0; k < R2; ++k) out(g, li, k, u[k]);
+        }
+    }
+}
+#endif
+
 template <typename Real> struct PairTabs;
 template <> struct PairTabs<float> {
     typedef float2 C; typedef float4 V16;
@@ -1014,6 +1151,72 @@ __device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem
 #endif
     typename Spec::Tw tw;
 
+    const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
+    IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
+    // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
+    const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
+#ifdef FFT_DIF
+    constexpr bool kDif = Spec::dif && sizeof(Real) == 4 && sizeof(IO) == 4 && NA >= NB; // (NA < NB: bins beyond the input band would have to read zeros)
+#else
+    constexpr bool kDif = false;
+#endif
+    if constexpr (kDif) {
+#ifdef FFT_DIF
+        // wave-local schedule (dif_first / dif_local): 6 workgroup barriers per pair instead of 11
+        constexpr int A0 = Spec::RA0, A1 = Spec::RA1, A2 = Spec::RA2, B0 = Spec::RB0, B1 = Spec::RB1, B2 = Spec::RB2;
+        constexpr int SA = A1 * A2, SB = B1 * B2;
+        if (ina >= 0) {
+            const int64_t left = (in_frames - ina) * ES;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                uniform_ptr((void *)(xin + ina)), 0, __builtin_amdgcn_readfirstlane((int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left)), 0x00020000);
+            dif_first<NA, A0, SA, -1, NT, false>(cur, PairTabs<Real>::wa(a), [&](int n, int t) -> C {
+                const int j4 = (n - t * SA) * ES;
+                return C((Real)buf_load_real<IO>(rs, j4, t * SA * ES), (Real)buf_load_real<IO>(rs, j4, (t * SA + hop_in) * ES));
+            });
+        } else {
+            const int64_t inb = ina + hop_in;
+            dif_first<NA, A0, SA, -1, NT, false>(cur, PairTabs<Real>::wa(a), [&](int n, int) -> C {
+                const int64_t la = ina + n, lb = inb + n;
+                return C((la >= 0 && la < in_frames) ? (Real)xin[la] : (Real)0, (lb >= 0 && lb < in_frames) ? (Real)xin[lb] : (Real)0);
+            });
+        }
+        FFT_STAMP();
+        {
+            DifPre<C, A1> pre;
+            dif_local_pre<NA, A0, A1, A2, NT>(PairTabs<Real>::wa(a), pre);
+            __syncthreads();
+            FFT_STAMP();
+            // the filter rides on the forward transform's last stores (20 consecutive values per lane: five 16-byte loads)
+            const float *HF = reinterpret_cast<const float *>(a.HP) + NB;
+            dif_local<NA, A0, A1, A2, -1, NT, false>(cur, pre, [&](int g, int li, int k, C v) {
+                const float h = HF[(g * A1 + li) * A2 + k];
+                const int row = (li + g) % A1; // rows rotated by the sub-transform's index (see the inverse's loads)
+                const int sx = dif_swz<A2>() ? (row >> 3) & 1 : 0;
+                cur[g * SA + row * A2 + ((k & 1) ? k - sx : k + sx)] = C(v.x * h, v.y * h);
+            });
+        }
+        const uint32_t *HPo = reinterpret_cast<const uint32_t *>(a.HP);
+        FFT_STAMP();
+        __syncthreads();
+        FFT_STAMP();
+        dif_first<NB, B0, SB, +1, NT, true>(cur, PairTabs<Real>::wb(a), [&](int n, int) -> C {
+            return *reinterpret_cast<const C *>(smem_raw + HPo[n]);
+        });
+        FFT_STAMP();
+        DifPre<C, B1> preb;
+        dif_local_pre<NB, B0, B1, B2, NT>(PairTabs<Real>::wb(a), preb);
+        __syncthreads();
+        FFT_STAMP();
+        dif_local<NB, B0, B1, B2, +1, NT, true>(cur, preb, [&](int g, int li, int k, C w) {
+            const int m = B0 * (B1 * k + li) + g; // local output index
+            if (m >= v0 && m < v1) {
+                stage[m - v0 + sh] = (IO)w.x;
+                stage[m - v0 + sh + hop_out] = (IO)w.y;
+            }
+        });
+        FFT_STAMP();
+#endif
+    } else {
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
 #ifdef FFT_LDS_DMA
     // Experiment (round 3, measured slower — profiles/r03_ab_experiments.txt): the two blocks land in LDS by DMA
@@ -1084,10 +1287,6 @@ __device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem
     FFT_STAMP();
 
     // ---- inverse (see k_fft_pair), last pass into the staging layout -------------------------------
-    const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
-    IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
-    // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
-    const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
     auto h_load = [&](int n, int t) -> C { // bin n of the output grid <- bin n or n + NA - NB of the input grid, times (real) H
         const bool neg = n > NB / 2;
         const int q = neg ? NB - n : n; // |frequency| in bins
@@ -1113,6 +1312,7 @@ __device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem
             stage[n - v0 + sh + hop_out] = (IO)w.y;
         }
     });
+    } // (!kDif)
     staged();
     __syncthreads();
     FFT_STAMP();
@@ -1501,7 +1701,7 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_
     if (force_k && 2 * (int64_t)g.hop_out < g.N_out) { *out = g; return nullptr; }
 
     const int A = g.A, B = g.B;
-    std::vector<float2> tab((size_t)A + B + (A + 1) + B + (B + 1) + g.N_in + g.N_out + (B + 2) / 2 + 1);
+    std::vector<float2> tab((size_t)A + B + (A + 1) + B + (B + 1) + g.N_in + g.N_out + (B + 2) / 2 + 1 + (g.N_out + g.N_in) / 2 + 2 /* HP (-DFFT_DIF) */);
     float2 *WA = tab.data(), *WB = WA + A, *P = WB + B, *Q = P + (A + 1), *Hs = Q + B;
     float2 *WA2 = Hs + (B + 1), *WB2 = WA2 + g.N_in;
     for (int m = 0; m < g.N_in; ++m) WA2[m] = make_float2((float)std::cos(6.283185307179586476925286766559 * m / g.N_in), (float)-std::sin(6.283185307179586476925286766559 * m / g.N_in));
@@ -1538,6 +1738,28 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_
         reinterpret_cast<float *>(WB2 + g.N_out)[q] = (float)(hr * scale);
         hr64[q] = hr * scale;
     }
+#ifdef FFT_DIF
+    { // k_fft_pair2's wave-local schedule: per output-grid bin n the filter value and the LDS byte offset of the input-grid
+      // bin it takes, in the layout the forward transform leaves (dif_local: rows rotated by the sub-transform index)
+        int r0 = 0, r1 = 0, r2 = 0;
+        if (sched_of(g.N_in, &r0, &r1, &r2)) {
+            uint32_t *hpo = reinterpret_cast<uint32_t *>(WB2 + g.N_out + (B + 2) / 2 + 1);
+            float *hf = reinterpret_cast<float *>(hpo) + g.N_out;
+            const float *hrf = reinterpret_cast<const float *>(WB2 + g.N_out);
+            const int NA = g.N_in, NB = g.N_out;
+            auto nat = [&](int k) { return ((k % r0) * r1 + (k / r0) % r1) * r2 + k / (r0 * r1); }; // (k0, k1, k2) order: what a lane of the last forward pass holds
+            for (int k = 0; k < NA; ++k) hf[nat(k)] = 0.f;
+            for (int n = 0; n < NB && NA >= NB; ++n) {
+                const bool neg = n > NB / 2;
+                const int q = neg ? NB - n : n, k = neg ? n + (NA - NB) : n;
+                const int k0 = k % r0, k1 = (k / r0) % r1, k2 = k / (r0 * r1);
+                hf[nat(k)] = hrf[q];
+                const int row = (k1 + k0) % r1, sx = (r2 % 4 == 0) ? (row >> 3) & 1 : 0;
+                hpo[n] = (uint32_t)((k0 * r1 * r2 + row * r2 + (k2 ^ sx)) * sizeof(float2));
+            }
+        }
+    }
+#endif
     HIP_TRY(hipMalloc((void **)&g.dev, tab.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(g.dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
     { // the float64 instance's tables (small: N_in + N_out + B/2 double2)
@@ -1698,7 +1920,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.in = j.in; a.out = j.out;
                 a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
                 a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
-                a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
+                a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.HP = a.WB2 + g.N_out + (g.B + 2) / 2 + 1; a.trace = nullptr;
                 a.WA2d = g.devd; a.WB2d = g.devd + g.N_in; a.Hrd = reinterpret_cast<const double *>(g.devd + g.N_in + g.N_out);
                 a.A = g.A; a.B = g.B; a.nA = a.nB = 0;
                 for (int i = 0; i < 8; ++i) a.radA[i] = a.radB[i] = 1;
@@ -1858,7 +2080,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.in = j.in; a.out = j.out;
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
-    a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
+    a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.HP = a.WB2 + g.N_out + (g.B + 2) / 2 + 1; a.trace = nullptr;
     a.WA2d = a.WB2d = nullptr; a.Hrd = nullptr; a.clip_tab = nullptr; a.queue = nullptr; a.n_items = 0; a.stagger = 0;
     a.walk = 1; a.n_blocks_col = 0;
     a.A = g.A; a.B = g.B; a.nA = g.nA; a.nB = g.nB;

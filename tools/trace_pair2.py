@@ -31,6 +31,9 @@ life = end.max(axis=1) - start.min(axis=1)
 print("workgroup lifetime (cycles/100) median %.2f  p10 %.2f  p90 %.2f" % tuple(np.percentile(life, [50, 10, 90]) / 100))
 names = ["F1(load+bfly+st)", "bar", "F2", "bar", "F3", "bar", "I1", "bar", "I2", "bar", "I3+stage", "bar", "store-out"]
 idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15]
+if os.environ.get("DIF"):  # -DFFT_DIF -DFFT2_TRACE build: stamps 0 start, 1 first pass + barrier, 2 local passes + barrier, 3 inverse first pass + barrier, 4 local + staging + barrier, 15 end
+    names = ["F1", "bar", "F-local", "bar", "I1(incl. its barrier)", "bar", "I-local(+barrier+staging)", "bar", "store-out"]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 15]
 mid = t[t.shape[0] // 4: 3 * t.shape[0] // 4]          # steady state: the middle half of the launch
 for w in range(NW):
     seg = np.diff(mid[:, w, idx], axis=1)
