@@ -1151,17 +1151,14 @@ __device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem
 #endif
     typename Spec::Tw tw;
 
+#ifdef FFT_DIF
+    // (experiment builds only: in the product the three definitions below stand where the inverse transform starts —
+    //  hoisting them costs the plain kernel 2-4 %)
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
-    IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
-    // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
+    IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0);
     const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
-#ifdef FFT_DIF
     constexpr bool kDif = Spec::dif && sizeof(Real) == 4 && sizeof(IO) == 4 && NA >= NB; // (NA < NB: bins beyond the input band would have to read zeros)
-#else
-    constexpr bool kDif = false;
-#endif
     if constexpr (kDif) {
-#ifdef FFT_DIF
         // wave-local schedule (dif_first / dif_local): 6 workgroup barriers per pair instead of 11
         constexpr int A0 = Spec::RA0, A1 = Spec::RA1, A2 = Spec::RA2, B0 = Spec::RB0, B1 = Spec::RB1, B2 = Spec::RB2;
         constexpr int SA = A1 * A2, SB = B1 * B2;
@@ -1215,8 +1212,8 @@ __device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem
             }
         });
         FFT_STAMP();
-#endif
     } else {
+#endif
     // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
 #ifdef FFT_LDS_DMA
     // Experiment (round 3, measured slower — profiles/r03_ab_experiments.txt): the two blocks land in LDS by DMA
@@ -1287,6 +1284,12 @@ __device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem
     FFT_STAMP();
 
     // ---- inverse (see k_fft_pair), last pass into the staging layout -------------------------------
+#ifndef FFT_DIF
+    const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
+    IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
+    // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
+    const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
+#endif
     auto h_load = [&](int n, int t) -> C { // bin n of the output grid <- bin n or n + NA - NB of the input grid, times (real) H
         const bool neg = n > NB / 2;
         const int q = neg ? NB - n : n; // |frequency| in bins
@@ -1312,7 +1315,9 @@ __device__ __forceinline__ bool pair2_item(const FftArgs &a, unsigned char *smem
             stage[n - v0 + sh + hop_out] = (IO)w.y;
         }
     });
+#ifdef FFT_DIF
     } // (!kDif)
+#endif
     staged();
     __syncthreads();
     FFT_STAMP();
