@@ -582,11 +582,13 @@ static const char *stream_compact(hipsoxr_stream *s, size_t want_cap)
 static const char *stream_append(hipsoxr_stream *s, const void *in, size_t ilen)
 {
     const size_t bytes_in = ilen * s->ch * esz(s);
-    if (!s->split && !s->ring_on_host && !s->d_in && s->n_in_total == 0 && bytes_in <= kHostRingChunk &&
-        !switches().no_host_ring) {
-        // first chunk of a stream that owns no device ring yet, and a small one: ring in pinned host memory
-        // (a stream that inherited a device ring from the pool keeps it; finished streams hand their ring,
-        // of either kind, back to the pool)
+    if (!s->split && !s->ring_on_host && s->n_in_total == 0 && bytes_in <= kHostRingChunk && !switches().no_host_ring) {
+        // first chunk of a stream, and a small one: ring in pinned host memory.  A DEVICE ring inherited from the
+        // pool (the stream before this one fed large chunks) is given up for it: keeping it cost every later
+        // small-chunk stream of the process the host ring and with it the resident kernel — 441-frame calls 23 us
+        // instead of 15 (round 3; finished streams hand their ring, of either kind, back to the pool)
+        if (s->d_in) { (void)hipFree(s->d_in); s->d_in = nullptr; s->in_cap = 0; }
+        if (s->d_in_alt) { (void)hipFree(s->d_in_alt); s->d_in_alt = nullptr; s->alt_cap = 0; }
         s->ring_on_host = true;
     }
     if (s->ring_on_host) {
@@ -939,7 +941,7 @@ static const char *stream_process_deferred(hipsoxr_stream *s, const void *in, si
         if (s->ended) return "Input after last input";
         const int b = (int)(s->calls & 1);
         const size_t bytes = ilen * frame;
-        if (s->ring_on_host || (!s->d_in && s->n_in_total == 0 && bytes <= kHostRingChunk && !switches().no_host_ring)) {
+        if (s->ring_on_host || ((!s->split || !s->d_in) && s->n_in_total == 0 && bytes <= kHostRingChunk && !switches().no_host_ring)) {
             if (const char *e = stream_append(s, in, ilen)) return e; // host ring: a memcpy, nothing in flight to protect
         } else if (bytes <= kPinnedMax && (!s->ev_src[b] || hipEventSynchronize(s->ev_src[b]) == hipSuccess) &&
                    !pinned_ensure(&s->h_src[b], &s->h_src_bytes[b], bytes)) {
