@@ -1904,6 +1904,7 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab, int var
     }
     i_min = floor4(i_min); i_max = floor4(i_max) + 3; // slab = whole quads (vectorised staging)
     g.i_min = i_min;
+    g.span = i_max - i_min + 1;
     // periods per slab: 64 (one per lane); the VALU kernel also runs with 32 or 16 (the other lanes idle) when the
     // slab would not fit — float64 at 44.1k -> 16k: 64 x 441 x 8 B = 226 KB — which still beats one lane per output
     // walking T dependent loads by 5x (60 s mono int32: 1015 us on k_gather)
@@ -2340,6 +2341,19 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
             g.lds_bytes = ((size_t)g.plane * 4 + g.rowR) * sizeof(Real);
         }
     }
+    // float32 MFMA kernel in its general form (k_tile_mfma: input periods that are no multiple of 16, e.g. 44.1k -> 16k):
+    // a job of few 64-period slabs — a 96 000-frame stream chunk is four — runs on 16-period ones: four times as many
+    // workgroups, each staging a quarter and walking a chain a quarter as long (one wave does a row tile x ALL the
+    // slab's periods, and its ~880 k-steps cost the same whether they feed four MFMAs or one: the chain is bound by its
+    // per-step address arithmetic).  96 000-frame chunk, int16 44.1k -> 16k: kernel 53.6 -> 26.5 us, the stream call 108 -> 81 us.
+    if (sizeof(Real) == 4 && g.variant == 1 && !switches().dbg_slab64) {
+        const int64_t periods = (j.out_k0 + j.out_frames - 1) / g.Lc - j.out_k0 / g.Lc + 1;
+        if ((periods + 63) / 64 * (int64_t)j.n_clips * j.n_channels < 128) {
+            g.pb = 16;
+            g.x_count = ((g.pb - 1) * (int32_t)g.Mc + g.span + 3) / 4 * 4;
+            g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / g.Mc + 1) + 8) * sizeof(Real);
+        }
+    }
     TileArgs a;
     a.in = j.in; a.out = j.out;
     a.tab = g.variant >= 1 ? d.tile_tab_m : d.tile_tab;
@@ -2381,7 +2395,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     // (HIPSOXR_DEBUG_* are timing experiments only; results may be wrong when they are set)
     void (*kern)(TileArgs) = g.aligned ? k_tile<IO, Real, 16, true> : k_tile<IO, Real, 16, false>;
     if constexpr (sizeof(Real) == 4) {
-        if (g.variant == 1) kern = k_tile_mfma<IO>;
+        if (g.variant == 1) kern = g.pb == 64 ? k_tile_mfma<IO, float, 4> : g.pb == 32 ? k_tile_mfma<IO, float, 2> : k_tile_mfma<IO, float, 1>;
         if (g.variant == 2) kern = k_tile_mfma_p<IO>;
     } else {
         if (g.variant == 1) kern = g.pb == 64 ? k_tile_mfma<IO, double, 4> : g.pb == 32 ? k_tile_mfma<IO, double, 2> : k_tile_mfma<IO, double, 1>;
