@@ -61,7 +61,7 @@ const Switches &switches()
         w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_persist = on("HIPSOXR_FFT_PERSIST"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY"); w.fft_small_4pass = on("HIPSOXR_FFT_SMALL_4PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
-        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32");
+        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_stagger = num("HIPSOXR_DEBUG_STAGGER"); w.dbg_walk = num("HIPSOXR_DEBUG_WALK"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.no_auto_resident = on("HIPSOXR_NO_AUTO_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
@@ -984,6 +984,7 @@ struct TileArgs {
     // same input; consecutive ids go to different XCDs (private L2s), so they are laid out as
     // id = 8*(chunk*Z + z) + xcd  <->  slab = 8*chunk + xcd: same XCD, adjacent in dispatch order.
     int32_t xz, nx;      // Z (0: plain 3-D grid), number of slabs
+    int32_t halves, scratch_off; // k_tile_mfma: a row tile's two half-chains on two waves (sum through LDS at scratch_off, in elements)
 };
 
 // Stage the input slab of one workgroup: samples [bw*Mc + i_min, +x_count) of column (clip, ch)
@@ -1238,8 +1239,20 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
     const bool interior = bw * a.Lc >= a.out_k0 && (bw + 16 * NG) * a.Lc <= a.out_k0 + a.out_frames;
     IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
 
-    for (int rt_ = wave < n_waves ? wave + n_waves * (int)blockIdx.z : a.n_rt; rt_ < a.n_rt; rt_ += n_waves * (int)gridDim.z) { // (gridDim.z: see k_tile)
-        const int rt = __builtin_amdgcn_readfirstlane(rt_);
+    // Small jobs (a.halves, round 3): a row tile's left and right half-chains run on TWO waves — a chain of ~440 k-steps
+    // is bound by its per-step address arithmetic, whatever the number of MFMAs it feeds, and the two halves are
+    // independent until their sum — and meet through LDS: wave 2p writes its accumulators, the workgroup synchronises,
+    // wave 2p + 1 adds its own (left + right, as ever) and stores.  Every wave then runs the same number of rounds.
+    const bool halves = a.halves != 0;
+    const int units = halves ? n_waves >> 1 : n_waves;           // row tiles per round of this workgroup
+    const int pw = halves ? wave >> 1 : wave, side = halves ? wave & 1 : 2; // side 0: left half, 1: right half, 2: both
+    const int stride_rt = units * (int)gridDim.z;
+    const int rounds = halves ? (a.n_rt + stride_rt - 1) / stride_rt : 0;
+    Real *const scratch = xs + a.scratch_off;
+    int round = 0;
+    for (int rt_ = wave < n_waves ? pw + units * (int)blockIdx.z : a.n_rt; halves ? round < rounds : rt_ < a.n_rt; rt_ += stride_rt, ++round) { // (gridDim.z: see k_tile)
+        const bool active = rt_ < a.n_rt;
+        const int rt = __builtin_amdgcn_readfirstlane(active ? rt_ : 0);
         const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]);
         const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
         const size_t half_stride = (size_t)(a.I_h + 16) * 16; // + 4 chunks of prefetch slack
@@ -1254,7 +1267,7 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
         // opaque so that the compiler cannot fold the software pipeline back into load-then-use.
         constexpr int G = 4; // n_chunks is a multiple of G (host geometry); tables carry G chunks of slack
         // left half-chain: lane k handles input e = eL0 + 4q + k (ascending)
-        {
+        if (active && side != 1) {
             int32_t e = eL0 + kq;
             int32_t off = e + pad * (e / Mc), next = (e / Mc + 1) * Mc;
             int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
@@ -1284,7 +1297,7 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
         }
         // right half-chain: chunk q covers inputs [eR0 - 4q, eR0 - 4q + 3]; lane k takes the
         // (3-k)-th of them, so that k = 0 is the highest index (descending order)
-        {
+        if (active && side != 0) {
             int32_t e = eR0 + 3 - kq;
             int32_t off = e + pad * (e / Mc), lo = (e / Mc) * Mc;
             int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
@@ -1311,6 +1324,21 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
 #pragma unroll
                 for (int u = 0; u < G; ++u) ac[u] = an[u];
             }
+        }
+        if (halves) { // the left half's accumulators to the wave that holds the right half
+            if (round) __syncthreads(); // (the scratch of the round before has been read)
+            if (active && side == 0) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) scratch[((pw * NG + g) * 4 + v) * 64 + lane] = accL[g][v];
+            }
+            __syncthreads();
+            if (!active || side == 0) continue;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) accL[g][v] = scratch[((pw * NG + g) * 4 + v) * 64 + lane];
         }
         // lane holds rows rt*16 + row(kq, v) (v = 0..3; f32: 4 kq + v, f64: kq + 4 v) of periods bw + 16g + j
         const int32_t rbase = rt * 16;
@@ -2402,6 +2430,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         if (g.variant == 2) kern = f64_pb == 16 ? k_tile_mfma64_p<IO, 1, 16> : switches().dbg_mfma64_split ? k_tile_mfma64_p<IO, 1, 32> : k_tile_mfma64_p<IO, 2, 32>;
     }
     a.rowR = g.rowR; a.plane = g.plane;
+    a.halves = 0; a.scratch_off = 0;
     dim3 grid((unsigned)n_blocks, (unsigned)cols, 1), block(64 * nw);
     if (g.variant == 2) {
         // few slabs (e.g. one 60 s mono clip = 282): spread each slab's 2*n_rt units over up to
@@ -2432,6 +2461,16 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
             nw = per_wg; a.n_waves = nw;
             block = dim3((unsigned)std::max(256, 64 * per_wg)); // (at least four waves stage the slab)
             grid.z = (unsigned)((g.n_rt + per_wg - 1) / per_wg);
+        }
+        // small float32 jobs on 16-period slabs: a row tile's two half-chains on two waves (k_tile_mfma, a.halves)
+        if (sizeof(Real) == 4 && g.variant == 1 && g.pb == 16 && g_in.pb != 16 && !switches().dbg_nw && !switches().dbg_nrt && !switches().no_halves) {
+            const int want = (int)grid.z > 1 ? nw : g.n_rt, parts = (want + 7) / 8;
+            const int per_wg = (want + parts - 1) / parts; // row tiles per workgroup (at most 8: two waves each), evenly
+            nw = 2 * per_wg; a.n_waves = nw; a.halves = 1;
+            block = dim3((unsigned)std::max(256, 64 * nw));
+            grid.z = (unsigned)((g.n_rt + per_wg - 1) / per_wg);
+            a.scratch_off = (int32_t)((g.lds_bytes / sizeof(Real) + 63) / 64 * 64);
+            g.lds_bytes = ((size_t)a.scratch_off + (size_t)per_wg * (g.pb / 16) * 4 * 64) * sizeof(Real);
         }
     }
     size_t lds_bytes = g.lds_bytes;
