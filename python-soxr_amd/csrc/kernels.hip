@@ -2374,7 +2374,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     // workgroups, each staging a quarter and walking a chain a quarter as long (one wave does a row tile x ALL the
     // slab's periods, and its ~880 k-steps cost the same whether they feed four MFMAs or one: the chain is bound by its
     // per-step address arithmetic).  96 000-frame chunk, int16 44.1k -> 16k: kernel 53.6 -> 26.5 us, the stream call 108 -> 81 us.
-    if (sizeof(Real) == 4 && g.variant == 1 && !switches().dbg_slab64) {
+    if (g.variant == 1 && g.pb > 16 && !switches().dbg_slab64) { // (float64 too: k_tile_mfma<IO, double, 1>)
         const int64_t periods = (j.out_k0 + j.out_frames - 1) / g.Lc - j.out_k0 / g.Lc + 1;
         if ((periods + 63) / 64 * (int64_t)j.n_clips * j.n_channels < 128) {
             g.pb = 16;
@@ -2463,7 +2463,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
             grid.z = (unsigned)((g.n_rt + per_wg - 1) / per_wg);
         }
         // small float32 jobs on 16-period slabs: a row tile's two half-chains on two waves (k_tile_mfma, a.halves)
-        if (sizeof(Real) == 4 && g.variant == 1 && g.pb == 16 && g_in.pb != 16 && !switches().dbg_nw && !switches().dbg_nrt && !switches().no_halves) {
+        if (g.variant == 1 && g.pb == 16 && g_in.pb != 16 && !switches().dbg_nw && !switches().dbg_nrt && !switches().no_halves) {
             const int want = (int)grid.z > 1 ? nw : g.n_rt, parts = (want + 7) / 8;
             const int per_wg = (want + parts - 1) / parts; // row tiles per workgroup (at most 8: two waves each), evenly
             nw = 2 * per_wg; a.n_waves = nw; a.halves = 1;
