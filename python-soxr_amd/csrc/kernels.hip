@@ -2376,7 +2376,9 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     // per-step address arithmetic).  96 000-frame chunk, int16 44.1k -> 16k: kernel 53.6 -> 26.5 us, the stream call 108 -> 81 us.
     if (g.variant == 1 && g.pb > 16 && !switches().dbg_slab64) { // (float64 too: k_tile_mfma<IO, double, 1>)
         const int64_t periods = (j.out_k0 + j.out_frames - 1) / g.Lc - j.out_k0 / g.Lc + 1;
-        if ((periods + 63) / 64 * (int64_t)j.n_clips * j.n_channels < 128) {
+        // (up to 96 slabs of 64 periods: 8 x 96 workgroups of 10 waves are what the chip holds at once — tools/slab16_ab.sh:
+        //  50 slabs 54 -> 33 us, 100 slabs 65 -> 63, 127 slabs 66 -> 76)
+        if ((periods + 63) / 64 * (int64_t)j.n_clips * j.n_channels <= 96 || switches().dbg_slab32) {
             g.pb = 16;
             g.x_count = ((g.pb - 1) * (int32_t)g.Mc + g.span + 3) / 4 * 4;
             g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / g.Mc + 1) + 8) * sizeof(Real);
