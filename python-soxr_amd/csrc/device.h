@@ -87,6 +87,7 @@ struct Switches {
     bool resident = false;        // HIPSOXR_RESIDENT         small-chunk synchronous streams use the resident kernel (as the HIPSOXR_RESIDENT flag)
     bool no_auto_resident = false; // HIPSOXR_NO_AUTO_RESIDENT streams never turn the resident path on by themselves (16 small back-to-back calls do, by default)
     int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
+    int direct_max = 0;           // HIPSOXR_DEBUG_DIRECT_MAX  largest result (bytes) a kernel writes straight into pinned host memory (0: engine.cpp's rule)
     bool resident_no_bar = false; // HIPSOXR_RESIDENT_NO_BAR  mailbox words and input stay in pinned host memory even on large-BAR systems
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids
     bool no_tile_split = false;   // HIPSOXR_NO_TILE_SPLIT    k_tile / k_tile_mfma: never spread a slab's row tiles over several workgroups

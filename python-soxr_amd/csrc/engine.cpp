@@ -812,7 +812,14 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     // the device's address space): no device-to-host copy call, just the completion wait.
     const size_t out_bytes = n * s->ch * esz(s);
     if (s->res.running && out_bytes > s->h_out_bytes) resident_stop(s); // (the result buffer is about to move)
-    const bool direct = out_bytes <= kPinnedMax && !pinned_ensure(&s->h_out, &s->h_out_bytes, out_bytes);
+    // ... up to 1 MiB where the output is unit-stride (mono, split layouts); interleaved multi-channel results only up to
+    // 64 KiB: every 4-byte sample then lands in host memory as a write of its own, and how many of them the fabric merges
+    // depends on which workgroups happen to store side by side — 44.1k -> 48k stereo, 100 000 frames: 348 us against 121
+    // through device memory and a copy; 16k -> 48k 8 channels, 10 000 frames: 366 against 109 (tools/direct_ab.py).  The
+    // copy path costs ~17 us more where the direct writes did merge (48k -> 44.1k stereo, 20 000 frames: 52 -> 70 us).
+    const size_t direct_max = switches().direct_max > 0 ? (size_t)switches().direct_max
+                              : (s->ch == 1 || s->split) ? kPinnedMax : kHostRingChunk;
+    const bool direct = out_bytes <= direct_max && !pinned_ensure(&s->h_out, &s->h_out_bytes, out_bytes);
     hipsoxr_job_t j;
     std::memset(&j, 0, sizeof j);
     j.in = s->d_in; j.out = direct ? s->h_out : s->d_out; j.elem = s->elem;
@@ -1036,8 +1043,8 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
         s->device = dev;
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
-            for (size_t i = 0; i < g_pool.size(); ++i)
-                if (g_pool[i].device == dev) {
+            for (size_t i = g_pool.size(); i-- > 0;) // newest first: the shell a loop of same-sized calls just gave back has its
+                if (g_pool[i].device == dev) {       // pinned buffers at that size already (oldest-first cycled through all eight, growing each)
                     StreamShell sh = g_pool[i];
                     g_pool.erase(g_pool.begin() + (long)i);
                     const size_t frame = (size_t)ch * esz(s);

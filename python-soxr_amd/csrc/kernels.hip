@@ -63,7 +63,7 @@ const Switches &switches()
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY"); w.fft_small_4pass = on("HIPSOXR_FFT_SMALL_4PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
         w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_stagger = num("HIPSOXR_DEBUG_STAGGER"); w.dbg_walk = num("HIPSOXR_DEBUG_WALK"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.no_auto_resident = on("HIPSOXR_NO_AUTO_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
-        if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
+        if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
         w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
