@@ -102,6 +102,7 @@ struct Switches {
     size_t dbg_lds = 0;           // HIPSOXR_DEBUG_LDS        extra dynamic LDS (occupancy experiments)
     bool dbg_slab32 = false;       // HIPSOXR_DEBUG_SLAB32     k_tile_mfma_p: 32-period slabs whatever the job size (A/B)
     bool no_halves = false;        // HIPSOXR_DEBUG_NO_HALVES  k_tile_mfma: both half-chains of a row tile on one wave for small jobs too (A/B)
+    bool dbg_pad = false;          // HIPSOXR_DEBUG_PAD        k_tile_mfma: padded slab rows for odd periods too (round 2; A/B; read when a plan's tables are built)
     bool dbg_slab64 = false;       // HIPSOXR_DEBUG_SLAB64     k_tile_mfma_p: 64-period slabs for small jobs too (round-2 behaviour; A/B)
     int dbg_mfma64_pb = 0;         // HIPSOXR_DEBUG_MFMA64_PB  k_tile_mfma64_p: periods per slab, 16 or 32 (default: 16 below 1536 slabs of 32)
     bool dbg_mfma64_split = false; // HIPSOXR_DEBUG_MFMA64_SPLIT k_tile_mfma64_p: units of 16 periods even where 4 divides the tile count

@@ -61,7 +61,7 @@ const Switches &switches()
         w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
         w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_persist = on("HIPSOXR_FFT_PERSIST"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
         w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY"); w.fft_small_4pass = on("HIPSOXR_FFT_SMALL_4PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
-        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32");
+        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_stagger = num("HIPSOXR_DEBUG_STAGGER"); w.dbg_walk = num("HIPSOXR_DEBUG_WALK"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.no_auto_resident = on("HIPSOXR_NO_AUTO_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
         if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
@@ -1266,10 +1266,12 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
         // the current group's 4*G MFMAs run (one VGPR per chunk).  The prefetch pointer is made
         // opaque so that the compiler cannot fold the software pipeline back into load-then-use.
         constexpr int G = 4; // n_chunks is a multiple of G (host geometry); tables carry G chunks of slack
+        auto chains = [&](auto pad0_tag) {
+        constexpr bool PAD0 = decltype(pad0_tag)::value; // unpadded slab: offset == input index
         // left half-chain: lane k handles input e = eL0 + 4q + k (ascending)
         if (active && side != 1) {
             int32_t e = eL0 + kq;
-            int32_t off = e + pad * (e / Mc), next = (e / Mc + 1) * Mc;
+            int32_t off = PAD0 ? e : e + pad * (e / Mc), next = PAD0 ? 0 : (e / Mc + 1) * Mc;
             int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
             Real ac[G], an[G];
 #pragma unroll
@@ -1288,8 +1290,8 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
                     for (int g = 0; g < NG; ++g) b[g] = (a.dbg & 2) ? ac[u] : px[16 * g * S];
 #pragma unroll
                     for (int g = 0; g < NG; ++g) accL[g] = MfmaOf<Real>::mac(ac[u], b[g], accL[g]);
-                    e += 4; off += 4;
-                    if (e >= next) { off += pad; next += Mc; }
+                    off += 4;
+                    if (!PAD0) { e += 4; if (e >= next) { off += pad; next += Mc; } }
                 }
 #pragma unroll
                 for (int u = 0; u < G; ++u) ac[u] = an[u];
@@ -1299,7 +1301,7 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
         // (3-k)-th of them, so that k = 0 is the highest index (descending order)
         if (active && side != 0) {
             int32_t e = eR0 + 3 - kq;
-            int32_t off = e + pad * (e / Mc), lo = (e / Mc) * Mc;
+            int32_t off = PAD0 ? e : e + pad * (e / Mc), lo = PAD0 ? 0 : (e / Mc) * Mc;
             int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
             Real ac[G], an[G];
 #pragma unroll
@@ -1318,13 +1320,15 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
                     for (int g = 0; g < NG; ++g) b[g] = (a.dbg & 2) ? ac[u] : px[16 * g * S];
 #pragma unroll
                     for (int g = 0; g < NG; ++g) accR[g] = MfmaOf<Real>::mac(ac[u], b[g], accR[g]);
-                    e -= 4; off -= 4;
-                    if (e < lo) { off -= pad; lo -= Mc; }
+                    off -= 4;
+                    if (!PAD0) { e -= 4; if (e < lo) { off -= pad; lo -= Mc; } }
                 }
 #pragma unroll
                 for (int u = 0; u < G; ++u) ac[u] = an[u];
             }
         }
+        };
+        if (pad == 0) chains(std::true_type{}); else chains(std::false_type{});
         if (halves) { // the left half's accumulators to the wave that holds the right half
             if (round) __syncthreads(); // (the scratch of the round before has been read)
             if (active && side == 0) {
@@ -1901,6 +1905,12 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab, int var
         // conflict-free iff the row stride S = Mc + pad is 2*odd (mod 32).
         g.pad = 0;
         while (((Mc + g.pad) % 4) != 2) ++g.pad;
+        // Odd periods (441, 147 ...) run UNPADDED (round 3): a lane's LDS offset is then just its input index — no
+        // period-boundary test and no second offset in the chain's inner step (five vector-ALU instructions per chunk
+        // fewer, in a loop that is bound by exactly those) — at the price of two-way conflicts on about half the
+        // banks of each B read (row stride odd: the sixteen periods start in sixteen different banks, their second
+        // input collides with a neighbour's first).
+        if (Mc % 2 == 1 && !switches().dbg_pad) g.pad = 0;
     } else if (g.aligned) { // row stride = 4*odd words -> conflict-free ds_read_b128 across lanes
         g.pad = ((Mc / 4) % 2 == 0) ? 4 : 0;
     } else {         // row stride odd -> conflict-free ds_read_b32
