@@ -1266,67 +1266,63 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
         // the current group's 4*G MFMAs run (one VGPR per chunk).  The prefetch pointer is made
         // opaque so that the compiler cannot fold the software pipeline back into load-then-use.
         constexpr int G = 4; // n_chunks is a multiple of G (host geometry); tables carry G chunks of slack
+        // One half-chain, software-pipelined one GROUP (four chunks) ahead for both operands (round 3): the B values of
+        // group q + 1 (G x NG ds_read_b32) and the A values of group q + 1 (G loads) are issued before group q's MFMAs.
+        // Before, every MFMA waited for its own LDS read (ds_read; s_waitcnt lgkmcnt(0); v_mfma — four LDS round trips
+        // per group), and the timing-ablation switches sat inside the loop as branches.
         auto chains = [&](auto pad0_tag) {
         constexpr bool PAD0 = decltype(pad0_tag)::value; // unpadded slab: offset == input index
-        // left half-chain: lane k handles input e = eL0 + 4q + k (ascending)
-        if (active && side != 1) {
-            int32_t e = eL0 + kq;
-            int32_t off = PAD0 ? e : e + pad * (e / Mc), next = PAD0 ? 0 : (e / Mc + 1) * Mc;
-            int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
-            Real ac[G], an[G];
+        auto half = [&](auto right_tag, Acc (&acc)[NG], const Real *tab_lane, int32_t e_first) {
+            constexpr bool RIGHT = decltype(right_tag)::value;
+            // left: lane k handles input e = eL0 + 4q + k (ascending); right: chunk q covers inputs [eR0 - 4q, eR0 - 4q + 3]
+            // and lane k takes the (3-k)-th of them, so that k = 0 is the highest index (descending order)
+            int32_t e = e_first;
+            int32_t off = PAD0 ? e : e + pad * (e / Mc);
+            int32_t edge = PAD0 ? 0 : RIGHT ? (e / Mc) * Mc : (e / Mc + 1) * Mc; // next period boundary in e's direction
+            auto load_b1 = [&](Real (&b)[NG]) { // one chunk's B values, then on to the next chunk
+                const Real *px = xrow + off;
 #pragma unroll
-            for (int u = 0; u < G; ++u) ac[u] = tL[u * 64];
+                for (int g = 0; g < NG; ++g) b[g] = px[16 * g * S];
+                if (!RIGHT) { off += 4; if (!PAD0) { e += 4; if (e >= edge) { off += pad; edge += Mc; } } }
+                else { off -= 4; if (!PAD0) { e -= 4; if (e < edge) { off -= pad; edge -= Mc; } } }
+            };
+            auto load_b = [&](auto &b) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) load_b1(b[u]);
+            };
+            int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
+            // (float64 with four period groups: 64 registers of accumulators leave no room for groups of B values in the
+            //  128 a 16-wave workgroup may use — there a chunk's B values are loaded in front of its own MFMAs, as before)
+            constexpr bool AHEAD = sizeof(Real) * NG <= 16;
+            Real ac[G], an[G], bc[AHEAD ? G : 1][NG], bn[AHEAD ? G : 1][NG];
+#pragma unroll
+            for (int u = 0; u < G; ++u) ac[u] = tab_lane[u * 64];
+            if constexpr (AHEAD) load_b(bc);
             for (int32_t q = 0; q < n_chunks; q += G) {
                 poff += G * 64;
                 asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
 #pragma unroll
-                for (int u = 0; u < G; ++u) an[u] = (a.dbg & 4) ? (Real)1 : tL[poff + u * 64];
-                __builtin_amdgcn_sched_barrier(0); // the prefetch is issued BEFORE this group's MFMAs
+                for (int u = 0; u < G; ++u) an[u] = tab_lane[poff + u * 64]; // (tables carry G chunks of slack)
+                if constexpr (AHEAD) { if (q + G < n_chunks) load_b(bn); } // (the slab carries none: no B read past the chain's last group)
+                __builtin_amdgcn_sched_barrier(0); // the prefetches are issued BEFORE this group's MFMAs
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
-                    const Real *px = xrow + off;
-                    Real b[NG];
+                    if constexpr (!AHEAD) load_b1(bc[0]);
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) b[g] = (a.dbg & 2) ? ac[u] : px[16 * g * S];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) accL[g] = MfmaOf<Real>::mac(ac[u], b[g], accL[g]);
-                    off += 4;
-                    if (!PAD0) { e += 4; if (e >= next) { off += pad; next += Mc; } }
+                    for (int g = 0; g < NG; ++g) acc[g] = MfmaOf<Real>::mac(ac[u], bc[AHEAD ? u : 0][g], acc[g]);
                 }
-#pragma unroll
-                for (int u = 0; u < G; ++u) ac[u] = an[u];
-            }
-        }
-        // right half-chain: chunk q covers inputs [eR0 - 4q, eR0 - 4q + 3]; lane k takes the
-        // (3-k)-th of them, so that k = 0 is the highest index (descending order)
-        if (active && side != 0) {
-            int32_t e = eR0 + 3 - kq;
-            int32_t off = PAD0 ? e : e + pad * (e / Mc), lo = PAD0 ? 0 : (e / Mc) * Mc;
-            int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
-            Real ac[G], an[G];
-#pragma unroll
-            for (int u = 0; u < G; ++u) ac[u] = tR[u * 64];
-            for (int32_t q = 0; q < n_chunks; q += G) {
-                poff += G * 64;
-                asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
-#pragma unroll
-                for (int u = 0; u < G; ++u) an[u] = (a.dbg & 4) ? (Real)1 : tR[poff + u * 64];
-                __builtin_amdgcn_sched_barrier(0); // the prefetch is issued BEFORE this group's MFMAs
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
-                    const Real *px = xrow + off;
-                    Real b[NG];
+                    ac[u] = an[u];
+                    if constexpr (AHEAD) {
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) b[g] = (a.dbg & 2) ? ac[u] : px[16 * g * S];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) accR[g] = MfmaOf<Real>::mac(ac[u], b[g], accR[g]);
-                    off -= 4;
-                    if (!PAD0) { e -= 4; if (e < lo) { off -= pad; lo -= Mc; } }
+                        for (int g = 0; g < NG; ++g) bc[u][g] = bn[u][g];
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < G; ++u) ac[u] = an[u];
             }
-        }
+        };
+        if (active && side != 1) half(std::false_type{}, accL, tL, eL0 + kq);
+        if (active && side != 0) half(std::true_type{}, accR, tR, eR0 + 3 - kq);
         };
         if (pad == 0) chains(std::true_type{}); else chains(std::false_type{});
         if (halves) { // the left half's accumulators to the wave that holds the right half
@@ -1955,7 +1951,8 @@ static TileGeom build_tile_tables(const Plan &p, std::vector<Real> *tab, int var
         // workgroup cannot hide its own staging — 48k -> 44.1k int32 60 s: 105 us on 83 KB slabs, 90 us on 42 KB ones),
         // else 32 periods up to 120 KB (44.1k -> 16k: 72 us on 116 KB against 84 us on 59 KB), else 16.
         const size_t limit = (variant == 1 && sizeof(Real) == 8)
-                                 ? (switches().dbg_mfma64_lds ? switches().dbg_mfma64_lds : g.pb == 64 ? 48 * 1024 : 120 * 1024) : 160 * 1024;
+                                 ? (g.pb == 64 ? 0 /* (four period groups of float64: 64 accumulator registers — the pipelined chain no longer fits; two groups it is) */
+                                               : switches().dbg_mfma64_lds ? switches().dbg_mfma64_lds : 120 * 1024) : 160 * 1024;
         if (g.lds_bytes <= limit || (variant != 0 && sizeof(Real) == 4) || g.pb == 16) break;
         g.pb /= 2;
     }
@@ -2438,7 +2435,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
         if (g.variant == 1) kern = g.pb == 64 ? k_tile_mfma<IO, float, 4> : g.pb == 32 ? k_tile_mfma<IO, float, 2> : k_tile_mfma<IO, float, 1>;
         if (g.variant == 2) kern = k_tile_mfma_p<IO>;
     } else {
-        if (g.variant == 1) kern = g.pb == 64 ? k_tile_mfma<IO, double, 4> : g.pb == 32 ? k_tile_mfma<IO, double, 2> : k_tile_mfma<IO, double, 1>;
+        if (g.variant == 1) kern = g.pb == 32 ? k_tile_mfma<IO, double, 2> : k_tile_mfma<IO, double, 1>; // (pb = 64 is never chosen for float64: build_tile_tables)
         if (g.variant == 2) kern = f64_pb == 16 ? k_tile_mfma64_p<IO, 1, 16> : switches().dbg_mfma64_split ? k_tile_mfma64_p<IO, 1, 32> : k_tile_mfma64_p<IO, 2, 32>;
     }
     a.rowR = g.rowR; a.plane = g.plane;
