@@ -427,10 +427,15 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     const GatherArgs &a = ia.g;
     constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
     const int32_t KO = ta.KO, P = ia.P, T = a.T, H = T / 2;
+    // (round 3: no per-output record in LDS any more — 8 of the 10 bytes of bookkeeping per output; an output's position
+    //  is located again where it is needed, ~50 vector-ALU instructions against the ~1500 of its taps.  LDS then holds
+    //  twice the outputs per workgroup, a bucket — the outputs of one phase interval, served 64 at a time — 60 instead
+    //  of 30.  48000 -> 44101: mono 60 s 254 -> 242 us, 200 000 frames 152 -> 114; stereo 60 s stays at 402 — the kernel issues
+    //  one vector-ALU instruction per 7 cycles per SIMD: what it waits for is the per-tap ds_read_b32 of 64 windows ~278 words
+    //  apart, two- to four-way bank conflicts on the one LDS pipe the four SIMDs share)
     Real *xs = reinterpret_cast<Real *>(smem_raw);                       // [span_cap]
-    uint64_t *rec = reinterpret_cast<uint64_t *>(xs + ta.span_cap);      // [KO]  iv:8 | n0_local:24 | xq:32
-    uint16_t *order = reinterpret_cast<uint16_t *>(rec + KO);            // [KO]  outputs sorted by interval
-    uint32_t *off = reinterpret_cast<uint32_t *>(order + KO);            // [P + 1] bucket offsets
+    uint16_t *order = reinterpret_cast<uint16_t *>(xs + ta.span_cap);    // [KO]  outputs sorted by interval
+    uint32_t *off = reinterpret_cast<uint32_t *>(order + ((KO + 1) & ~1)); // [P + 1] bucket offsets
     uint32_t *cur = off + (P + 1);                                       // [P]     scatter cursors
 
     const uint32_t col = blockIdx.y;
@@ -464,7 +469,6 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     // 1. locate every output once; histogram of intervals
     for (int i = threadIdx.x; i < n_here; i += blockDim.x) {
         const InterpPos<Real> r = locate(i);
-        rec[i] = ((uint64_t)r.iv << 56) | ((uint64_t)(uint32_t)(r.n0 - n_first) << 32) | (uint64_t)(uint32_t)r.xq;
         atomicAdd(&off[r.iv + 1], 1u);
     }
     // 2. stage the input span (zero outside the signal), converted to the engine precision
@@ -490,7 +494,7 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_here; i += blockDim.x) {
-        const uint32_t iv = (uint32_t)(rec[i] >> 56);
+        const uint32_t iv = locate(i).iv;
         order[off[iv] + atomicAdd(&cur[iv], 1u)] = (uint16_t)i;
     }
     __syncthreads();
@@ -524,9 +528,9 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
                 }
             const bool live = key != 0xFFFFu;
             const int i = live ? (int)key : (int)order[b0];
-            const uint64_t rc = rec[i];
-            const Real *xl = xs + (uint32_t)((rc >> 32) & 0xFFFFFFu);
-            const Real xx = (Real)(uint32_t)rc * (Real)(1. / (double)(1ULL << SH));
+            const InterpPos<Real> rc = locate(i);
+            const Real *xl = xs + (uint32_t)(rc.n0 - n_first);
+            const Real xx = (Real)(uint32_t)rc.xq * (Real)(1. / (double)(1ULL << SH));
             Real accL = 0, accR = 0;
 #pragma unroll 2
             for (int b = 0; b < H / 4; ++b) { // T is a multiple of 8: H is a multiple of 4
@@ -2240,7 +2244,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             ia.g = a; ia.tab = d.interp_tab; ia.P = p->phases;
             while ((1 << ia.lgP) < ia.P) ++ia.lgP;
             // throughput kernel for large launches: KO outputs per workgroup, as many as LDS allows
-            // (input span + 10 bytes of bookkeeping per output), at least ~32 outputs per interval
+            // (input span + 2 bytes of bookkeeping per output), at least ~32 outputs per interval
             const bool no_itile = switches().no_interp_tile;
             int64_t KO = 0, span_cap = 0;
             if (!no_itile && nf >= 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
@@ -2253,12 +2257,20 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 }
                 // a bucket (outputs of one interval) is served 64 at a time: aim at a mean of 60 per
                 // interval (30, 15 when LDS cannot hold that many outputs and their input span)
-                for (int per = 60; per >= 15 && !KO; per /= 2) {
+                // (round 3: among the sizes that fit, the one that leaves the fewest workgroup-layers x outputs per
+                //  workgroup on the 256 CUs — 48000 -> 44101 stereo 60 s: 60 per interval are 346 workgroups, two layers
+                //  of which the second is a third full; 41 per interval are 506)
+                double best_cost = 1e300;
+                const double cols_ = (double)j.n_clips * j.n_channels;
+                for (int per = 64; per >= 15; --per) {
                     const int64_t k = (int64_t)per * p->phases;
-                    if (k > 15360 || k > nf) continue;
-                    span_cap = (int64_t)std::ceil((double)k * step) + p->T + 8;
-                    const int64_t bytes = span_cap * (int64_t)sizeof(Real) + k * 10 + (2 * p->phases + 2) * 4 + 64;
-                    if (bytes <= 150 * 1024) KO = k;
+                    if (k > 16384 || k > nf) continue;
+                    const int64_t sc = (int64_t)std::ceil((double)k * step) + p->T + 8;
+                    const int64_t bytes = sc * (int64_t)sizeof(Real) + k * 2 + (2 * p->phases + 2) * 4 + 64;
+                    if (bytes > 150 * 1024) continue;
+                    const double wgs_ = std::ceil((double)nf / (double)k) * cols_;
+                    const double cost = std::ceil(wgs_ / 256.) * (double)k * (per >= 30 ? 1. : 30. / per); // (thin buckets: idle lanes)
+                    if (cost < best_cost) { best_cost = cost; KO = k; span_cap = sc; }
                 }
                 // ... which pays off once the launch fills the chip.  A workgroup of it is long (KO outputs x T taps one
                 // interval at a time: ~130 us at VHQ, 1.5 ms with the variable-rate clock), so a launch of a few of them
@@ -2286,7 +2298,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     ta.ia.s_hi = (uint64_t)(S1 >> 64); ta.ia.s_lo = (uint64_t)S1;
                     ta.ia.d_hi = vr->d_hi; ta.ia.d_lo = vr->d_lo;
                 }
-                const size_t lds = (size_t)ta.span_cap * sizeof(Real) + (size_t)KO * 10 + (size_t)(2 * p->phases + 2) * 4 + 64;
+                const size_t lds = (size_t)ta.span_cap * sizeof(Real) + (size_t)KO * 2 + (size_t)(2 * p->phases + 2) * 4 + 64;
                 const dim3 tgrid((unsigned)((nf + KO - 1) / KO), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1);
                 void (*tk)(InterpTileArgs) = vr ? k_interp_tile<IO, Real, true> : k_interp_tile<IO, Real, false>;
                 HIP_TRY(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
