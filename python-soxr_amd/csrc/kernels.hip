@@ -1390,11 +1390,22 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
 // group g+2 are in flight while the 8 MFMAs of group g issue, so that a single wave per SIMD keeps
 // the matrix pipe busy.  The loop is unrolled by two groups with ping-pong registers (no copies).
 // RIGHT = false: ascending groups, chunk c uses component c; true: descending, component 3-c.
+// (round 3: the table is read through a buffer descriptor — `buffer_load_dwordx4 v, v_lane16, s[rsrc], s_offset offen`:
+//  wave-uniform base in the descriptor, the lane's 16-byte column as the one vector offset, the group as a SCALAR offset —
+//  so that an A load costs no vector-ALU instruction; as a per-lane pointer plus scalar offset every load came with a
+//  64-bit v_lshl_add, and beside a busy matrix pipe each vector-ALU instruction costs ~4 pipe cycles.  Plain pointer
+//  arithmetic does not get there: base + lane offset is hoisted out of the loop as one 64-bit per-lane pointer.)
 template <bool RIGHT>
-__device__ __forceinline__ void mfma_half_chain(f32x4 (&acc)[2], const float4 *t, const float *xb,
+__device__ __forceinline__ void mfma_half_chain(f32x4 (&acc)[2], const char *tb, uint32_t lane16, const float *xb,
                                                 int32_t e0, int32_t n_groups, int32_t Mc, int32_t R,
                                                 int32_t padR)
 {
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)tb, 0, 0x40000000, 0x00020000);
+    auto t_at = [&](int32_t idx) { // element idx of the lane's column
+        // (bit_cast of the builtin's own result: assigning it to an ext_vector_type of unsigned first silently yields
+        //  four copies of its first element with this compiler)
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(trs, (int)lane16, idx * 16, 0));
+    };
     int32_t rem = e0 % Mc, fo = (e0 / Mc) * R + (rem >> 2); // wave-uniform plane offset of the next B read
     auto ldb = [&](float4 &b0, float4 &b1) {
         const float *px = xb + fo;
@@ -1426,7 +1437,7 @@ __device__ __forceinline__ void mfma_half_chain(f32x4 (&acc)[2], const float4 *t
     // A operands: ring of 4 registers, each reloaded for group g+4 right after group g's MFMAs
     // (3 groups = 24 MFMAs = 768 pipe cycles ahead of use: an L2 round trip).  B operands: one
     // group ahead (LDS latency).  sched_barrier(0) pins "loads first, then this group's MFMAs".
-    float4 a0 = t[0], a1 = t[64], a2 = t[128], a3 = t[192];
+    float4 a0 = t_at(0), a1 = t_at(64), a2 = t_at(128), a3 = t_at(192);
     float4 bE0, bE1, bO0, bO1;
     ldb(bE0, bE1);                  // B of group 0
     int32_t poff = 192;             // table offset (float4) of the newest A in flight
@@ -1437,7 +1448,7 @@ __device__ __forceinline__ void mfma_half_chain(f32x4 (&acc)[2], const float4 *t
     HIPSOXR_MFMA8(AR, BC0, BC1)                                                                 \
     poff += 64;                                                                                 \
     asm volatile("" : "+s"(poff)); /* opaque: the pipeline must not be re-rolled */             \
-    AR = t[poff];                   /* A of group +4 */
+    AR = t_at(poff);                /* A of group +4 */
     for (; grp + 3 < n_groups; grp += 4) {
         HIPSOXR_STEP(a0, bE0, bE1, bO0, bO1)
         HIPSOXR_STEP(a1, bO0, bO1, bE0, bE1)
@@ -1577,14 +1588,15 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
         const int32_t wL = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]), wR = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
         const int32_t eL0 = wL & 0xffffff, eR0 = wR & 0xffffff; // multiples of 16
         const int32_t gL = (a.dbg & 16) ? n_groups : wL >> 24, gR = (a.dbg & 16) ? n_groups : wR >> 24; // groups this tile's half-chains need (build_mfma_planes; HIPSOXR_DEBUG_FLAGS 16: all of them)
-        const float4 *tL = (const float4 *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane;
-        const float4 *tR = (const float4 *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane;
+        const char *tL = (const char *)a.tab + (size_t)(rt * 2 + 0) * half_stride * 16; // (wave-uniform; lanes add lane * 16)
+        const char *tR = tL + half_stride * 16;
+        const uint32_t lane16 = (uint32_t)lane * 16;
         f32x4 accL[2], accR[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) { accL[g] = (f32x4){0, 0, 0, 0}; accR[g] = (f32x4){0, 0, 0, 0}; }
 
-        mfma_half_chain<false>(accL, tL, xL + ph * 32 * R, eL0, gL, Mc, R, padR);
-        mfma_half_chain<true>(accR, tR, xR + ph * 32 * R, eR0, gR, Mc, R, padR);
+        mfma_half_chain<false>(accL, tL, lane16, xL + ph * 32 * R, eL0, gL, Mc, R, padR);
+        mfma_half_chain<true>(accR, tR, lane16, xR + ph * 32 * R, eR0, gR, Mc, R, padR);
         HIPSOXR_STAMP();
 
         const int32_t r0 = rt * 16 + 4 * kq;
