@@ -1260,8 +1260,8 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
         const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]);
         const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
         const size_t half_stride = (size_t)(a.I_h + 16) * 16; // + 4 chunks of prefetch slack
-        const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane;
-        const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane;
+        const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride; // (wave-uniform: lanes add their column in the load)
+        const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride;
         Acc accL[NG], accR[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) { accL[g] = (Acc){0, 0, 0, 0}; accR[g] = (Acc){0, 0, 0, 0}; }
@@ -1276,8 +1276,15 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
         // per group), and the timing-ablation switches sat inside the loop as branches.
         auto chains = [&](auto pad0_tag) {
         constexpr bool PAD0 = decltype(pad0_tag)::value; // unpadded slab: offset == input index
-        auto half = [&](auto right_tag, Acc (&acc)[NG], const Real *tab_lane, int32_t e_first) {
+        auto half = [&](auto right_tag, Acc (&acc)[NG], const Real *tab_half, int32_t e_first) {
             constexpr bool RIGHT = decltype(right_tag)::value;
+            // (coefficients through a buffer descriptor — scalar offsets, no vector address arithmetic: see mfma_half_chain)
+            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)tab_half, 0, 0x40000000, 0x00020000);
+            const int lane_bytes = lane * (int)sizeof(Real);
+            auto tab_at = [&](int32_t idx) -> Real {
+                if constexpr (sizeof(Real) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(trs, lane_bytes, idx * 4, 0));
+                else return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(trs, lane_bytes, idx * 8, 0));
+            };
             // left: lane k handles input e = eL0 + 4q + k (ascending); right: chunk q covers inputs [eR0 - 4q, eR0 - 4q + 3]
             // and lane k takes the (3-k)-th of them, so that k = 0 is the highest index (descending order)
             int32_t e = e_first;
@@ -1300,13 +1307,13 @@ __global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
             constexpr bool AHEAD = sizeof(Real) * NG <= 16;
             Real ac[G], an[G], bc[AHEAD ? G : 1][NG], bn[AHEAD ? G : 1][NG];
 #pragma unroll
-            for (int u = 0; u < G; ++u) ac[u] = tab_lane[u * 64];
+            for (int u = 0; u < G; ++u) ac[u] = tab_at(u * 64);
             if constexpr (AHEAD) load_b(bc);
             for (int32_t q = 0; q < n_chunks; q += G) {
                 poff += G * 64;
                 asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
 #pragma unroll
-                for (int u = 0; u < G; ++u) an[u] = tab_lane[poff + u * 64]; // (tables carry G chunks of slack)
+                for (int u = 0; u < G; ++u) an[u] = tab_at(poff + u * 64); // (tables carry G chunks of slack)
                 if constexpr (AHEAD) { if (q + G < n_chunks) load_b(bn); } // (the slab carries none: no B read past the chain's last group)
                 __builtin_amdgcn_sched_barrier(0); // the prefetches are issued BEFORE this group's MFMAs
 #pragma unroll
@@ -1650,10 +1657,12 @@ __global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
 // NG = 1: a unit is a row tile across 16 periods — twice as many, half as long: the four waves of a workgroup then
 // share 2 n_rt units evenly where n_rt is not a multiple of four (147 phases = 10 tiles: 3/3/2/2 -> 5/5/5/5).
 template <bool RIGHT, int NG>
-__device__ __forceinline__ void mfma64_half_chain(f64x4 (&acc)[NG], const double *t, const double *xb, int32_t e0, int32_t n_groups,
-                                                  int32_t Mc, int32_t R, int32_t padR)
+__device__ __forceinline__ void mfma64_half_chain(f64x4 (&acc)[NG], const double *tbase, uint32_t lane_bytes, const double *xb, int32_t e0,
+                                                  int32_t n_groups, int32_t Mc, int32_t R, int32_t padR)
 {
     typedef double d2 __attribute__((ext_vector_type(2)));
+    // (coefficients through a buffer descriptor, the group as a scalar offset: see mfma_half_chain)
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)tbase, 0, 0x40000000, 0x00020000);
     int32_t rem = e0 % Mc, fo = (e0 / Mc) * R + (rem >> 2); // wave-uniform plane offset of the next B read
     auto ldb = [&](d2 (&b)[2 * NG]) { // period j (and j + 16), four consecutive chunk columns each
         const double *px = xb + fo;
@@ -1667,8 +1676,8 @@ __device__ __forceinline__ void mfma64_half_chain(f64x4 (&acc)[NG], const double
         else { fo -= 4; rem -= 16; if (rem < 0) { rem += Mc; fo -= padR; } }
     };
     auto lda = [&](d2 (&av)[2], int32_t off) { // this lane's coefficients of the group's four chunks
-        av[0] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(t + off, 16));
-        av[1] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(t + off + 2, 16));
+        av[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(trs, (int)lane_bytes, off * 8, 0));
+        av[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(trs, (int)lane_bytes, off * 8 + 16, 0));
     };
     d2 ac[2], an[2], bc[2 * NG], bn[2 * NG];
     lda(ac, 0);
@@ -1741,13 +1750,13 @@ __global__ void __launch_bounds__(640) k_tile_mfma64_p(TileArgs a)
         const int32_t wL = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]), wR = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
         const int32_t eL0 = wL & 0xffffff, eR0 = wR & 0xffffff; // multiples of 16
         const int32_t gL = wL >> 24, gR = wR >> 24;             // groups this tile's half-chains need (build_mfma_planes)
-        const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride + lane * 4;
-        const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride + lane * 4;
+        const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride; // (wave-uniform; a lane's column starts lane * 32 bytes in)
+        const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride;
         f64x4 accL[NG], accR[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) { accL[g] = (f64x4){0, 0, 0, 0}; accR[g] = (f64x4){0, 0, 0, 0}; }
-        mfma64_half_chain<false, NG>(accL, tL, xL + ph * 16 * R, eL0, gL, Mc, R, padR);
-        mfma64_half_chain<true, NG>(accR, tR, xR + ph * 16 * R, eR0, gR, Mc, R, padR);
+        mfma64_half_chain<false, NG>(accL, tL, (uint32_t)lane * 32, xL + ph * 16 * R, eL0, gL, Mc, R, padR);
+        mfma64_half_chain<true, NG>(accR, tR, (uint32_t)lane * 32, xR + ph * 16 * R, eR0, gR, Mc, R, padR);
 
         const int32_t rbase = rt * 16; // this lane: rows rbase + kq + 4 v, periods bw + 16 g + j
 #pragma unroll
