@@ -430,9 +430,12 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     // (round 3: no per-output record in LDS any more — 8 of the 10 bytes of bookkeeping per output; an output's position
     //  is located again where it is needed, ~50 vector-ALU instructions against the ~1500 of its taps.  LDS then holds
     //  twice the outputs per workgroup, a bucket — the outputs of one phase interval, served 64 at a time — 60 instead
-    //  of 30.  48000 -> 44101: mono 60 s 254 -> 242 us, 200 000 frames 152 -> 114; stereo 60 s stays at 402 — the kernel issues
-    //  one vector-ALU instruction per 7 cycles per SIMD: what it waits for is the per-tap ds_read_b32 of 64 windows ~278 words
-    //  apart, two- to four-way bank conflicts on the one LDS pipe the four SIMDs share)
+    //  of 30.  48000 -> 44101: mono 60 s 254 -> 242 us, 200 000 frames 152 -> 114; stereo 60 s stays at 402.  The kernel issues
+    //  one vector-ALU instruction per 7 cycles per SIMD, and it is not the LDS: with every lane reading lane 0's window — no
+    //  bank conflict left — it takes 382 us.  Time goes with the NUMBER OF GROUPS, whatever the occupancy (30 outputs per
+    //  interval, three workgroups per CU: 628 us; 15: 1013): a group of <= 64 outputs walks its interval's whole row of
+    //  cubic records, 4.8 KB, through the scalar cache, which it misses — 423 MB per launch, ~6 bytes per cycle per scalar
+    //  cache.  Coefficient delivery is the bound; requesting a block ahead (one block is all the SGPRs hold) was slower.)
     Real *xs = reinterpret_cast<Real *>(smem_raw);                       // [span_cap]
     uint16_t *order = reinterpret_cast<uint16_t *>(xs + ta.span_cap);    // [KO]  outputs sorted by interval
     uint32_t *off = reinterpret_cast<uint32_t *>(order + ((KO + 1) & ~1)); // [P + 1] bucket offsets
