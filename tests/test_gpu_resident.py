@@ -158,8 +158,13 @@ def test_small_chunk_stream_after_a_large_chunk_stream_still_gets_the_host_ring(
             outs.append(rs.resample_chunk(x[a:a + chunk], last=(a + chunk >= len(x)))); n += 1
         return (time.perf_counter() - t0) / n, np.concatenate(outs)
 
-    t_fresh, y_fresh = per_call(441)
-    per_call(96000)                       # leaves a device ring in the pool
-    t_after, y_after = per_call(441)
-    assert np.array_equal(y_fresh, y_after)
+    # (best of three on either side: a timing test must not trip over one hiccup of the box)
+    fresh = [per_call(441) for _ in range(3)]
+    t_fresh, y_fresh = min(t for t, _ in fresh), fresh[0][1]
+    after = []
+    for _ in range(3):
+        per_call(96000)                   # leaves a device ring in the pool
+        after.append(per_call(441))
+    t_after = min(t for t, _ in after)
+    assert all(np.array_equal(y_fresh, y) for _, y in fresh + after)
     assert t_after < 1.35 * t_fresh + 2e-6, (t_fresh, t_after)
