@@ -2379,8 +2379,8 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     // are stacked ("layers": the dispatcher fills 256 CUs evenly only in whole layers) times what one workgroup does
     // serially, plus staging; the constants are fitted to tools/slab_ab.sh sweeps (10 .. 6016 slabs, 48k -> 44.1k VHQ,
     // profiles/r03_ab_experiments.txt), in units of one unit's MFMA time:
-    //     cost = c0 + layers x (units per wave) x k;   (pb, one unit per wave): c0, k = 32: 1.43, 1.21 | 64: 1.9, 1.43
-    //                                                  (pb, several)          :         32: 1.77, 1.10 | 64: 2.8, 1.21
+    //     cost = c0 + layers x (units per wave) x k;   (pb, one unit per wave): c0, k = 32: 1.15, 1.153 | 64: 1.25, 1.41
+    //                                                  (pb, several)          :         32: 2.35, 0.958 | 64: 3.32, 1.052
     // e.g. 47 slabs (a 10 s clip): 64/split (235 workgroups, one layer); 20: 32/split (120 workgroups staging half as
     // much); 376: 32/whole (752 workgroups, 3 layers of 3 units: 35 us where round 2's 64/4 took 51); from 512 slabs of
     // 64 on the whole-slab form is the rule again (12 waves per CU stream coefficients for 20 units each).
@@ -2395,10 +2395,16 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
                 const int units = (pb / 32) * g.n_rt, full = (units + 3) / 4;
                 for (int split : {1, full}) {
                     const int upw = (units + 4 * split - 1) / (4 * split);
-                    const int64_t layers = ((pb == 64 ? slabs64 : slabs32) * split + 255) / 256;
-                    const double c0 = pb == 32 ? (upw == 1 ? 1.43 : 1.77) : (upw == 1 ? 1.9 : 2.8);
-                    const double k = pb == 32 ? (upw == 1 ? 1.21 : 1.10) : (upw == 1 ? 1.43 : 1.21);
-                    const double cost = c0 + (double)layers * upw * k;
+                    const double wgs_ = (double)((pb == 64 ? slabs64 : slabs32) * split);
+                    double layers = std::ceil(wgs_ / 256.);
+                    // (a partly filled last layer of multi-unit workgroups costs less than a full one: half-way;
+                    //  64-period slabs split into single units, three per CU: between 1.5 and 3 x 256 workgroups the
+                    //  dispatcher stacks them three deep on the CUs it has started on — refit after the round-3 kernels)
+                    if (upw > 1) layers = 0.5 * (layers + wgs_ / 256.);
+                    else if (pb == 64 && wgs_ > 384. && wgs_ <= 768.) layers = 3.;
+                    const double c0 = pb == 32 ? (upw == 1 ? 1.15 : 2.35) : (upw == 1 ? 1.25 : 3.32);
+                    const double k = pb == 32 ? (upw == 1 ? 1.153 : 0.958) : (upw == 1 ? 1.41 : 1.052);
+                    const double cost = c0 + layers * upw * k;
                     if (cost < best) { best = cost; best_pb = pb; best_split = split; }
                 }
             }
