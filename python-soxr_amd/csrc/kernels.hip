@@ -2423,11 +2423,28 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     // workgroups, each staging a quarter and walking a chain a quarter as long (one wave does a row tile x ALL the
     // slab's periods, and its ~880 k-steps cost the same whether they feed four MFMAs or one: the chain is bound by its
     // per-step address arithmetic).  96 000-frame chunk, int16 44.1k -> 16k: kernel 53.6 -> 26.5 us, the stream call 108 -> 81 us.
+    bool v1_small = false; // the small-job form of the general-period kernel (16-period slabs, half-chains on two waves)
     if (g.variant == 1 && g.pb > 16 && !switches().dbg_slab64) { // (float64 too: k_tile_mfma<IO, double, 1>)
         const int64_t periods = (j.out_k0 + j.out_frames - 1) / g.Lc - j.out_k0 / g.Lc + 1;
         // (up to 96 slabs of 64 periods: 8 x 96 workgroups of 10 waves are what the chip holds at once — tools/slab16_ab.sh:
         //  50 slabs 54 -> 33 us, 100 slabs 65 -> 63, 127 slabs 66 -> 76)
-        if ((periods + 63) / 64 * (int64_t)j.n_clips * j.n_channels <= 96 || switches().dbg_slab32) {
+        const int64_t s64 = (periods + 63) / 64 * (int64_t)j.n_clips * j.n_channels;
+        v1_small = s64 <= 96 || switches().dbg_slab32;
+        // Beyond that: 16-period slabs WITHOUT the half-chain split where four times as many, four times shorter
+        // workgroups fill the chip's layers better than 64-period ones — a layer of 256 workgroups of the 16-period
+        // form costs 0.276 of a 64-period layer (not 0.25), a last 64-period layer that is at most half full 0.82
+        // (tools/slab16_ab.sh: 127 slabs 45 -> 33 us, 300: 108 -> 77, 800: 213 -> 190; 250 and 500 stay)
+        bool v1_mid = false;
+        if (!v1_small && s64 < 4096 && !switches().no_halves) {
+            // (in layers of the plan's own slab size — 64 periods, or 32 where a float64 slab of 64 does not fit LDS,
+            //  whose layer a 16-period one costs 0.53 of)
+            const double s0 = (double)((periods + g.pb - 1) / g.pb * (int64_t)j.n_clips * j.n_channels);
+            const double l0 = std::ceil(s0 / 256.), frac = s0 / 256. - (l0 - 1.);
+            const double est0 = (l0 - 1.) + (frac <= 0.5 ? 0.82 : 1.0);
+            const double est16 = 0.04 + (g.pb == 64 ? 0.276 : 0.53) * std::ceil((double)((periods + 15) / 16 * (int64_t)j.n_clips * j.n_channels) / 256.);
+            v1_mid = est16 < est0;
+        }
+        if (v1_small || v1_mid) {
             g.pb = 16;
             g.x_count = ((g.pb - 1) * (int32_t)g.Mc + g.span + 3) / 4 * 4;
             g.lds_bytes = ((size_t)g.x_count + (size_t)g.pad * (g.x_count / g.Mc + 1) + 8) * sizeof(Real);
@@ -2514,7 +2531,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
             grid.z = (unsigned)((g.n_rt + per_wg - 1) / per_wg);
         }
         // small float32 jobs on 16-period slabs: a row tile's two half-chains on two waves (k_tile_mfma, a.halves)
-        if (g.variant == 1 && g.pb == 16 && g_in.pb != 16 && !switches().dbg_nw && !switches().dbg_nrt && !switches().no_halves) {
+        if (g.variant == 1 && g.pb == 16 && g_in.pb != 16 && v1_small && !switches().dbg_nw && !switches().dbg_nrt && !switches().no_halves) {
             const int want = (int)grid.z > 1 ? nw : g.n_rt, parts = (want + 7) / 8;
             const int per_wg = (want + parts - 1) / parts; // row tiles per workgroup (at most 8: two waves each), evenly
             nw = 2 * per_wg; a.n_waves = nw; a.halves = 1;
