@@ -81,10 +81,13 @@ typedef enum {
                                   HIPSOXR_RESIDENT_IDLE_US (default 1000) without a call; until then device-wide
                                   synchronisations elsewhere in the process wait for it.  Interleaved streams,
                                   constant or variable rate (a variable-rate message carries its own Q64.64
-                                  clock), without HIPSOXR_DEFER.  Also: environment HIPSOXR_RESIDENT.
-                                  Without the flag a stream turns this path on BY ITSELF once it has been fed 16 small
-                                  chunks back to back (each within 500 us of the one before), and the kernel retires
-                                  itself on idle as above; environment HIPSOXR_NO_AUTO_RESIDENT disables that. */
+                                  clock), without HIPSOXR_DEFER.  Also: environment HIPSOXR_RESIDENT. */
+#define HIPSOXR_AUTO_RESIDENT 256UL /* (extension, opt-in; also environment HIPSOXR_AUTO_RESIDENT) the stream turns the
+                                  resident path on BY ITSELF once it has been fed 16 small chunks back to back (each
+                                  within 500 us of the one before) and off again at the first call that breaks the run;
+                                  such instances may hold at most an eighth of the chip.  Not a default: while a
+                                  resident kernel spins, hipDeviceSynchronize / hipFree anywhere in the process wait
+                                  until it leaves (up to the idle time, longer if another thread keeps feeding it). */
 
 /* Element types used by device jobs (layout is given by strides, not by the type). */
 typedef enum { HIPSOXR_F32 = 0, HIPSOXR_F64 = 1, HIPSOXR_I32 = 2, HIPSOXR_I16 = 3 } hipsoxr_elem_t;

@@ -25,9 +25,15 @@ mkdir -p "$OBJ"
 "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/engine.cpp" -o "$OBJ/engine.o" & P2=$!
 "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/kernels.hip" -o "$OBJ/kernels.o" & P3=$!
 "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/soxr_abi.cpp" -o "$OBJ/soxr_abi.o" & P5=$!
+# The A/B and timing-experiment switches (device.h `Switches`, everything but four product names) are read from the
+# environment only by a build with -DHIPSOXR_DEBUG_SWITCHES.  The reader lives in kernels.hip alone, so the debug build is
+# that one object compiled a second time and linked with the product's other objects: _variants/dbg/libhipsoxr.so
+# (tests/test_gpu_switches.py, tests/test_gpu_launch_forms.py and tools/*.sh load it through HIPSOXR_LIBRARY).
+P8=""
+if [ -z "$HIPSOXR_VARIANT" ]; then
+  "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -DHIPSOXR_DEBUG_SWITCHES -c "$SRC/kernels.hip" -o "$OBJ/kernels_dbg.o" & P8=$!
+fi
 # (fft.hip in three translation units: see "Three translation units" there)
-# (experiment builds — the looping kernels k_fft_pair2p / k_fft_strided2<.., K > 0>, measured slower and left out of the product —
-#  are made with HIPSOXR_VARIANT=exp HIPSOXR_EXTRA_FLAGS="-DFFT_EXPERIMENTS -mllvm -disable-machine-licm": see fft_tid() in fft.hip)
 FFTFLAGS="-ffp-contract=fast -fno-slp-vectorize"
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=0 -c "$SRC/fft.hip" -o "$OBJ/fft.o" & P4=$!
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=1 -c "$SRC/fft.hip" -o "$OBJ/fft1.o" & P6=$!
@@ -39,4 +45,9 @@ OBJS="$OBJ/plan.o $OBJ/engine.o $OBJ/kernels.o $OBJ/fft.o $OBJ/fft1.o $OBJ/fft2.
 # reference's USE_SYSTEM_LIBSOXR build picks up (reference CMakeLists.txt:83-93).
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libsoxr.so.0 $OBJS -o "$OUTDIR/libsoxr.so.0"
 ln -sf libsoxr.so.0 "$OUTDIR/libsoxr.so"
+if [ -n "$P8" ]; then
+  wait $P8
+  mkdir -p "$HERE/_variants/dbg"
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC ${OBJS/kernels.o/kernels_dbg.o} -o "$HERE/_variants/dbg/libhipsoxr.so"
+fi
 echo "built $OUT (+ libsoxr.so.0)"

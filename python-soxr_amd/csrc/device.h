@@ -43,10 +43,11 @@ struct ResidentLaunch {
     uint32_t epoch;        // number of this instance (never 0)
     int64_t idle_us;       // the instance leaves after this long without a message
     int64_t used_mcu = 0;  // in: milli-CUs already held by this process's resident instances
+    int budget_shift = 1;  // in: resident instances may hold (CUs >> budget_shift) of the chip together
     uint32_t n_wgs = 0;    // out: workgroups of the instance
     int64_t max_out = 0;   // out: outputs per column one message may ask for
     uint32_t cost_mcu = 0; // out: CU capacity the instance occupies, n_wgs * 1024 / (workgroups that fit one CU)
-    bool over_budget = false; // out: refused because used_mcu + cost_mcu would exceed half the chip
+    bool over_budget = false; // out: refused because used_mcu + cost_mcu would exceed the budget
 };
 // Completion words for a small launch: if the job turns out to be ONE launch of the small-launch kernel (k_chain) of at
 // most `cap` workgroups, each workgroup stores `seq` into words[w] (pinned host memory) after its results are in host
@@ -64,29 +65,31 @@ void resident_leave(volatile uint64_t *words, uint32_t epoch);
 
 int device_count();
 
-// Engine-selection and timing-experiment switches, read ONCE from the environment.  None of them
-// changes results beyond what the selected engine implies; they exist so that every number in
-// DESIGN.md §6 / tools/*.sh can be reproduced without rebuilding.
+// Environment switches, read ONCE per process.  The product library reads four names:
+//   HIPSOXR_NO_FFT, HIPSOXR_RESIDENT, HIPSOXR_AUTO_RESIDENT, HIPSOXR_RESIDENT_IDLE_US.
+// Everything else is an A/B or timing-experiment switch behind the numbers in DESIGN.md / profiles/ and is compiled in
+// only with -DHIPSOXR_DEBUG_SWITCHES (build.sh makes that build beside the product: _variants/dbg/libhipsoxr.so, loaded
+// through HIPSOXR_LIBRARY by tests/test_gpu_switches.py, tests/test_gpu_launch_forms.py and tools/*.sh).  None of them
+// changes results beyond what the selected engine implies (dbg_flags excepted: timing only).
 struct Switches {
-    // engine selection (A/B measurements)
-    bool no_fft = false;          // HIPSOXR_NO_FFT           AUTO never picks the frequency-domain engine
-    bool fft_no_pair = false;     // HIPSOXR_FFT_NO_PAIR      one block per workgroup instead of the paired kernel
+    // ---- product ----
+    bool no_fft = false;          // HIPSOXR_NO_FFT           AUTO never picks the frequency-domain engine (every job bit-exact)
+    bool resident = false;        // HIPSOXR_RESIDENT         small-chunk synchronous streams use the resident kernel (as the HIPSOXR_RESIDENT flag)
+    bool auto_resident = false;   // HIPSOXR_AUTO_RESIDENT    streams turn the resident path on by themselves after 16 small back-to-back calls
+    int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
+    // ---- debug builds only (-DHIPSOXR_DEBUG_SWITCHES) ----
+    bool fft_no_pair = false;     // HIPSOXR_FFT_NO_PAIR      one block per workgroup instead of the paired kernels
     bool fft_no_chpair = false;   // HIPSOXR_FFT_NO_CHPAIR    pair blocks even for interleaved even-channel data
     bool fft_no_xcd_map = false;  // HIPSOXR_FFT_NO_XCD_MAP   plain (block, column) workgroup ids for interleaved data
-    bool fft_persist = false;     // HIPSOXR_FFT_PERSIST      48k<->44.1k / 44.1k<->16k float32 jobs on resident workgroups with an item queue (k_fft_pair2p: A/B only, slower)
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
     bool fft_no_tiny = false;     // HIPSOXR_FFT_NO_TINY      never the quarter-size blocks
-    bool fft_small_4pass = false; // HIPSOXR_FFT_SMALL_4PASS  small 48k->44.1k jobs on round 1's four-pass low-latency schedule (first-generation kernel)
-    bool fft_pair_v1 = false;     // HIPSOXR_FFT_PAIR_V1      unit-stride jobs on k_fft_pair instead of k_fft_pair2
+    int fft_x2 = -1;              // HIPSOXR_FFT_X2           1 / 0: always / never two block pairs per workgroup (k_fft_pair2<.., 2>); default: by job size
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_mfma64 = false;       // HIPSOXR_NO_MFMA64        float64 engine (float64 / int32 I/O) on the vector ALU (k_tile) instead of v_mfma_f64
     bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)
     bool no_chain = false;        // HIPSOXR_NO_CHAIN         small launches on k_gather / k_interp
     bool no_done_words = false;   // HIPSOXR_NO_DONE_WORDS    streaming calls wait on an event, not on the kernel's completion words
-    bool resident = false;        // HIPSOXR_RESIDENT         small-chunk synchronous streams use the resident kernel (as the HIPSOXR_RESIDENT flag)
-    bool no_auto_resident = false; // HIPSOXR_NO_AUTO_RESIDENT streams never turn the resident path on by themselves (16 small back-to-back calls do, by default)
-    int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
     int direct_max = 0;           // HIPSOXR_DEBUG_DIRECT_MAX  largest result (bytes) a kernel writes straight into pinned host memory (0: engine.cpp's rule)
     bool resident_no_bar = false; // HIPSOXR_RESIDENT_NO_BAR  mailbox words and input stay in pinned host memory even on large-BAR systems
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids
@@ -97,8 +100,6 @@ struct Switches {
     int dbg_nrt = 0, dbg_nw = 0;  // HIPSOXR_DEBUG_NRT / _NW  tiles / waves per workgroup
     int dbg_split = 0;            // HIPSOXR_DEBUG_SPLIT      grid.z unit split
     int dbg_chain_no = 0;         // HIPSOXR_DEBUG_CHAIN_NO   outputs per workgroup of k_chain (power of two <= 32)
-    int dbg_walk = 0;             // HIPSOXR_DEBUG_WALK       blocks walked per workgroup by the channel-pair kernel (1 = never walk; default 3 for large jobs)
-    int dbg_stagger = 0;          // HIPSOXR_DEBUG_STAGGER    k_fft_pair2p: start offset in cycles between the workgroup slots of a CU
     size_t dbg_lds = 0;           // HIPSOXR_DEBUG_LDS        extra dynamic LDS (occupancy experiments)
     bool dbg_slab32 = false;       // HIPSOXR_DEBUG_SLAB32     k_tile_mfma_p: 32-period slabs whatever the job size (A/B)
     bool no_halves = false;        // HIPSOXR_DEBUG_NO_HALVES  k_tile_mfma: both half-chains of a row tile on one wave for small jobs too (A/B)
@@ -107,8 +108,9 @@ struct Switches {
     int dbg_mfma64_pb = 0;         // HIPSOXR_DEBUG_MFMA64_PB  k_tile_mfma64_p: periods per slab, 16 or 32 (default: 16 below 1536 slabs of 32)
     bool dbg_mfma64_split = false; // HIPSOXR_DEBUG_MFMA64_SPLIT k_tile_mfma64_p: units of 16 periods even where 4 divides the tile count
     size_t dbg_mfma64_lds = 0;    // HIPSOXR_DEBUG_MFMA64_LDS LDS budget (bytes) that picks the float64 MFMA kernel's slab: 64, 32 or 16 periods
-    size_t dbg_fft_lds = 0;       // HIPSOXR_DEBUG_FFT_LDS    the same for k_fft_block
-    const char *dbg_trace = nullptr; // HIPSOXR_DEBUG_TRACE   path for per-wave s_memtime stamps (k_tile_mfma_p)
+    size_t dbg_fft_lds = 0;       // HIPSOXR_DEBUG_FFT_LDS    the same for the frequency-domain kernels
+    int dbg_tile_form = 0;        // HIPSOXR_DEBUG_TILE_FORM  k_tile_mfma_p: force launch form 1..4 (slab 64 whole / 64 split / 32 whole / 32 split)
+    const char *dbg_trace = nullptr; // HIPSOXR_DEBUG_TRACE   path for per-wave s_memtime stamps (k_tile_mfma_p; k_fft_pair2 with -DFFT2_TRACE)
 };
 const Switches &switches();
 

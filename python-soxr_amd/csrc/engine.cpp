@@ -111,11 +111,14 @@ struct hipsoxr_stream {
     // Resident kernel (HIPSOXR_RESIDENT): synchronous small chunks are handed to a kernel that stays on the GPU
     // between calls, through a mailbox in pinned memory — no HIP call per chunk (see resident_emit)
     bool resident = false;
-    // Low latency by default: a constant-rate interleaved stream that is being fed small chunks back to back turns the
-    // resident path on by itself after kAutoResidentRun such calls in a row (each within half the kernel's idle time of
-    // the one before: a caller pacing 10 ms chunks in real time gains nothing from a kernel that leaves after 1 ms, and
-    // is left alone).  HIPSOXR_NO_AUTO_RESIDENT turns this off; the flag / environment switch turn it on from call 1.
-    bool resident_auto_ok = false;
+    // Opt-in (flag HIPSOXR_AUTO_RESIDENT / environment HIPSOXR_AUTO_RESIDENT): an interleaved stream that is being fed small
+    // chunks back to back turns the resident path on by itself after kAutoResidentRun such calls in a row (each within
+    // half the kernel's idle time of the one before: a caller pacing 10 ms chunks in real time gains nothing from a
+    // kernel that leaves after 1 ms, and is left alone) and OFF again at the first call that breaks the run (a gap, a
+    // large chunk, an instance that idled out).  Not a default: a spinning kernel makes every device-wide
+    // synchronisation in the process (hipDeviceSynchronize, hipFree) wait until it leaves — README / INTEGRATION.md.
+    // Auto instances may hold an eighth of the chip together, flagged ones half of it.
+    bool resident_auto_ok = false, resident_by_auto = false;
     unsigned small_run = 0;
     std::chrono::steady_clock::time_point last_small;
     struct Resident {
@@ -166,6 +169,7 @@ struct DeviceGuard {
 // n * 1024 / occ milli-CUs (with a large-LDS plan, one workgroup per CU, 64 workgroups are 64 CUs), and the process
 // keeps at most half the chip resident, so every admitted instance's workgroups really are on the chip together.
 static std::atomic<int64_t> g_resident_mcu{0};
+static std::mutex g_resident_mu; // reserving budget = read it, launch, add: one instance at a time
 static const unsigned kAutoResidentRun = 16; // small back-to-back synchronous calls before a stream turns resident by itself
 
 // Retire the stream's resident kernel, if one is running: everything else that uses the HIP stream queues
@@ -720,7 +724,9 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
         rl.epoch = r.epoch; rl.idle_us = std::max(50, switches().resident_idle_us);
         hipsoxr_job_t cap = jr; // room for chunks a quarter longer than this one
         cap.out_frames = std::max<int64_t>(64, j.out_frames + j.out_frames / 4 + 2);
+        std::lock_guard<std::mutex> reserve(g_resident_mu);
         rl.used_mcu = g_resident_mcu.load(); // (the launcher knows occupancy and CU count: it refuses what does not fit)
+        rl.budget_shift = s->resident_by_auto ? 3 : 1; // the share of the chip resident instances may hold: 1/8 (auto) or 1/2
         if (const char *e = launch_job(&s->plan->p, cap, s->st, vp, &rl)) { // (vp: only says "variable rate" here — every message carries its own clock)
             if (rl.over_budget) return ""; // over the budget: the ordinary path, this time
             (void)e; // not a job the resident form serves: the ordinary path does
@@ -855,7 +861,18 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
         const auto gap = std::chrono::microseconds(std::max(50, switches().resident_idle_us) / 2);
         s->small_run = (small_call && (s->small_run == 0 || now - s->last_small < gap)) ? s->small_run + 1 : 0;
         s->last_small = now;
-        if (s->small_run >= kAutoResidentRun) s->resident = true;
+        if (s->small_run >= kAutoResidentRun) s->resident = s->resident_by_auto = true;
+    } else if (s->resident_by_auto) {
+        // a stream that turned resident by itself drops back the moment the run breaks: a call that is not small, one
+        // that comes after a gap (its instance has idled out or is about to), or an instance that left on its own
+        const auto now = std::chrono::steady_clock::now();
+        const auto gap = std::chrono::microseconds(std::max(50, switches().resident_idle_us) / 2);
+        if (!small_call || now - s->last_small >= gap || (s->res.running && s->res.box->exited == s->res.epoch)) {
+            resident_stop(s);
+            s->resident = s->resident_by_auto = false;
+            s->small_run = small_call ? 1 : 0;
+        }
+        s->last_small = now;
     }
     if (s->resident && small_call) {
         if (const char *e = resident_emit(s, j, &served, v.on ? &vp : nullptr)) return e;
@@ -1029,7 +1046,7 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
     s->elem = (int)io & 3; s->split = ((int)io & 4) != 0; s->flags = flags;
     s->defer = (flags & HIPSOXR_DEFER) && !(flags & HIPSOXR_VR) && !s->split;
     s->resident = ((flags & HIPSOXR_RESIDENT) || switches().resident) && !s->defer && !s->split;
-    s->resident_auto_ok = !s->resident && !s->defer && !s->split && !switches().no_auto_resident;
+    s->resident_auto_ok = !s->resident && !s->defer && !s->split && ((flags & HIPSOXR_AUTO_RESIDENT) || switches().auto_resident);
     if (flags & HIPSOXR_VR) {
         const double io0 = plan->p.in_rate / plan->p.out_rate;
         if (!(io0 > 9.5367431640625e-07) || !(io0 < 1048576.)) { delete s; return "io ratio out of range for variable rate"; }

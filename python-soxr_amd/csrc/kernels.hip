@@ -58,15 +58,23 @@ const Switches &switches()
         Switches w;
         auto on = [](const char *n) { return getenv(n) != nullptr; };
         auto num = [](const char *n) { const char *v = getenv(n); return v ? atoi(v) : 0; };
-        w.no_fft = on("HIPSOXR_NO_FFT"); w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR");
-        w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP"); w.fft_persist = on("HIPSOXR_FFT_PERSIST"); w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY");
-        w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY"); w.fft_small_4pass = on("HIPSOXR_FFT_SMALL_4PASS"); w.fft_pair_v1 = on("HIPSOXR_FFT_PAIR_V1");
-        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32");
-        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_stagger = num("HIPSOXR_DEBUG_STAGGER"); w.dbg_walk = num("HIPSOXR_DEBUG_WALK"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.resident = on("HIPSOXR_RESIDENT"); w.no_auto_resident = on("HIPSOXR_NO_AUTO_RESIDENT"); w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR");
-        if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
+        w.no_fft = on("HIPSOXR_NO_FFT"); w.resident = on("HIPSOXR_RESIDENT"); w.auto_resident = on("HIPSOXR_AUTO_RESIDENT");
+        if (getenv("HIPSOXR_RESIDENT_IDLE_US")) w.resident_idle_us = num("HIPSOXR_RESIDENT_IDLE_US");
+#ifdef HIPSOXR_DEBUG_SWITCHES
+        w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR"); w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP");
+        w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY"); w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY");
+        if (getenv("HIPSOXR_FFT_X2")) w.fft_x2 = num("HIPSOXR_FFT_X2");
+        w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING");
+        w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX");
+        w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT");
+        w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
-        w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
-        w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
+        w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
+        w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD");
+        w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT");
+        w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS");
+        w.dbg_tile_form = num("HIPSOXR_DEBUG_TILE_FORM"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
+#endif
         return w;
     }();
     return sw;
@@ -2235,7 +2243,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     if (occ < 1 || (int64_t)gx * gy > (int64_t)occ * cus / 4 || (int64_t)gx * gy > (int64_t)kResidentMaxWgs) return "resident kernel: message too large";
                     // process-wide budget in CU capacity (engine.cpp): all resident instances together hold at most half the chip
                     res->cost_mcu = (uint32_t)(((int64_t)gx * gy * 1024 + occ - 1) / occ);
-                    if (res->used_mcu + (int64_t)res->cost_mcu > (int64_t)cus * 1024 / 2) { res->over_budget = true; return "resident kernel: over the budget"; }
+                    if (res->used_mcu + (int64_t)res->cost_mcu > ((int64_t)cus * 1024) >> res->budget_shift) { res->over_budget = true; return "resident kernel: over the budget"; }
                     ResidentArgs ra;
                     std::memset(&ra, 0, sizeof ra);
                     ra.ca = ca; ra.box = res->box; ra.words = res->words; ra.ctl = res->ctl; ra.base_seq = res->base_seq; ra.epoch = res->epoch;

@@ -159,8 +159,11 @@ class ResampleStream:
                                     call instead of ~31 us).  Output identical, frames surface in the same
                                     call.  The kernel leaves by itself 1 ms after the last call
                                     (HIPSOXR_RESIDENT_IDLE_US).  Interleaved streams (constant or variable rate), not with
-                                    `deferred`.  Without the flag a stream turns this path on by itself after 16 small
-                                    back-to-back calls.
+                                    `deferred`.  resident="auto" (or environment HIPSOXR_AUTO_RESIDENT): the stream turns
+                                    this path on by itself after 16 small back-to-back calls and off again when the
+                                    run breaks.  Opt-in, because while a resident kernel spins every device-wide
+                                    synchronisation in the process (torch.cuda.synchronize, hipFree) waits for it to
+                                    leave.
     dither_seed : int               (extension) seed of the int16 TPDF dither.  libsoxr seeds randomly per
                                     handle; here dither is a deterministic function of (seed, channel,
                                     output index), default seed 0 — pass distinct seeds to decorrelate
@@ -178,7 +181,7 @@ class ResampleStream:
         self._ratio = float(out_rate) / float(in_rate)
         self._h = _C.c_void_p()
         flags = ((_n.VR if vr else 0) | (_n.DEFER if deferred and not vr else 0)
-                 | (_n.RESIDENT if resident and not deferred else 0))
+                 | ((_n.AUTO_RESIDENT if resident == "auto" else _n.RESIDENT) if resident and not deferred else 0))
         _n.check(_n.lib.hipsoxr_stream_create(float(in_rate), float(out_rate), self._channels,
                                               elem, recipe, flags, _C.byref(self._h)))
         if dither_seed:

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhipsoxr.so")
+# HIPSOXR_LIBRARY: another build of the same library — the tests and tools that sweep A/B switches load the
+# -DHIPSOXR_DEBUG_SWITCHES build (python-soxr_amd/_variants/dbg/) this way; the product build ignores those switches.
+LIB_PATH = os.environ.get("HIPSOXR_LIBRARY") or os.path.join(_HERE, "libhipsoxr.so")
 if not os.path.exists(LIB_PATH):
     # installed wheel: the one copy of the engine is the libsoxr-named object (it exports both ABIs)
     _alt = os.path.join(_HERE, "prefix", "lib", "libsoxr.so.0")
@@ -55,6 +57,7 @@ VR = 32
 NO_DITHER = 8
 DEFER = 64
 RESIDENT = 128
+AUTO_RESIDENT = 256
 KERNEL_AUTO, KERNEL_GATHER, KERNEL_TILE, KERNEL_TILE_VALU, KERNEL_TILE_MFMA, KERNEL_FFT, KERNEL_EXACT, KERNEL_WAVE_DOT, KERNEL_FFT_F64 = range(9)
 
 

@@ -47,3 +47,25 @@ def test_version_and_device_count_do_not_need_a_gpu():
     from soxr_amd import _native
     assert _native.version().startswith("hipsoxr-")
     assert _native.device_count() >= 0
+
+
+def test_product_library_reads_four_environment_names():
+    """The product build reads HIPSOXR_NO_FFT, HIPSOXR_RESIDENT, HIPSOXR_AUTO_RESIDENT, HIPSOXR_RESIDENT_IDLE_US and no
+    other HIPSOXR_* name: the A/B and timing-experiment switches exist only in the -DHIPSOXR_DEBUG_SWITCHES build
+    (python-soxr_amd/_variants/dbg/), which tests/test_gpu_switches.py sweeps."""
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(os.path.dirname(here), "python-soxr_amd")
+
+    def names(path):
+        with open(path, "rb") as f:
+            blob = f.read()
+        return set(m.decode() for m in re.findall(rb"HIPSOXR_[A-Z0-9_]{3,}", blob))
+
+    prod = names(os.path.join(pkg, "soxr_amd", "libhipsoxr.so"))
+    allowed = {"HIPSOXR_NO_FFT", "HIPSOXR_RESIDENT", "HIPSOXR_AUTO_RESIDENT", "HIPSOXR_RESIDENT_IDLE_US"}
+    env_like = {n for n in prod if not n.startswith(("HIPSOXR_KERNEL_", "HIPSOXR_F32", "HIPSOXR_F64", "HIPSOXR_I"))}
+    assert env_like <= allowed, sorted(env_like - allowed)
+    dbg = os.path.join(pkg, "_variants", "dbg", "libhipsoxr.so")
+    assert os.path.exists(dbg)
+    assert {"HIPSOXR_FFT_X2", "HIPSOXR_DEBUG_SLAB64", "HIPSOXR_NO_PLANES"} <= names(dbg)

@@ -38,6 +38,7 @@ def _run(tmp_path, name, env_extra, a, b, q, dt, frames, ch, seed):
     out = str(tmp_path / (name + ".npy"))
     env = {k: v for k, v in os.environ.items() if not k.startswith("HIPSOXR_")}
     env.update(env_extra)
+    env["HIPSOXR_LIBRARY"] = os.path.join(ROOT, "python-soxr_amd", "_variants", "dbg", "libhipsoxr.so")  # the build that reads HIPSOXR_DEBUG_*
     subprocess.run([sys.executable, "-c", _CHILD, os.path.join(ROOT, "python-soxr_amd"), str(a), str(b), q, dt, str(frames), str(ch), str(seed), out],
                    check=True, env=env, timeout=600)
     return np.load(out)

@@ -3,7 +3,7 @@
 the per-wave s_memtime stamps.  Stamp index: 0 start | forward: 1 pass-1 done (input arrived + butterfly +
 LDS stores), 2 barrier, 3 pass-2 done, 4 barrier, 5 pass-3 done | 6 barrier | inverse: 7, 8, 9, 10, 11 likewise
 (11 = staging written) | 12 barrier | 13 HW_ID | 14 XCC_ID | 15 end (run stored).
-    HIPSOXR_VARIANT=trace HIPSOXR_EXTRA_FLAGS=-DFFT2_TRACE bash python-soxr_amd/build.sh   (here)
+    HIPSOXR_VARIANT=trace HIPSOXR_EXTRA_FLAGS="-DFFT2_TRACE -DHIPSOXR_DEBUG_SWITCHES" bash python-soxr_amd/build.sh   (here)
     tools/with_variant.sh trace python tools/trace_pair2.py                                 (GPU box)
 Besides the per-phase medians it rebuilds every CU's timeline from the HW_ID / XCC_ID words: how many workgroups
 a CU holds over time, how long a freed slot stays empty, and what a CU's steady-state rate is."""
@@ -81,3 +81,31 @@ for c in cus:
     if len(e) >= 4:
         tail4.append(e[-1] - e[-4]); tail2.append(e[-1] - e[-2])
 print("drain: last end minus 4th-last end per CU (cycles/100) median %.1f; minus 2nd-last %.1f" % (np.median(tail4) / 100, np.median(tail2) / 100))
+
+# ---- do the workgroups of a CU run in step?  At any instant, how many of a CU's resident workgroups are in their load
+# phase (stamp 0 -> 1 of wave 0: input requested ... first pass stored)?  If phases were independent the count would be
+# binomial with p = the load phase's share of a lifetime; bunching shows as excess mass at 0 and at 3-4.
+f1s, f1e = t[:, 0, 0], t[:, 0, 1]
+hist = np.zeros(8); res_hist = np.zeros(8); tot = 0.0
+for c in cus:
+    m = key == c
+    ev = []
+    for a, b in zip(f1s[m], f1e[m]): ev.append((a, 1, 0)); ev.append((b, -1, 0))
+    for a, b in zip(ws[m], we[m]): ev.append((a, 0, 1)); ev.append((b, 0, -1))
+    ev.sort()
+    lo, hi = np.percentile(ws[m], 20), np.percentile(we[m], 80)     # steady state of this CU
+    nl = nr = 0; last = None
+    for tt, dl, dr in ev:
+        if last is not None and tt > last:
+            a, b = max(last, lo), min(tt, hi)
+            if b > a:
+                hist[min(nl, 7)] += b - a; res_hist[min(nr, 7)] += b - a; tot += b - a
+        nl += dl; nr += dr; last = tt
+p_load = float(np.median((f1e - f1s) / np.maximum(we - ws, 1)))
+print("share of a lifetime in the load phase (median): %.3f" % p_load)
+print("time share with k workgroups of the CU in their load phase: " + " ".join("k=%d: %.3f" % (k, hist[k] / tot) for k in range(6)))
+print("time share with k workgroups resident:                      " + " ".join("k=%d: %.3f" % (k, res_hist[k] / tot) for k in range(6)))
+from math import comb
+nres = sum(k * res_hist[k] for k in range(8)) / tot
+n = int(round(nres))
+print("binomial(n=%d, p=%.3f) for comparison:                        " % (n, p_load) + " ".join("k=%d: %.3f" % (k, comb(n, k) * p_load ** k * (1 - p_load) ** (n - k)) for k in range(min(n, 5) + 1)))
