@@ -180,14 +180,22 @@ typedef struct {
      * length per call, src/soxr/__init__.py:182-231).  NULL: every clip has in_frames / out_frames and starts at
      * clip * clip_stride.  Else n_clips rows of four int64 { in_offset, in_frames, out_offset, out_frames }, offsets in
      * ELEMENTS from `in` / `out` (clip c, frame f, channel ch is at in + in_offset[c] + f*in_frame_stride +
-     * ch*in_chan_stride; the clip strides are ignored), out_frames[c] <= hipsoxr_plan_out_len(in_frames[c]).  The
-     * table is given twice, in host memory (clip_table) and in device memory (clip_table_dev, same content);
-     * in_frames / out_frames of the job are then the LARGEST per-clip values.  Whole signals only (in_abs0 == 0,
-     * out_k0 == 0).  Unit-stride float columns go out as one launch of the frequency-domain engine; every other
+     * ch*in_chan_stride; the clip strides are ignored), out_frames[c] <= hipsoxr_plan_out_len(in_frames[c]).
+     * clip_table is in HOST memory and is what the library validates (counts against the job and the plan; the
+     * caller guarantees that offset + extent stays inside its buffers — the library does not know their sizes).
+     * clip_table_dev is optional: NULL = the library uploads the host table itself, in stream order, on every call
+     * (~10 us); a device copy supplied by the caller (a prepared job launched many times) is used as it is and must
+     * equal the host table — it is not checked.  in_frames / out_frames of the job are then the LARGEST per-clip
+     * values.  Whole signals only (in_abs0 == 0, out_k0 == 0).  Unit-stride float columns go out as one launch of
+     * the frequency-domain engine (AUTO: from 2^13 output samples in all, as for equal-length jobs); every other
      * case is served clip by clip, same results. */
     const int64_t *clip_table;
     const int64_t *clip_table_dev;
 } hipsoxr_job_t;
+/* ZERO-INITIALISE the struct (memset / = {0}) before filling it: fields are only ever APPENDED, a zero field always
+ * means "feature not used", and hipsoxr_version() changes when one is added (0.1: up to dither_seed; 0.3: clip_table,
+ * clip_table_dev).  A client compiled against an older header must not be run against a newer struct-consuming
+ * library without recompiling — check the version string at load time as soxr_amd/_native.py does. */
 
 /* Enqueue the job on `hip_stream` (a hipStream_t; NULL = default stream). Asynchronous. */
 HIPSOXR_API hipsoxr_error_t hipsoxr_run_device(hipsoxr_plan_t *, const hipsoxr_job_t *job,

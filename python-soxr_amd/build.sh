@@ -34,7 +34,7 @@ if [ -z "$HIPSOXR_VARIANT" ]; then
   "$HIPCC" $COMMON -ffp-contract=off ${HIPSOXR_EXTRA_FLAGS} -DHIPSOXR_DEBUG_SWITCHES -c "$SRC/kernels.hip" -o "$OBJ/kernels_dbg.o" & P8=$!
 fi
 # (fft.hip in three translation units: see "Three translation units" there)
-FFTFLAGS="-ffp-contract=fast -fno-slp-vectorize"
+FFTFLAGS="${HIPSOXR_FFTFLAGS:--ffp-contract=fast -fno-slp-vectorize}"
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=0 -c "$SRC/fft.hip" -o "$OBJ/fft.o" & P4=$!
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=1 -c "$SRC/fft.hip" -o "$OBJ/fft1.o" & P6=$!
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=2 -c "$SRC/fft.hip" -o "$OBJ/fft2.o" & P7=$!

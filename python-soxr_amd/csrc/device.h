@@ -84,7 +84,7 @@ struct Switches {
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
     bool fft_no_tiny = false;     // HIPSOXR_FFT_NO_TINY      never the quarter-size blocks
-    int fft_x2 = -1;              // HIPSOXR_FFT_X2           1 / 0: always / never two block pairs per workgroup (k_fft_pair2<.., 2>); default: by job size
+    int fft_x2 = -1;              // HIPSOXR_FFT_X2           1: two block pairs per workgroup (k_fft_pair2<.., 2>; builds with -DFFT_EXPERIMENT_X2 only)
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_mfma64 = false;       // HIPSOXR_NO_MFMA64        float64 engine (float64 / int32 I/O) on the vector ALU (k_tile) instead of v_mfma_f64
     bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)

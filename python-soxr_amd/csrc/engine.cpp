@@ -316,7 +316,7 @@ static void plan_release(hipsoxr_plan *h)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *hipsoxr_version(void) { return "hipsoxr-0.1.0 (gfx950)"; }
+const char *hipsoxr_version(void) { return "hipsoxr-0.4.0 (gfx950)"; }
 
 int hipsoxr_device_count(void) { return device_count(); }
 

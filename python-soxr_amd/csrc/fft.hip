@@ -58,8 +58,16 @@ namespace hipsoxr {
 typedef float2 cf;
 typedef double2 cd;
 template <typename C> using real_of = decltype(C().x);
+#ifdef FFT_PK_ADD // experiment: complex add / subtract as one packed instruction (v_pk_add_f32) through native vector types
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return __builtin_bit_cast(float2, __builtin_bit_cast(v2f_t, a) + __builtin_bit_cast(v2f_t, b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return __builtin_bit_cast(float2, __builtin_bit_cast(v2f_t, a) - __builtin_bit_cast(v2f_t, b)); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return double2(a.x - b.x, a.y - b.y); }
+#else
 template <typename C> __device__ __forceinline__ C cadd(C a, C b) { return C(a.x + b.x, a.y + b.y); }
 template <typename C> __device__ __forceinline__ C csub(C a, C b) { return C(a.x - b.x, a.y - b.y); }
+#endif
 template <typename C> __device__ __forceinline__ C cmul(C a, C b) { return C(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 template <typename C> __device__ __forceinline__ C cconj(C a) { return C(a.x, -a.y); }
 // multiply by SIGN * i
@@ -525,12 +533,27 @@ __device__ __forceinline__ void *uniform_ptr(void *p) // the same address, prova
     return reinterpret_cast<void *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
                                     (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v));
 }
+// Cache policy of the signal's loads and stores (the `aux` operand of the raw buffer builtins: 1 = sc0, 2 = nt, 16 = sc1).
+// k_fft_pair2's staged run is written once, in whole 16-byte granules of whole lines, and not read again by the launch:
+// NON-TEMPORAL stores keep it out of the L2's and the Infinity Cache's way — and the batch launch, which runs AT the
+// board's 1.4 kW power cap (tools/power_probe.py: 1370 W, shader clock throttled from 2.4 to 2.05 GHz), gets 10-14 %
+// faster for 12 % less energy per launch (122 -> 109 us on one box, 122 -> 104.6 on another; sc0 0 %, sc1 +4 %,
+// sc1 nt -5 %); float64 jobs -10 %, the 60 s clip -4 %.  Only there: stores that write PART of a line per instruction
+// want the L2's write combining — k_fft_strided2's 8-byte words at a frame stride +17 % with nt (configs[2] 45.7 -> 53.7
+// us), the exact engine's 4-byte stores +3 .. +87 % (tools/nt_ab.sh).  Loads: nt +9 % (neighbouring blocks share their
+// overlap through the caches), sc0 / sc1 0 %: default policy.  profiles/r04_cache_policy.txt.
+#ifndef FFT_LOAD_AUX
+#define FFT_LOAD_AUX 0
+#endif
+#ifndef FFT_STORE_AUX
+#define FFT_STORE_AUX 2
+#endif
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 template <typename Real> __device__ __forceinline__ Real buf_load_real(__amdgpu_buffer_rsrc_t r, int voff, int soff);
 template <> __device__ __forceinline__ float buf_load_real<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, FFT_LOAD_AUX));
 }
 template <> __device__ __forceinline__ double buf_load_real<double>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
@@ -683,7 +706,7 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
                 for (int c = 0; c < EPS; ++c)
                     if (c >= sh && c - sh < valid) ybase[c - sh] = e[c];
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), ro, q * 16, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), ro, q * 16, 0, FFT_STORE_AUX);
             }
         }
     }
@@ -1030,7 +1053,15 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
      k_fft_strided2<PairOf<NA, NB, NT>, float, true>, k_fft_strided2<PairOf<NA, NB, NT>, double, true>, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>, X2, NT2}
 #define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, nullptr, 0)
+// Two pairs per workgroup (P = 2: one set of twiddle powers and filter values for both, 6 % fewer vector-ALU instructions):
+// measured in round 4 and NOT faster — 5120-point blocks 158 vs 133 us (80 KB of LDS: two workgroups per CU), 2560-point
+// blocks 137 vs 138 (P = 1, four waves) — because the batch launch is bound by the board's power cap, not by instruction
+// issue (profiles/NOTES_r04.md).  Instantiated only in experiment builds (-DFFT_EXPERIMENT_X2; tools/x2_check.py, tools/nt_sweep.sh).
+#ifdef FFT_EXPERIMENT_X2
 #define HIPSOXR_PAIR_X2(L, M, k, small, NA, NB, NT, NT2) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, (k_fft_pair2<PairOf<NA, NB, NT2>, float, float, 2>), NT2)
+#else
+#define HIPSOXR_PAIR_X2(L, M, k, small, NA, NB, NT, NT2) HIPSOXR_PAIR(L, M, k, small, NA, NB, NT)
+#endif
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
         HIPSOXR_PAIR_X2(147, 160, 32, false, 5120, 4704, 384, 384), HIPSOXR_PAIR_X2(147, 160, 16, true, 2560, 2352, 384, 256),   // 48k -> 44.1k
@@ -1160,15 +1191,12 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 size_t lds = lds1;
                 if (v2ok) {
                     kern = io64 ? use->kern2d : wide32 ? use->kern2fd : use->kern2;
-                    // Throughput jobs (float32): two pairs per workgroup in one instruction stream — when every CU still
-                    // gets its fill of workgroups that way (HIPSOXR_FFT_X2 = 1 / 0 forces / forbids)
-                    const int64_t wg2 = ((int64_t)grid.x + 1) / 2 * grid.y;
-                    const int x2 = switches().fft_x2;
-                    if (!f64 && use->kern2x2 && x2 != 0 && (x2 > 0 || wg2 >= 2048) && 4 * (int64_t)g.hop_periods * p->M * (int64_t)esz < (1LL << 30)) {
+                    // experiment builds: HIPSOXR_FFT_X2=1 runs two pairs per workgroup in one instruction stream (see HIPSOXR_PAIR_X2)
+                    if (!f64 && use->kern2x2 && switches().fft_x2 > 0 && 4 * (int64_t)g.hop_periods * p->M * (int64_t)esz < (1LL << 30)) {
                         kern = use->kern2x2; nt = use->nt2; lds = 2 * lds1;
                         grid.x = (grid.x + 1) / 2;
                     }
-#ifdef FFT_NT_SWEEP // experiment build: thread-count sweep of the 48k -> 44.1k kernels (HIPSOXR_DEBUG_NW = waves per workgroup)
+#if defined(FFT_NT_SWEEP) && defined(FFT_EXPERIMENT_X2) // experiment build: thread-count sweep of the 48k -> 44.1k kernels (HIPSOXR_DEBUG_NW = waves per workgroup)
                     if (!f64 && p->L == 147 && p->M == 160 && switches().dbg_nw) {
                         const int nw = switches().dbg_nw;
                         const bool two = kern == use->kern2x2;

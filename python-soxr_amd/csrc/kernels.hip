@@ -107,15 +107,20 @@ struct OutCtx {
 // channel is keyed by its index in the WHOLE signal
 static thread_local uint32_t t_ch_base = 0;
 
+// (Plain stores: a lane writes 2-8 bytes, a wave's instruction a part of each line it touches, and the L2's write combining
+// is what turns that into whole-line traffic — non-temporal stores cost the 60 s clip 3 %, int32 6 %, 8-channel interleaved
+// data 87 %; tools/nt_ab.sh, profiles/r04_cache_policy.txt.  The frequency-domain kernel's staged 16-byte stores are the
+// case where they pay: fft.hip, FFT_STORE_AUX.)
+template <typename T> __device__ __forceinline__ void put_out(T *p, T v) { *p = v; }
 template <typename Real>
 __device__ __forceinline__ void store_out(float *p, Real v, const OutCtx &, uint32_t, int64_t)
 {
-    *p = (float)v;
+    put_out(p, (float)v);
 }
 template <typename Real>
 __device__ __forceinline__ void store_out(double *p, Real v, const OutCtx &, uint32_t, int64_t)
 {
-    *p = (double)v;
+    put_out(p, (double)v);
 }
 template <typename Real>
 __device__ __forceinline__ void store_out(int16_t *p, Real v, const OutCtx &c, uint32_t ch, int64_t k)
@@ -127,7 +132,7 @@ __device__ __forceinline__ void store_out(int16_t *p, Real v, const OutCtx &c, u
     if (r > 32767.f) { r = 32767.f; clip = true; }
     else if (r < -32768.f) { r = -32768.f; clip = true; }
     if (clip && c.clip_counter) atomicAdd((unsigned long long *)c.clip_counter, 1ULL);
-    *p = (int16_t)r;
+    put_out(p, (int16_t)r);
 }
 template <typename Real>
 __device__ __forceinline__ void store_out(int32_t *p, Real v, const OutCtx &c, uint32_t, int64_t)
@@ -137,7 +142,7 @@ __device__ __forceinline__ void store_out(int32_t *p, Real v, const OutCtx &c, u
     if (r > 2147483647.) { r = 2147483647.; clip = true; }
     else if (r < -2147483648.) { r = -2147483648.; clip = true; }
     if (clip && c.clip_counter) atomicAdd((unsigned long long *)c.clip_counter, 1ULL);
-    *p = (int32_t)r;
+    put_out(p, (int32_t)r);
 }
 
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -2693,17 +2698,38 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     if (j.clip_table) {
         if (vr || res) return "ragged batches: constant-rate device jobs only";
         if (j.in_abs0 != 0 || j.out_k0 != 0) return "ragged batches: whole signals only (in_abs0 == 0, out_k0 == 0)";
-        if (!j.clip_table_dev) return "ragged batches need the table in device memory too (clip_table_dev)";
+        int64_t total_out = 0;
         for (uint32_t c = 0; c < j.n_clips; ++c) {
             const int64_t *r = j.clip_table + 4 * (size_t)c;
-            if (r[1] < 0 || r[3] < 0 || r[1] > j.in_frames || r[3] > j.out_frames || (uint64_t)r[3] > plan_out_len(*p, (uint64_t)r[1]))
-                return "ragged batches: a clip's frame counts exceed the job's or the plan's output length";
+            if (r[0] < 0 || r[2] < 0 || r[1] < 0 || r[3] < 0 || r[1] > j.in_frames || r[3] > j.out_frames || (uint64_t)r[3] > plan_out_len(*p, (uint64_t)r[1]))
+                return "ragged batches: a clip's offsets or frame counts are negative, exceed the job's, or exceed the plan's output length";
+            total_out += r[3];
         }
-        if ((j.kernel == HIPSOXR_KERNEL_AUTO || j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_FFT_F64) &&
-            (uint64_t)j.n_clips * j.n_channels <= 65535 && !switches().no_fft && fft_job_eligible(*p, j)) {
+        // AUTO takes the 1e-6-class engine under the same rule as for equal-length jobs (>= 2^13 outputs in all): engine
+        // choice — and with it bit-exactness — does not depend on whether a table is present
+        const bool want_fft = j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_FFT_F64;
+        const bool big = total_out * (int64_t)j.n_channels >= (1 << 13);
+        if ((want_fft || (j.kernel == HIPSOXR_KERNEL_AUTO && big && !switches().no_fft)) &&
+            (uint64_t)j.n_clips * j.n_channels <= 65535 && fft_job_eligible(*p, j)) {
             if (const char *e = device_bank_ensure(p, engine_prec(j.elem))) return e;
+            // The kernel reads the DEVICE copy of the table.  Without one (clip_table_dev == NULL) the host table — the
+            // one validated above — is uploaded here, in stream order (stream-ordered allocation: the buffer lives until
+            // the launch behind it has run).  A caller-supplied device copy is trusted to equal the host table.
+            hipsoxr_job_t jj = j;
+            void *tmp = nullptr;
+            if (!jj.clip_table_dev) {
+                const size_t bytes = (size_t)j.n_clips * 4 * sizeof(int64_t);
+                if (hipMallocAsync(&tmp, bytes, (hipStream_t)stream) != hipSuccess) return "ragged batches: no device memory for the clip table";
+                if (hipMemcpyAsync(tmp, j.clip_table, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+                    (void)hipFreeAsync(tmp, (hipStream_t)stream);
+                    return "ragged batches: clip table upload failed";
+                }
+                jj.clip_table_dev = (const int64_t *)tmp;
+            }
             bool handled = false;
-            if (const char *e = launch_fft(p, j, stream, &handled)) return e;
+            const char *e = launch_fft(p, jj, stream, &handled);
+            if (tmp) (void)hipFreeAsync(tmp, (hipStream_t)stream);
+            if (e) return e;
             if (handled) return nullptr;
         }
         if (j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_FFT_F64) return "FFT engine unavailable for this ragged job (unit-stride float columns of a tabled ratio)";

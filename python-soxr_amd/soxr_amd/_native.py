@@ -129,5 +129,12 @@ def version():
     return lib.hipsoxr_version().decode()
 
 
+# The ctypes mirrors above (Job = hipsoxr_job_t with its clip_table fields) are laid out for this ABI generation: a
+# library of another generation would read garbage from the struct's tail, so loading one is an import error.
+ABI_VERSION = "hipsoxr-0.4"
+if not version().startswith(ABI_VERSION):
+    raise ImportError(f"{LIB_PATH} is {version()!r}; this package binds {ABI_VERSION}.x (rebuild: python-soxr_amd/build.sh)")
+
+
 def device_count():
     return int(lib.hipsoxr_device_count())

@@ -3,11 +3,12 @@
 The reference has no batch axis and no GPU; its concurrency model is *threads over independent calls* with
 the GIL released (src/soxr_ext.cpp:222,297; tests/gil_bench.py:22-56).  The MI355X form of that model:
 
-* `resample_batch(clips, in_rate, out_rate, quality, devices=None)` — ONE process, one host thread + one HIP
-  stream per visible device; clips (any lengths: a corpus is ragged) are dealt to the devices in contiguous
-  blocks (`shard`), each device resamples its block with ONE launch (ragged job table, include/hipsoxr.h
-  `hipsoxr_job_t::clip_table`), results come back in the caller's order.  No data-path collective: clips are
-  independent.
+* `resample_batch(clips, in_rate, out_rate, quality, devices=None)` — ONE process, one host thread per visible
+  device; clips (any lengths: a corpus is ragged) are dealt to the devices by total frames (`shard_by_frames`), each
+  device resamples its share as ragged launches (job table, include/hipsoxr.h `hipsoxr_job_t::clip_table`), results
+  come back in the caller's order.  Device tensors are resampled where they lie (the table addresses them in
+  place); host arrays go through a pinned staging ring with the H2D copy of block k+1, the launch of block k and
+  the D2H copy of block k-1 overlapped on three streams.  No data-path collective: clips are independent.
 * one process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI): `shard(n, world, rank)` names the
   rank's clips and `broadcast_bank(plan, ...)` is the path's only collective — the shared filter bank from rank 0
   at plan time, through torch's communicator or, with no torch in the path, through `hipsoxr_plan_broadcast`
@@ -33,6 +34,21 @@ def shard(n_units, world, rank):
     base, rem = divmod(int(n_units), world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_frames(lengths, world):
+    """Partition clips of unequal length over `world` devices so that the devices' TOTAL frames are as even as greedy
+    longest-first assignment makes them (a ragged corpus dealt by count loads devices by luck).  Returns `world` lists
+    of clip indices (each ascending); every index appears exactly once.  Deterministic."""
+    if world < 1:
+        raise ValueError("need world >= 1")
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    loads, parts = [0] * world, [[] for _ in range(world)]
+    for i in order:
+        w = min(range(world), key=lambda k: (loads[k], k))
+        parts[w].append(i)
+        loads[w] += int(lengths[i])
+    return [sorted(p) for p in parts]
 
 
 def broadcast_bank(plan, group=None, root=0, comm=None, rank=None, stream=None, device=None):
@@ -92,13 +108,18 @@ def rank_info(plan, device=None, group=None):
 
 
 class RaggedJob:
-    """A batch of clips of unequal length on ONE device as one job: the clips packed end to end in a single buffer
-    `[total_frames, channels]`, the per-clip table of `hipsoxr_job_t::clip_table` built once (host and device copy),
-    `launch()` = one C call.  `outputs()` returns per-clip views of the packed result."""
+    """A batch of clips of unequal length on ONE device as one job.  Clips that are already device tensors are
+    resampled WHERE THEY LIE: the per-clip table of `hipsoxr_job_t::clip_table` addresses each one relative to the
+    lowest clip (no packed copy of the input); results go to one packed buffer `[total_out_frames, channels]`.
+    `launch()` = one C call.  `outputs()` returns per-clip views of the packed result.
+
+    Stream order: the job's tensors are produced on the caller's current stream; when it launches on another stream
+    that stream first waits for the current one (and the result records its use there)."""
 
     def __init__(self, plan, clips, kernel=_n.KERNEL_AUTO, stream=None, dither=None):
         """dither: TPDF dither on int16 output (None = on for int16, as `soxr_amd.resample` and libsoxr do; keyed by
-        channel and output index within each clip, so a clip's result does not depend on its neighbours)."""
+        channel and output index within each clip, so a clip's result does not depend on its neighbours).
+        stream: a torch.cuda.Stream (ordering handled here) or a raw hipStream_t handle (the caller orders it)."""
         import torch
         if not clips:
             raise ValueError("no clips")
@@ -107,27 +128,38 @@ class RaggedJob:
         for c in clips:
             if c.device != device or c.dtype != clips[0].dtype or (1 if c.ndim == 1 else c.shape[1]) != ch or c.ndim not in (1, 2):
                 raise ValueError("clips of one job share device, dtype and channel count; each is [frames] or [frames, channels]")
-        n_in = [int(c.shape[0]) for c in clips]
+        es = clips[0].element_size()
+        keep = [c if c.is_contiguous() else c.contiguous() for c in clips]  # (a strided clip is the one case that is copied)
+        n_in = [int(c.shape[0]) for c in keep]
         n_out = [plan.out_len(n) for n in n_in]
-        self.x = torch.cat([c.reshape(-1, ch) for c in clips]).contiguous()  # packed [total_frames, channels]
-        self.y = torch.empty((sum(n_out), ch), dtype=self.x.dtype, device=device)
-        in_off = np.concatenate([[0], np.cumsum(n_in)[:-1]]) * ch
-        out_off = np.concatenate([[0], np.cumsum(n_out)[:-1]]) * ch
+        ptrs = [c.data_ptr() for c in keep if c.shape[0] > 0]   # (an empty tensor has no storage address)
+        self.y = torch.empty((sum(n_out), ch), dtype=keep[0].dtype, device=device)
+        base = min(ptrs) if ptrs else self.y.data_ptr()
+        in_off = np.array([(c.data_ptr() - base) // es if c.shape[0] > 0 else 0 for c in keep], dtype=np.int64)
+        out_off = np.concatenate([[0], np.cumsum(n_out)[:-1]]).astype(np.int64) * ch
         self._table = np.ascontiguousarray(np.stack([in_off, n_in, out_off, n_out], axis=1), dtype=np.int64)
         self._table_dev = torch.from_numpy(self._table).to(device)
-        self.n_in, self.n_out, self._mono = n_in, n_out, [c.ndim == 1 for c in clips]
+        self.n_in, self.n_out, self._mono, self._keep = n_in, n_out, [c.ndim == 1 for c in clips], keep
         j = _n.Job()
-        j.in_, j.out, j.elem, j.kernel = self.x.data_ptr(), self.y.data_ptr(), _dev._torch_elem(self.x.dtype), kernel
+        j.in_, j.out, j.elem, j.kernel = base, self.y.data_ptr(), _dev._torch_elem(keep[0].dtype), kernel
         j.n_clips, j.n_channels = len(clips), ch
         j.in_clip_stride = j.out_clip_stride = 0
         j.in_frame_stride, j.in_chan_stride = ch, 1
         j.out_frame_stride, j.out_chan_stride = ch, 1
         j.in_abs0, j.in_frames, j.out_k0, j.out_frames = 0, max(n_in), 0, max(n_out)
         j.clip_table, j.clip_table_dev = self._table.ctypes.data, self._table_dev.data_ptr()
-        j.dither = int(self.x.dtype == torch.int16 if dither is None else bool(dither))
+        j.dither = int(keep[0].dtype == torch.int16 if dither is None else bool(dither))
         j.dither_seed = 0
         self._job, self._ref, self._plan = j, _C.byref(j), plan
-        self._stream = stream if stream is not None else torch.cuda.current_stream(device).cuda_stream
+        cur = torch.cuda.current_stream(device)
+        if isinstance(stream, torch.cuda.Stream):
+            stream.wait_stream(cur)           # y, the table and the clips themselves were produced on the current stream
+            self.y.record_stream(stream)
+            for c in keep:
+                c.record_stream(stream)
+            self._stream = stream.cuda_stream
+        else:
+            self._stream = stream if stream is not None else cur.cuda_stream
         self._any = max(n_out) > 0
 
     def launch(self):
@@ -143,31 +175,191 @@ class RaggedJob:
         return outs
 
 
+# Plans per (device, conversion), least recently used first: device tables live where they were built, and a long-lived
+# service that meets many rate pairs must not keep all of them for ever.
 _PLANS = {}
+_PLANS_MAX = 32
 
 
 def _plan_on(device_index, in_rate, out_rate, quality, bank=None):
-    """One plan per (device, conversion): device tables live where they were built.  Every device installs device
-    0's bank (the in-process form of the bank broadcast: one design, identical coefficients everywhere)."""
+    """One plan per (device, conversion).  Every device installs device 0's bank (the in-process form of the bank
+    broadcast: one design, identical coefficients everywhere).  At most `_PLANS_MAX` plans are kept (LRU);
+    `clear_plans()` drops them all."""
     key = (device_index, float(in_rate), float(out_rate), str(quality))
-    p = _PLANS.get(key)
+    p = _PLANS.pop(key, None)
     if p is None:
         p = _dev.Plan(in_rate, out_rate, quality)
         if bank is not None:
             p.set_bank(bank)
-        _PLANS[key] = p
+    _PLANS[key] = p                      # (re-inserted: most recently used last)
+    while len(_PLANS) > _PLANS_MAX:
+        _PLANS.pop(next(iter(_PLANS)))
     return p
 
 
-def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel=_n.KERNEL_AUTO):
+def clear_plans():
+    """Drop the cached plans (and with them their device tables)."""
+    _PLANS.clear()
+
+
+class _HostPipe:
+    """Host clips of one device through a pinned staging ring: three streams, SLOTS block slots.
+         stage(k)   CPU copies block k's clips into the pinned input slot      (host thread A)
+         h2d(k)     pinned slot -> packed device buffer                        (stream `sin`)
+         run(k)     ONE ragged launch over the block                           (stream `sc`, behind h2d(k))
+         d2h(k)     packed device result -> pinned output slot                 (stream `sout`, behind run(k))
+         unstage(k) CPU copies the slot into the caller's result arrays        (host thread B, behind d2h(k))
+    so that the H2D copy of block k+1, the launch of block k and the D2H copy of block k-1 are in flight together and
+    the two CPU copies run beside them.  Blocks hold whole clips, about `block_bytes` of input each."""
+    SLOTS = 3
+
+    def __init__(self, plan, device, dtype, ch, kernel, block_bytes):
+        import torch
+        self.torch, self.plan, self.device, self.kernel, self.ch = torch, plan, device, kernel, ch
+        self.tdtype = dtype
+        self.sin, self.sc, self.sout = (torch.cuda.Stream(device=device) for _ in range(3))
+        self.block_bytes = block_bytes
+        self.cap_in = self.cap_out = 0
+        self.pin_in = self.pin_out = self.dev_in = self.dev_out = None
+
+    def _ensure(self, n_in_el, n_out_el):
+        torch = self.torch
+        if n_in_el > self.cap_in:
+            self.cap_in = n_in_el
+            self.pin_in = [torch.empty(n_in_el, dtype=self.tdtype, pin_memory=True) for _ in range(self.SLOTS)]
+            self.dev_in = [torch.empty(n_in_el, dtype=self.tdtype, device=self.device) for _ in range(self.SLOTS)]
+        if n_out_el > self.cap_out:
+            self.cap_out = n_out_el
+            self.pin_out = [torch.empty(n_out_el, dtype=self.tdtype, pin_memory=True) for _ in range(self.SLOTS)]
+            self.dev_out = [torch.empty(n_out_el, dtype=self.tdtype, device=self.device) for _ in range(self.SLOTS)]
+
+    def run(self, clips, results, idx):
+        """clips: numpy arrays of this device (all the same dtype / channel count); results[idx[i]] = resampled clips[i]."""
+        import threading
+        torch, ch, plan = self.torch, self.ch, self.plan
+        es = clips[0].dtype.itemsize
+        n_in = [int(c.shape[0]) for c in clips]
+        n_out = [plan.out_len(n) for n in n_in]
+        blocks, cur, cur_b = [], [], 0
+        for i, n in enumerate(n_in):
+            if cur and cur_b + n * ch * es > self.block_bytes:
+                blocks.append(cur); cur, cur_b = [], 0
+            cur.append(i); cur_b += n * ch * es
+        if cur:
+            blocks.append(cur)
+        self._ensure(max(sum(n_in[i] for i in b) for b in blocks) * ch, max(sum(n_out[i] for i in b) for b in blocks) * ch)
+        ev_free_in = [None] * self.SLOTS    # h2d of the block that used the slot before has read the pinned input
+        ev_out = [None] * len(blocks)       # d2h(k) done
+        ev_run = [None] * len(blocks)       # run(k) done
+        free_out = [threading.Semaphore(1) for _ in range(self.SLOTS)]   # the output slot has been unstaged
+        staged = [threading.Event() for _ in blocks]
+        issued = [threading.Event() for _ in blocks]
+        err = []
+
+        def stager():
+            try:
+                for k, b in enumerate(blocks):
+                    s = k % self.SLOTS
+                    if k >= self.SLOTS:               # the pinned slot's previous block has been copied to the device
+                        issued[k - self.SLOTS].wait()
+                        if err:
+                            return
+                        ev_free_in[s].synchronize()
+                    view, pos = self.pin_in[s].numpy(), 0
+                    for i in b:
+                        n = n_in[i] * ch
+                        np.copyto(view[pos:pos + n], clips[i].reshape(-1), casting="no")
+                        pos += n
+                    staged[k].set()
+            except Exception as e:  # pragma: no cover
+                err.append(e)
+                for ev in staged:
+                    ev.set()
+
+        def unstager():
+            try:
+                for k, b in enumerate(blocks):
+                    issued[k].wait()
+                    if err:
+                        return
+                    ev_out[k].synchronize()
+                    s = k % self.SLOTS
+                    view, pos = self.pin_out[s].numpy(), 0
+                    for i in b:
+                        n = n_out[i] * ch
+                        out = np.empty((n_out[i],) if clips[i].ndim == 1 else (n_out[i], ch), dtype=clips[i].dtype)
+                        np.copyto(out.reshape(-1), view[pos:pos + n], casting="no")
+                        results[idx[i]] = out
+                        pos += n
+                    free_out[s].release()
+            except Exception as e:  # pragma: no cover
+                err.append(e)
+
+        ta, tb = threading.Thread(target=stager), threading.Thread(target=unstager)
+        ta.start(); tb.start()
+        try:
+            for k, b in enumerate(blocks):
+                s = k % self.SLOTS
+                staged[k].wait()
+                if err:
+                    break
+                tot_in, tot_out = sum(n_in[i] for i in b) * ch, sum(n_out[i] for i in b) * ch
+                with torch.cuda.stream(self.sin):
+                    if k >= self.SLOTS:
+                        self.sin.wait_event(ev_run[k - self.SLOTS])   # dev_in[s] was read by run(k - SLOTS)
+                    self.dev_in[s][:tot_in].copy_(self.pin_in[s][:tot_in], non_blocking=True)
+                    e_in = torch.cuda.Event(); e_in.record(self.sin)
+                ev_free_in[s] = e_in
+                # the block's table: clips end to end in the packed device buffers (device copy uploaded by the library)
+                ni = np.array([n_in[i] for i in b], np.int64); no = np.array([n_out[i] for i in b], np.int64)
+                table = np.ascontiguousarray(np.stack([np.concatenate([[0], np.cumsum(ni)[:-1]]) * ch, ni,
+                                                       np.concatenate([[0], np.cumsum(no)[:-1]]) * ch, no], axis=1), dtype=np.int64)
+                j = _n.Job()
+                j.in_, j.out = self.dev_in[s].data_ptr(), self.dev_out[s].data_ptr()
+                j.elem, j.kernel = _dev._torch_elem(self.tdtype), self.kernel
+                j.n_clips, j.n_channels = len(b), ch
+                j.in_frame_stride, j.in_chan_stride, j.out_frame_stride, j.out_chan_stride = ch, 1, ch, 1
+                j.in_frames, j.out_frames = int(ni.max()), int(no.max())
+                j.clip_table, j.clip_table_dev = table.ctypes.data, None
+                j.dither = int(self.tdtype == torch.int16)
+                free_out[s].acquire()                 # the result slot of block k - SLOTS has been copied out
+                self.sc.wait_event(e_in)
+                if k >= self.SLOTS:
+                    self.sc.wait_event(ev_out[k - self.SLOTS])   # ... and its device buffer read by d2h(k - SLOTS)
+                if j.out_frames > 0:
+                    _n.check(_n.lib.hipsoxr_run_device(plan.handle, _C.byref(j), self.sc.cuda_stream))
+                e_c = torch.cuda.Event(); e_c.record(self.sc)
+                ev_run[k] = e_c
+                with torch.cuda.stream(self.sout):
+                    self.sout.wait_event(e_c)
+                    self.pin_out[s][:tot_out].copy_(self.dev_out[s][:tot_out], non_blocking=True)
+                    e_o = torch.cuda.Event(); e_o.record(self.sout)
+                ev_out[k] = e_o
+                issued[k].set()
+        finally:
+            for ev in issued:
+                ev.set()
+            ta.join(); tb.join()
+        if err:
+            raise err[0]
+
+
+_PIPES = {}
+
+
+def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel=_n.KERNEL_AUTO, block_bytes=64 << 20):
     """Resample independent clips on the GPUs of this node from ONE process.
 
     clips    : sequence of arrays, each [frames] or [frames, channels] — numpy (host) or torch tensors (any
                device); lengths may differ; dtype float32 / float64 / int16 / int32, the same for all.
-    devices  : HIP device indices to use (default: all visible).  Clips are dealt in contiguous blocks
-               (`shard(len(clips), len(devices), i)`); each device runs its block as ONE ragged launch on its
-               own stream, driven by its own host thread (ctypes releases the GIL during every library call —
-               the reference's threading model, tests/gil_bench.py:22-56).
+    devices  : HIP device indices to use (default: all visible).  Clips are dealt by total frames
+               (`shard_by_frames`); each device is driven by its own host thread (ctypes releases the GIL during
+               every library call — the reference's threading model, tests/gil_bench.py:22-56).
+               Device tensors: one ragged launch per device over the clips WHERE THEY LIE (a clip on another device
+               is copied over first), on a side stream ordered behind the caller's current streams; the caller's
+               current stream on the computing device waits for the results.
+               Host arrays: a pinned staging ring per device, blocks of about `block_bytes` of input, with the H2D
+               copy of block k+1, the launch of block k and the D2H copy of block k-1 in flight together.
     kernel   : engine selector for the device jobs (AUTO: the frequency-domain engine for large float jobs,
                1e-6-class; KERNEL_EXACT: the canonical-order engine, bit-identical to `soxr_amd.resample`).
     Returns a list of arrays of the same kind (numpy in -> numpy out; tensor in -> tensor on the device that
@@ -185,27 +377,48 @@ def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel
         raise ValueError("no devices")
     bank0 = _plan_on(devices[0], in_rate, out_rate, quality).bank() if len(devices) > 1 else None
     results = [None] * len(clips)
+    parts = shard_by_frames([int(c.shape[0]) for c in clips], len(devices))
 
     def work(i):
-        lo, hi = shard(len(clips), len(devices), i)
-        if lo == hi:
+        mine = parts[i]
+        if not mine:
             return
         d = devices[i]
+        dev_t = torch.device("cuda", d)
         with torch.cuda.device(d):
             plan = _plan_on(d, in_rate, out_rate, quality, bank0 if i else None)
-            stream = torch.cuda.Stream(device=d)
-            with torch.cuda.stream(stream):
-                mine, was_numpy = [], []
-                for c in clips[lo:hi]:
-                    was_numpy.append(isinstance(c, np.ndarray))
-                    t = torch.from_numpy(np.ascontiguousarray(c)) if isinstance(c, np.ndarray) else c
-                    mine.append(t.to(torch.device("cuda", d), non_blocking=True))
-                job = RaggedJob(plan, mine, kernel=kernel, stream=stream.cuda_stream)
-                job.launch()
-                outs = job.outputs()
-                outs = [o.cpu().numpy() if w else o for o, w in zip(outs, was_numpy)]
-            stream.synchronize()
-        results[lo:hi] = outs
+            host = [k for k in mine if isinstance(clips[k], np.ndarray)]
+            dev = [k for k in mine if not isinstance(clips[k], np.ndarray)]
+            if host:
+                c0 = clips[host[0]]
+                ch = 1 if c0.ndim == 1 else c0.shape[1]
+                tdt = torch.from_numpy(np.empty(0, c0.dtype)).dtype
+                key = (d, i, tdt, ch, int(kernel), int(block_bytes))   # (one pipe per device SLOT: the same device listed twice runs two)
+                pipe = _PIPES.get(key)
+                if pipe is None:
+                    pipe = _PIPES[key] = _HostPipe(plan, dev_t, tdt, ch, kernel, block_bytes)
+                pipe.plan = plan
+                pipe.run([np.ascontiguousarray(clips[k]) for k in host], results, host)
+            if dev:
+                cur = torch.cuda.current_stream(dev_t)
+                side = torch.cuda.Stream(device=dev_t)
+                tens = []
+                for k in dev:
+                    c = clips[k]
+                    if c.is_cuda:   # whatever produced the clip on its own device's current stream comes first
+                        side.wait_stream(torch.cuda.current_stream(c.device))
+                    with torch.cuda.stream(side):
+                        tens.append(c if c.device == dev_t else c.to(dev_t, non_blocking=True))
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    job = RaggedJob(plan, tens, kernel=kernel, stream=side.cuda_stream)
+                    job.launch()
+                    outs = job.outputs()
+                for t in tens + [job.y, job._table_dev]:
+                    t.record_stream(side)
+                cur.wait_stream(side)   # the caller's stream sees finished results (no host synchronisation needed)
+                for k, o in zip(dev, outs):
+                    results[k] = o
 
     if len(devices) == 1:
         work(0)

@@ -68,4 +68,4 @@ def test_product_library_reads_four_environment_names():
     assert env_like <= allowed, sorted(env_like - allowed)
     dbg = os.path.join(pkg, "_variants", "dbg", "libhipsoxr.so")
     assert os.path.exists(dbg)
-    assert {"HIPSOXR_FFT_X2", "HIPSOXR_DEBUG_SLAB64", "HIPSOXR_NO_PLANES"} <= names(dbg)
+    assert {"HIPSOXR_FFT_NO_PAIR", "HIPSOXR_DEBUG_SLAB64", "HIPSOXR_NO_PLANES"} <= names(dbg)

@@ -85,6 +85,16 @@ def test_shard_partition_properties():
     assert sdist.shard(1024, 8, 3) == (384, 512)
     with pytest.raises(ValueError):
         sdist.shard(8, 2, 2)
+    # a ragged corpus is dealt by total frames: every clip exactly once, loads within one longest clip of each other
+    rng = np.random.default_rng(4)
+    for world in (1, 2, 3, 8):
+        lengths = [int(v) for v in rng.integers(5, 16, size=101) * 48000]
+        parts = sdist.shard_by_frames(lengths, world)
+        assert len(parts) == world and sorted(i for p in parts for i in p) == list(range(len(lengths)))
+        loads = [sum(lengths[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(lengths)
+        assert parts == sdist.shard_by_frames(lengths, world)          # deterministic
+    assert sdist.shard_by_frames([], 3) == [[], [], []]
     sys.path.insert(0, ROOT)
     import bench                                 # bench.py uses the product's rule, not a copy of it
     assert bench.shard(1024, 8, 3) == sdist.shard(1024, 8, 3)

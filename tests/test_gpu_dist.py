@@ -73,9 +73,16 @@ def test_ragged_job_rejects_bad_tables():
     with pytest.raises(RuntimeError):
         job.launch()
     job._table[1, 3] -= 1
-    job._job.clip_table_dev = None                              # host table without its device copy
+    job._table[0, 0] = -4                                       # an offset in front of the job's base
     with pytest.raises(RuntimeError):
         job.launch()
+    job._table[0, 0] = 0
+    ref = [o.clone() for o in (job.launch(), job.outputs())[1]]
+    job._job.clip_table_dev = None                              # host table only: the library uploads it in stream order
+    job.y.zero_()
+    job.launch()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(ref, job.outputs()))
     with pytest.raises(ValueError):
         sdist.RaggedJob(plan, [torch.zeros(10, device="cuda"), torch.zeros((10, 2), device="cuda")])
 
@@ -93,6 +100,48 @@ def test_resample_batch_threads_over_devices_and_order():
     for a, b, c in zip(one, two, three):
         assert np.array_equal(a, b) and torch.is_tensor(c) and c.is_cuda and np.array_equal(a, c.cpu().numpy())
     assert sdist.resample_batch([], 48000, 44100) == []
+
+
+def test_device_clips_are_resampled_in_place_and_in_stream_order():
+    """Device tensors are not packed into a second buffer (the job table addresses them where they lie), and work queued
+    on the caller's current stream just before the call — the producer of the clips — is seen by the side stream that
+    runs the job; the caller's stream in turn sees finished results without a host synchronisation."""
+    import torch
+    from soxr_amd import dist as sdist, device as dev
+    plan = dev.Plan(48000, 44100, "VHQ")
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    base = [torch.randn(300000 + 1111 * i, device="cuda", generator=g) * 0.1 for i in range(5)]
+    want = [dev.resample_tensor(plan, b * 2.0 + 0.25, kernel=dev.KERNEL_EXACT) for b in base]
+    torch.cuda.synchronize()
+    for trial in range(3):
+        big = torch.randn(1 << 26, device="cuda", generator=g)
+        for _ in range(4):
+            big = big * 1.0001 + 1e-3          # a few ms of work in front of the producers on the current stream
+        clips = [b * 2.0 + 0.25 for b in base]  # produced on the current stream, not yet finished
+        outs = sdist.resample_batch(clips, 48000, 44100, "VHQ", devices=[0], kernel=dev.KERNEL_EXACT)
+        acc = [o + 0.0 for o in outs]           # consumed on the current stream, no synchronize in between
+        del clips
+        torch.cuda.synchronize()
+        for a, w in zip(acc, want):
+            assert torch.equal(a, w), trial
+    job = sdist.RaggedJob(plan, base)
+    assert job._job.in_ == min(b.data_ptr() for b in base)      # no packed copy of the input
+
+
+def test_host_corpus_goes_through_the_staging_pipeline(oracle):
+    """numpy clips of unequal length, several blocks of the pinned staging ring (small block size forced), float32 and
+    int16: every clip equals the one-shot host surface bit for bit (canonical-order engine)."""
+    import soxr_amd as soxr
+    from soxr_amd import dist as sdist, device as dev
+    rng = np.random.default_rng(77)
+    clips = [(rng.standard_normal(30000 + 4001 * (i % 7)) * 0.25).astype(np.float32) for i in range(23)]
+    outs = sdist.resample_batch(clips, 48000, 44100, "VHQ", devices=[0, 0], kernel=dev.KERNEL_EXACT, block_bytes=400000)
+    for c, o in zip(clips, outs):
+        assert isinstance(o, np.ndarray) and np.array_equal(o, soxr.resample(c, 48000, 44100, quality="VHQ"))
+    ci = [(rng.standard_normal((9000 + 501 * i, 2)) * 5000).astype(np.int16) for i in range(9)]
+    oi = sdist.resample_batch(ci, 44100, 16000, "HQ", devices=[0], kernel=dev.KERNEL_EXACT, block_bytes=100000)
+    for c, o in zip(ci, oi):
+        assert np.array_equal(o, soxr.resample(c, 44100, 16000, quality="HQ"))
 
 
 def test_config3_whole_batch_on_one_gpu(oracle):

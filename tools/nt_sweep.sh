@@ -1,5 +1,5 @@
 #!/bin/bash
-# thread-count sweep of the 48k -> 44.1k frequency-domain kernels (variant build ntsweep: -DFFT_NT_SWEEP -DHIPSOXR_DEBUG_SWITCHES)
+# thread-count sweep of the 48k -> 44.1k frequency-domain kernels (variant build ntsweep: -DFFT_NT_SWEEP -DFFT_EXPERIMENT_X2 -DHIPSOXR_DEBUG_SWITCHES)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 S="HIPSOXR_FFT_SMALL_ONLY=1 HIPSOXR_FFT_NO_TINY=1"
 for rep in 1 2; do

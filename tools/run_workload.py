@@ -27,8 +27,20 @@ elif what == "i32":
     x = (torch.randn(2880000, device="cuda", dtype=torch.float64, generator=g) * 0.25 * 2 ** 30).to(torch.int32)
 else:
     raise SystemExit("unknown workload " + what)
+if os.environ.get("ZERO_INPUT"):  # DVFS probe: the same launch on zero-filled input (less switching activity: higher clock if power-bound)
+    x = torch.zeros_like(x)
 y = dev.resample_tensor(plan, x, kernel=kernel)
 job = dev.PreparedJob(plan, x, y, kernel=kernel)
+ROT = int(os.environ.get("ROTATE", "0"))   # ROTATE=n: cycle through n distinct input / output buffers (nothing of a launch's input is cache-resident from the launch before)
+if ROT > 1:
+    xs = [x] + [torch.randn(x.shape, device="cuda", dtype=torch.float32).to(x.dtype) * 0.25 for _ in range(ROT - 1)]
+    ys = [y] + [torch.empty_like(y) for _ in range(ROT - 1)]
+    jobs = [dev.PreparedJob(plan, a, b, kernel=kernel) for a, b in zip(xs, ys)]
+    class _R:
+        i = 0
+        def launch(self):
+            jobs[self.i % ROT].launch(); self.i += 1
+    job = _R()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(3):

@@ -3,7 +3,7 @@
 tools/x2_check.py"""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DBG = os.path.join(ROOT, "python-soxr_amd", "_variants", "dbg", "libhipsoxr.so")
+DBG = os.path.join(ROOT, "python-soxr_amd", "_variants", "ntsweep", "libhipsoxr.so")  # HIPSOXR_VARIANT=ntsweep HIPSOXR_EXTRA_FLAGS="-DFFT_NT_SWEEP -DFFT_EXPERIMENT_X2 -DHIPSOXR_DEBUG_SWITCHES" bash python-soxr_amd/build.sh
 CHILD = r'''
 import sys, os, json, numpy as np, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "python-soxr_amd"))
