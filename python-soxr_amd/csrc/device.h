@@ -95,6 +95,7 @@ struct Switches {
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids
     bool no_tile_split = false;   // HIPSOXR_NO_TILE_SPLIT    k_tile / k_tile_mfma: never spread a slab's row tiles over several workgroups
     bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp
+    bool no_two_stage = false;    // HIPSOXR_NO_TWO_STAGE     float device jobs of interpolated-phase plans stay on the exact engine
     // timing experiments on the tile kernels (results may be wrong with dbg_flags != 0)
     int dbg_flags = 0;            // HIPSOXR_DEBUG_FLAGS      1 no staging, 2 no LDS reads, 4 no coefficient loads, 8 no stores
     int dbg_nrt = 0, dbg_nw = 0;  // HIPSOXR_DEBUG_NRT / _NW  tiles / waves per workgroup
@@ -120,5 +121,7 @@ const Switches &switches();
 bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &job);
 const char *launch_fft(Plan *p, const hipsoxr_job_t &job, void *stream, bool *handled);
 void fft_release(const Plan *p);
+// two-stage form for interpolated-phase plans (twostage.hip): FFT stage at 1:2 / 2:1 + a short polyphase stage in LDS
+const char *launch_two_stage(Plan *p, const hipsoxr_job_t &job, void *stream, bool *handled);
 
 } // namespace hipsoxr

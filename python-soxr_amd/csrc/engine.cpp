@@ -36,7 +36,7 @@ struct hipsoxr_plan {
 };
 
 namespace hipsoxr {
-Plan::~Plan() { device_bank_release(this); fft_release(this); }
+Plan::~Plan() { twostage_release(this); device_bank_release(this); fft_release(this); }
 } // namespace hipsoxr
 
 // Variable-rate state (SOXR_VR streams; reference: src/soxr_ext.cpp:74, :200-204).  Time is kept in
@@ -383,6 +383,7 @@ hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *h, const double *src, size
     if (h->cached) return "this plan is shared through the plan cache (it belongs to a stream); create one with hipsoxr_plan_create";
     device_bank_release(&h->p);
     fft_release(&h->p);
+    twostage_release(&h->p);
     std::memcpy(h->p.bank.data(), src, n * sizeof(double));
     return nullptr;
 }

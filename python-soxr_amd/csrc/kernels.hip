@@ -67,7 +67,7 @@ const Switches &switches()
         w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX");
         w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT");
-        w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE");
+        w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE"); w.no_two_stage = on("HIPSOXR_NO_TWO_STAGE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
         w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD");
@@ -2796,6 +2796,15 @@ const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPo
     // libsoxr's VHQ recipe computes in; float64 jobs run it anyway).
     const bool want_fft = j.kernel == HIPSOXR_KERNEL_FFT || j.kernel == HIPSOXR_KERNEL_FFT_F64;
     if (want_fft && (vr || res)) return "FFT engine: whole-signal device jobs only";
+    // Ratios without an exact bank (interpolated-phase plans): the two-stage form — FFT engine at 1:2 / 2:1 plus a short
+    // polyphase stage — for whole-signal float jobs (1e-6 class, like the FFT engine itself; twostage.hip)
+    if (!vr && !res && p->phases && (want_fft || (j.kernel == HIPSOXR_KERNEL_AUTO && !switches().no_fft)) &&
+        (j.elem == HIPSOXR_F32 || j.elem == HIPSOXR_F64) && !switches().no_two_stage) {
+        bool handled = false;
+        if (const char *e = launch_two_stage(p, j, stream, &handled)) return e;
+        if (handled) return nullptr;
+        if (want_fft) return "FFT engine unavailable for this plan (the two-stage form serves HQ / VHQ ratios down to 4:1, whole signals of >= ~5000 frames)";
+    }
     if (!vr && !res && (want_fft || j.kernel == HIPSOXR_KERNEL_AUTO)) {
         const bool no_fft = switches().no_fft;
         const bool eligible = fft_job_eligible(*p, j);

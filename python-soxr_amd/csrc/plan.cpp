@@ -92,7 +92,7 @@ const char *reduce_ratio(double in_rate, double out_rate, int64_t *L, int64_t *M
     return nullptr;
 }
 
-static double bessel_i0(double x)
+double bessel_i0(double x)
 {
     double sum = 1., term = 1., q = x * x * .25;
     for (int k = 1; k < 500; ++k) {
@@ -160,6 +160,7 @@ static void design_interp(Plan *p)
     const double s01 = node[0] + node[1], s012 = node[0] + node[1] + node[2], p01 = node[0] * node[1],
                  e2 = node[0] * node[1] + node[0] * node[2] + node[1] * node[2],
                  p012 = node[0] * node[1] * node[2];
+    p->proto_scale = scale;
     p->bank.assign((size_t)P * T * 4, 0.);
     std::vector<double> v((size_t)4 * T);
     for (int32_t i = 0; i < P; ++i) {
@@ -186,6 +187,17 @@ static void design_interp(Plan *p)
             a[0] = v0 - d01 * node[0] + d012 * p01 - d3 * p012;
         }
     }
+}
+
+double plan_proto(const Plan &p, double tau)
+{
+    Proto h;
+    h.W = .5 * (double)p.T;
+    const double fn = .5 * (p.in_rate < p.out_rate ? p.in_rate : p.out_rate);
+    h.fc = .5 * (p.q.passband_end + p.q.stopband_begin) * fn / p.in_rate;
+    h.beta = p.beta;
+    h.inv_i0 = 1. / bessel_i0(p.beta);
+    return h(tau) * p.proto_scale;
 }
 
 const char *plan_design(double in_rate, double out_rate, unsigned long recipe, Plan *p, bool force_interp)

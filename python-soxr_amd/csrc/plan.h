@@ -43,13 +43,20 @@ struct Plan {
     // the cubic coefficient table [P][T][4] (see plan.cpp, "interpolated-phase plans").
     int32_t phases = 0;
     std::vector<double> bank; // float64
+    double proto_scale = 0; // interpolated-phase plans: DC normalisation of the continuous-time prototype (plan_proto)
     // device side (lazily built on first use, per precision: 0 = f32, 1 = f64)
     DeviceBank dev[2];
     std::mutex mu;
     int device = -1;
+    struct TwoStage *two = nullptr; // arbitrary ratios, 1e-6-class float device jobs: FFT stage + short polyphase stage (twostage.hip)
 
     ~Plan();
 };
+// The prototype of an interpolated-phase plan as a function of continuous time tau (in INPUT samples), unit DC gain:
+// output k at input position t weights input sample n with plan_proto(p, t - n).  (Windowed-sinc recipes only.)
+double plan_proto(const Plan &p, double tau);
+double bessel_i0(double x);
+void twostage_release(Plan *p);
 
 // Returns nullptr on success, else a static error string.
 const char *quality_spec(unsigned long recipe, QualitySpec *q);

@@ -1,0 +1,380 @@
+// twostage.hip — arbitrary rate ratios at reduced cost: the frequency-domain engine + a short polyphase stage.
+//
+// Ratios outside the exact-bank range (random integer or float rates: reference tests/test_random.py:21-25) get an
+// interpolated-phase plan, and the canonical-order engine evaluates its 296-tap (VHQ) direct form with a cubic per tap:
+// 48000 -> 44101 stereo 60 s took 402 us against 70 us for its rational neighbour.  libsoxr itself serves such ratios at
+// near-constant cost with an FFT stage at a fixed ratio plus a short interpolated polyphase stage (SURVEY.md §0.3 / §A.4,
+// upstream-unverified).  The MI355X form, for whole-signal float32 / float64 device jobs under HIPSOXR_KERNEL_AUTO /
+// _FFT (1e-6 class; the host surface, streams and integer I/O keep the bit-exact k_interp / k_interp_tile):
+//
+//   up   (out > in):  x --[FFT engine 1:2, the plan's OWN prototype sampled on the half-sample grid]--> u at 2 f_in
+//                       --[k_poly: T2-tap interpolated polyphase, transparent on [0, f_in/2], stop from 1.5 f_in]--> y
+//   down (out < in):  x --[k_poly: transparent on [0, f_out/2], stop from 1.5 f_out]--> v at 2 f_out
+//                       --[FFT engine 2:1, the plan's own prototype re-expressed at 2 f_out]--> y
+//
+// The sharp filter of the composite IS the plan's prototype h (plan_proto), so the result equals the single-stage
+// filter's to the polyphase stage's ripple (designed 6 dB below the recipe) and the FFT engine's own floor — on any input,
+// not only band-limited ones: <= 1e-6 of the oracle's float64 direct form (tests/test_gpu_random_rates.py).
+// The polyphase stage's cubic table ([P2][T2] records of 16 bytes: 12-50 KB) lives in LDS, which ends the 423 MB stream of
+// coefficient records through the scalar cache that bounds k_interp_tile.
+// Edges: an intermediate signal exists only on [0, its length), so the few outputs whose second-stage support reaches
+// past either end (E per end: tens to ~150) come from the exact engine instead (two small launches).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "device.h"
+
+namespace hipsoxr {
+
+#define HIP_TRY(expr)                                       \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) return hipGetErrorString(e_); \
+    } while (0)
+
+struct TwoStage {
+    bool ok = false, up = false;
+    Plan fft;                 // the FFT stage's plan: L/M = 2/1 (up) or 1/2 (down), bank from the owner's prototype
+    int32_t T2 = 0, P2 = 0, row = 0; // polyphase stage: taps, table intervals, records per table row (T2 + 1: bank spreading)
+    int64_t Ls = 1, Ms = 1;   // polyphase stage: output k sits at k * Ms / Ls of ITS input samples
+    int64_t edge = 0;         // outputs per end taken from the exact engine
+    void *tab_f = nullptr, *tab_d = nullptr; // device: [P2][row] float4 / double4 records (a0..a3 of the cubic in x in [0, 1))
+};
+
+void twostage_release(Plan *p)
+{
+    if (!p->two) return;
+    if (p->two->tab_f) (void)hipFree(p->two->tab_f);
+    if (p->two->tab_d) (void)hipFree(p->two->tab_d);
+    delete p->two; // (the FFT stage's plan releases its own device tables: Plan::~Plan)
+    p->two = nullptr;
+}
+
+static int64_t gcd64(int64_t a, int64_t b)
+{
+    while (b) { const int64_t t = a % b; a = b; b = t; }
+    return a;
+}
+
+// Kaiser-windowed sinc of the polyphase stage in units of ITS input samples: cut-off fc (cycles per sample), half width W
+struct PolyProto {
+    double fc, W, beta, inv_i0, scale;
+    double operator()(double tau) const
+    {
+        const double u = tau / W;
+        double w = 1. - u * u;
+        if (w <= 0.) return 0.;
+        const double s = tau == 0. ? 2. * fc : std::sin(2. * M_PI * fc * tau) / (M_PI * tau);
+        return s * bessel_i0(beta * std::sqrt(w)) * inv_i0 * scale;
+    }
+};
+
+static const char *twostage_build(Plan *p)
+{
+    TwoStage *ts = new TwoStage;
+    p->two = ts;
+    if (!p->phases || p->q.bits < 20. || p->proto_scale == 0.) return nullptr; // HQ / VHQ windowed-sinc interpolated plans only
+    const double fi = p->in_rate, fo = p->out_rate;
+    ts->up = fo > fi;
+    const double rho = ts->up ? 1. : fi / (2. * fo); // polyphase stage: input samples per output sample is rho (down) / Ms/Ls (up)
+    if (!ts->up && fi / fo > 4.) return nullptr;      // (long polyphase filters: the table would leave LDS)
+    // ---- the FFT stage's plan: the owner's prototype H(tau) (tau in the OWNER's input samples) on the 2x grid ----
+    Plan &f = ts->fft;
+    f.recipe = p->recipe; f.q = p->q; f.att_db = p->att_db; f.beta = p->beta; f.phases = 0;
+    if (ts->up) { // u[m] = sum_n x[n] H(m/2 - n): bank[ph][j] = H(ph/2 + T/2 - 1 - j)
+        f.in_rate = fi; f.out_rate = 2. * fi; f.L = 2; f.M = 1; f.T = p->T;
+        f.bank.assign((size_t)2 * f.T, 0.);
+        for (int ph = 0; ph < 2; ++ph)
+            for (int j = 0; j < f.T; ++j) f.bank[(size_t)ph * f.T + j] = plan_proto(*p, .5 * ph + (double)(f.T / 2 - 1 - j));
+    } else {      // y[k] = sum_m v[m] g(2k - m), g(s) = H(s rho) rho (v at 2 f_out: rho owner-input samples per v sample)
+        f.in_rate = 2. * fo; f.out_rate = fo; f.L = 1; f.M = 2;
+        const int64_t tb = (int64_t)std::ceil((double)p->T / rho) + 2;
+        f.T = (int32_t)((tb + 7) / 8 * 8);
+        f.bank.assign((size_t)f.T, 0.);
+        for (int j = 0; j < f.T; ++j) f.bank[j] = plan_proto(*p, (double)(f.T / 2 - 1 - j) * rho) * rho;
+    }
+    // ---- the polyphase stage: transparent over the band the FFT stage passes, stop band where its images begin ----
+    // in cycles per sample of ITS input: up: input at 2 f_in: pass 0.25 (= f_in/2), stop 0.75; down: input at f_in: pass
+    // f_out/2, stop 1.5 f_out
+    const double fpass = ts->up ? .25 : .5 * fo / fi, fstop = ts->up ? .75 : 1.5 * fo / fi;
+    const double A = p->att_db + 6.;
+    const double n_taps = (A - 7.95) / (2.285 * 2. * M_PI * (fstop - fpass)) + 1.;
+    ts->T2 = 0;
+    for (int t : {8, 12, 16, 20, 24, 28, 32, 40, 48, 56}) // (HIPSOXR_POLY_TAPS: the kernel's instances)
+        if (!ts->T2 && t >= (int)std::ceil(n_taps)) ts->T2 = t;
+    if (!ts->T2) return nullptr;
+    ts->P2 = 128; // (the float32 table could do with 64 intervals — 1.5e-8 — at half the LDS: not needed so far)
+    ts->row = ts->T2 + 1;
+    if ((size_t)ts->P2 * ts->row * 16 > 100 * 1024) return nullptr;
+    // output k of the polyphase stage at k * Ms / Ls input samples: up: from 2 f_in to f_out: 2 M / L; down: from f_in to
+    // 2 f_out: M / (2 L)
+    {
+        int64_t a = ts->up ? 2 * p->M : p->M, b = ts->up ? p->L : 2 * p->L;
+        const int64_t g = gcd64(a, b);
+        ts->Ms = a / g; ts->Ls = b / g;
+        if (ts->Ms > (1LL << 31) || ts->Ls > (1LL << 31)) return nullptr;
+    }
+    PolyProto h;
+    h.fc = .5 * (fpass + fstop); h.W = .5 * ts->T2; h.beta = .1102 * (A - 8.7); h.inv_i0 = 1. / bessel_i0(h.beta); h.scale = 1.;
+    {
+        double sum = 0.;
+        for (int64_t m = -32 * ts->T2; m < 32 * ts->T2; ++m) sum += h((double)m / 64.);
+        h.scale = 64. / sum;
+    }
+    // cubic per (interval, tap) through the four Chebyshev nodes of the interval, monomials in x in [0, 1) (plan.cpp)
+    double node[4];
+    for (int c = 0; c < 4; ++c) node[c] = .5 - .5 * std::cos((double)(2 * c + 1) * M_PI / 8.);
+    std::vector<double> tab((size_t)ts->P2 * ts->row * 4, 0.);
+    for (int i = 0; i < ts->P2; ++i)
+        for (int j = 0; j < ts->T2; ++j) {
+            double v[4];
+            for (int c = 0; c < 4; ++c) v[c] = h(((double)i + node[c]) / ts->P2 + (double)(ts->T2 / 2 - 1 - j));
+            const double d01 = (v[1] - v[0]) / (node[1] - node[0]), d12 = (v[2] - v[1]) / (node[2] - node[1]), d23 = (v[3] - v[2]) / (node[3] - node[2]);
+            const double d012 = (d12 - d01) / (node[2] - node[0]), d123 = (d23 - d12) / (node[3] - node[1]);
+            const double d3 = (d123 - d012) / (node[3] - node[0]);
+            double *a = &tab[((size_t)i * ts->row + j) * 4];
+            a[3] = d3;
+            a[2] = d012 - d3 * (node[0] + node[1] + node[2]);
+            a[1] = d01 - d012 * (node[0] + node[1]) + d3 * (node[0] * node[1] + node[0] * node[2] + node[1] * node[2]);
+            a[0] = v[0] - d01 * node[0] + d012 * node[0] * node[1] - d3 * node[0] * node[1] * node[2];
+        }
+    std::vector<float> tabf(tab.size());
+    for (size_t i = 0; i < tab.size(); ++i) tabf[i] = (float)tab[i];
+    HIP_TRY(hipMalloc(&ts->tab_f, tabf.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(ts->tab_f, tabf.data(), tabf.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&ts->tab_d, tab.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(ts->tab_d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    // edges (outputs of the JOB per end): up: second-stage support T2/2 u-samples = T2/4 input samples; down: the FFT
+    // stage's support f.T/2 v-samples = f.T/4 outputs
+    ts->edge = ts->up ? (int64_t)std::ceil((ts->T2 / 4. + 2.) * (double)p->L / (double)p->M) + 2 : f.T / 4 + 4;
+    ts->ok = true;
+    return nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_poly: outputs [k_lo, k_lo + n_out) of one column per workgroup tile; output k at src position k * Ms / Ls;
+//   y[k] = sum_j c_j(frac) src[floor(pos) - (T/2 - 1) + j],   c_j(f) = cubic of table[floor(f P)][j] at x = f P - floor(f P)
+// The table and the tile's source span live in LDS; a thread owns R consecutive outputs (position by one 64-bit division,
+// then increments).
+// ---------------------------------------------------------------------------------------------
+struct PolyArgs {
+    const void *src; void *dst; const void *tab;
+    int32_t T, P, row, R, span_max;
+    int64_t Ls, Ms, Mq, Mr; // Ms = Mq * Ls + Mr
+    int64_t n_src, k_lo, n_out;
+    int64_t scs, sfs, schs, dcs, dfs, dchs;
+    uint32_t n_channels;
+};
+
+// tap counts the polyphase kernel is instantiated for (twostage_build rounds its design up to the next one)
+#define HIPSOXR_POLY_TAPS(X) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56)
+template <typename Real> struct Rec4;
+template <> struct Rec4<float> { typedef float4 type; };
+template <> struct Rec4<double> { typedef double4 type; };
+
+template <typename Real, int TT> // TT = taps (compile time: the tap loop unrolls and every LDS read of an output is in flight at once)
+__global__ void __launch_bounds__(256) k_poly(PolyArgs a)
+{
+    typedef typename Rec4<Real>::type R4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    R4 *tab = reinterpret_cast<R4 *>(smem);
+    Real *xs = reinterpret_cast<Real *>(smem + (size_t)a.P * a.row * sizeof(R4));
+    const uint32_t col = blockIdx.y, ch = col % a.n_channels, clip = col / a.n_channels;
+    const Real *src = (const Real *)a.src + (int64_t)clip * a.scs + (int64_t)ch * a.schs;
+    Real *dst = (Real *)a.dst + (int64_t)clip * a.dcs + (int64_t)ch * a.dchs;
+    const int tid = (int)threadIdx.x;
+    {
+        const R4 *g = (const R4 *)a.tab;
+        for (int i = tid; i < a.P * a.row; i += 256) tab[i] = g[i];
+    }
+    const int64_t per_tile = 256LL * a.R, n_tiles = (a.n_out + per_tile - 1) / per_tile;
+    constexpr int H = TT / 2;
+    constexpr int CH = TT % 16 == 0 ? 16 : TT % 12 == 0 ? 12 : TT % 8 == 0 ? 8 : 4; // taps whose LDS reads are in flight together
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t kA = a.k_lo + tile * per_tile;
+        const int64_t kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
+        // (k < 2^31 and Ms <= 2^31: the products fit 64 bits — launch_two_stage admits no larger job)
+        const int64_t nA = (int64_t)(((uint64_t)kA * (uint64_t)a.Ms) / (uint64_t)a.Ls) - (H - 1);
+        const int64_t nB = (int64_t)(((uint64_t)kB * (uint64_t)a.Ms) / (uint64_t)a.Ls) + H;
+        const int span = (int)(nB - nA + 1);
+        __syncthreads(); // (the tile before has been read; first trip: the table is complete behind the barrier below)
+        for (int i = tid; i < span; i += 256) {
+            const int64_t n = nA + i;
+            xs[i] = (n >= 0 && n < a.n_src) ? src[n * a.sfs] : (Real)0;
+        }
+        __syncthreads();
+        const int64_t k1 = kA + (int64_t)tid * a.R;
+        if (k1 <= kB) {
+            const uint64_t q = (uint64_t)k1 * (uint64_t)a.Ms;
+            int64_t n = (int64_t)(q / (uint64_t)a.Ls);
+            int64_t rem = (int64_t)(q % (uint64_t)a.Ls);
+            const double invL = 1. / (double)a.Ls;
+            for (int r = 0; r < a.R && k1 + r <= kB; ++r) {
+                const double fP = (double)rem * invL * (double)a.P;
+                int i = (int)fP;
+                if (i >= a.P) i = a.P - 1;
+                const Real x = (Real)(fP - (double)i);
+                const R4 *row = tab + (size_t)i * a.row;
+                const Real *w = xs + (n - nA - (H - 1));
+                Real acc0 = (Real)0, acc1 = (Real)0;
+#pragma unroll
+                for (int j0 = 0; j0 < TT; j0 += CH) {
+                    R4 c[CH];
+                    Real u[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) { c[j] = row[j0 + j]; u[j] = w[j0 + j]; }
+#pragma unroll
+                    for (int j = 0; j < CH; j += 2) {
+                        acc0 += (((c[j].w * x + c[j].z) * x + c[j].y) * x + c[j].x) * u[j];
+                        acc1 += (((c[j + 1].w * x + c[j + 1].z) * x + c[j + 1].y) * x + c[j + 1].x) * u[j + 1];
+                    }
+                }
+                dst[(k1 + r - a.k_lo) * a.dfs] = acc0 + acc1;
+                n += a.Mq; rem += a.Mr;
+                if (rem >= a.Ls) { rem -= a.Ls; ++n; }
+            }
+        }
+    }
+}
+
+template <typename Real>
+static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, int64_t n_src, int64_t k_lo, int64_t n_out, uint32_t n_clips, uint32_t n_channels,
+                               const int64_t sstr[3], const int64_t dstr[3], hipStream_t st)
+{
+    if (n_out <= 0) return nullptr;
+    PolyArgs a;
+    a.src = src; a.dst = dst; a.tab = sizeof(Real) == 4 ? ts.tab_f : ts.tab_d;
+    a.T = ts.T2; a.P = ts.P2; a.row = ts.row;
+    a.Ls = ts.Ls; a.Ms = ts.Ms; a.Mq = ts.Ms / ts.Ls; a.Mr = ts.Ms % ts.Ls;
+    a.n_src = n_src; a.k_lo = k_lo; a.n_out = n_out;
+    a.scs = sstr[0]; a.sfs = sstr[1]; a.schs = sstr[2]; a.dcs = dstr[0]; a.dfs = dstr[1]; a.dchs = dstr[2];
+    a.n_channels = n_channels;
+    // outputs per thread: as many as keep the tile's source span within the LDS left beside the table (<= 8)
+    const size_t tab_bytes = (size_t)ts.P2 * ts.row * 4 * sizeof(Real);
+    const size_t lds_cap = (sizeof(Real) == 4 ? 64 : 96) * 1024; // two (float) / one (double) workgroups per CU
+    const double ratio = (double)ts.Ms / (double)ts.Ls;
+    int Rmax = 12;
+    while (Rmax > 1 && tab_bytes + (size_t)(256. * Rmax * ratio + ts.T2 + 4) * sizeof(Real) > lds_cap) --Rmax;
+    // Lanes of a wave own outputs R apart: their source windows start R Ms / Ls samples apart and their table intervals form
+    // an arithmetic progression of step frac(R Ms / Ls) P.  A 4-byte LDS read serves 32 lanes per cycle when they fall on
+    // 32 different banks (word address mod 32), a 16-byte read 16 lanes when their rows fall on 16 different bank quads
+    // ((row stride * interval) mod 16).  R = 8 at 48000 -> 44101 puts the windows 4.35 words apart — four lanes per bank.
+    // Pick the R whose two progressions collide least (simulated for a few starting phases).
+    int R = Rmax;
+    {
+        double best = 1e30;
+        const double step = (double)ts.Ms / (double)ts.Ls;
+        for (int r = std::max(2, Rmax / 3); r <= Rmax; ++r) {
+            double cost = 0.;
+            for (int ph = 0; ph < 16; ++ph) {
+                for (int g0 = 0; g0 < 64; g0 += 16) { // table records: groups of 16 lanes, 16 bank quads
+                    int cnt[16] = {0}, mx = 0;
+                    for (int l = g0; l < g0 + 16; ++l) {
+                        const double f = ph / 16. + (double)l * r * step;
+                        const int i = (int)((f - std::floor(f)) * ts.P2) % ts.P2;
+                        mx = std::max(mx, ++cnt[(ts.row * i) & 15]);
+                    }
+                    cost += mx; // one cycle per group and distinct quad
+                }
+            }
+            cost *= 1. + .02 * (Rmax - r); // (a shorter run per thread: more position divisions and tiles per output)
+            if (cost < best) { best = cost; R = r; }
+        }
+    }
+    a.R = R;
+    a.span_max = (int)(256. * R * ratio + ts.T2 + 4);
+    const size_t lds = tab_bytes + (size_t)a.span_max * sizeof(Real);
+    if (lds > 160 * 1024) return "two-stage: polyphase tile does not fit LDS";
+    const uint64_t cols = (uint64_t)n_clips * n_channels;
+    if (cols > 65535) return "two-stage: too many columns";
+    const int64_t n_tiles = (n_out + 256LL * R - 1) / (256LL * R);
+    // workgroups walk tiles: the table is loaded once per workgroup, so no more workgroups than the chip holds twice over
+    const int64_t want = std::max<int64_t>(1, 1024 / (int64_t)cols);
+    const unsigned gx = (unsigned)std::min<int64_t>(n_tiles, want);
+    void (*kern)(PolyArgs) = nullptr;
+    switch (ts.T2) {
+#define HIPSOXR_POLY_T(t) case t: kern = k_poly<Real, t>; break;
+        HIPSOXR_POLY_TAPS(HIPSOXR_POLY_T)
+#undef HIPSOXR_POLY_T
+    }
+    if (!kern) return "two-stage: no polyphase instance for this tap count";
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)cols, 1), dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return nullptr;
+}
+
+// Whole-signal float job on an interpolated-phase plan: FFT stage + polyphase stage + exact edges.  *handled = false
+// (nothing launched) when the plan or the job is not one the two-stage form serves: the caller's ordinary path takes it.
+const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool *handled)
+{
+    *handled = false;
+    if (!p->phases || (j.elem != HIPSOXR_F32 && j.elem != HIPSOXR_F64) || j.in_abs0 != 0 || j.out_k0 != 0 || j.clip_table) return nullptr;
+    if ((uint64_t)j.out_frames > plan_out_len(*p, (uint64_t)j.in_frames)) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (!p->two)
+            if (const char *e = twostage_build(p)) return e;
+    }
+    const TwoStage &ts = *p->two;
+    if (!ts.ok) return nullptr;
+    const int64_t n = j.in_frames, n_out = j.out_frames;
+    if (n_out < 8 * ts.edge + 4096 || n >= (1LL << 30) || n_out >= (1LL << 30)) return nullptr;
+    const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
+    if (cols > 65535) return nullptr;
+    const size_t es = j.elem == HIPSOXR_F32 ? 4 : 8;
+    // the polyphase table and one tile's source span must fit LDS in the job's precision (long stages in float64 do not:
+    // the exact engine keeps those)
+    if ((size_t)ts.P2 * ts.row * 4 * es + (size_t)(512. * (double)ts.Ms / (double)ts.Ls + ts.T2 + 4) * es > 150u * 1024u) return nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    // intermediate signal: planar [clip][channel][frames], stream-ordered allocation
+    const int64_t n_mid = ts.up ? 2 * n : 2 * n_out;
+    void *mid = nullptr;
+    HIP_TRY(hipMallocAsync(&mid, (size_t)cols * (size_t)n_mid * es, st));
+    const int64_t mstr[3] = {n_mid * (int64_t)j.n_channels, 1, n_mid};
+    const int64_t istr[3] = {j.in_clip_stride, j.in_frame_stride, j.in_chan_stride};
+    const int64_t ostr[3] = {j.out_clip_stride, j.out_frame_stride, j.out_chan_stride};
+    auto fail = [&](const char *e) { (void)hipFreeAsync(mid, st); return e; };
+    hipsoxr_job_t fj = j;
+    fj.kernel = j.kernel == HIPSOXR_KERNEL_FFT_F64 ? HIPSOXR_KERNEL_FFT_F64 : HIPSOXR_KERNEL_FFT;
+    fj.clip_counter = nullptr; fj.dither = 0;
+    bool fft_done = false;
+    const char *err = nullptr;
+    if (ts.up) {
+        fj.out = mid; fj.out_clip_stride = mstr[0]; fj.out_frame_stride = mstr[1]; fj.out_chan_stride = mstr[2];
+        fj.in_frames = n; fj.out_frames = n_mid;
+        if ((err = device_bank_ensure(&p->two->fft, engine_prec(j.elem)))) return fail(err);
+        if ((err = launch_fft(&p->two->fft, fj, stream, &fft_done))) return fail(err);
+        if (!fft_done) { (void)hipFreeAsync(mid, st); return nullptr; }
+        err = j.elem == HIPSOXR_F32 ? launch_poly<float>(ts, mid, j.out, n_mid, 0, n_out, j.n_clips, j.n_channels, mstr, ostr, st)
+                                    : launch_poly<double>(ts, mid, j.out, n_mid, 0, n_out, j.n_clips, j.n_channels, mstr, ostr, st);
+        if (err) return fail(err);
+    } else {
+        err = j.elem == HIPSOXR_F32 ? launch_poly<float>(ts, j.in, mid, n, 0, n_mid, j.n_clips, j.n_channels, istr, mstr, st)
+                                    : launch_poly<double>(ts, j.in, mid, n, 0, n_mid, j.n_clips, j.n_channels, istr, mstr, st);
+        if (err) return fail(err);
+        fj.in = mid; fj.in_clip_stride = mstr[0]; fj.in_frame_stride = mstr[1]; fj.in_chan_stride = mstr[2];
+        fj.in_frames = n_mid; fj.out_frames = n_out;
+        if ((err = device_bank_ensure(&p->two->fft, engine_prec(j.elem)))) return fail(err);
+        if ((err = launch_fft(&p->two->fft, fj, stream, &fft_done))) return fail(err);
+        if (!fft_done) { (void)hipFreeAsync(mid, st); return nullptr; } // (the ordinary path recomputes everything)
+    }
+    (void)hipFreeAsync(mid, st);
+    // the outputs whose second-stage support reaches past an end of the intermediate signal: exact engine
+    for (int side = 0; side < 2; ++side) {
+        hipsoxr_job_t ej = j;
+        ej.kernel = HIPSOXR_KERNEL_EXACT;
+        ej.out_k0 = side ? n_out - ts.edge : 0;
+        ej.out_frames = ts.edge;
+        ej.out = (char *)j.out + (size_t)(ej.out_k0 * j.out_frame_stride) * es;
+        if (const char *e = launch_job(p, ej, stream)) return e;
+    }
+    *handled = true;
+    return nullptr;
+}
+
+} // namespace hipsoxr

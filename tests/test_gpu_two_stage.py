@@ -1,0 +1,88 @@
+"""GPU: the two-stage form of arbitrary ratios (csrc/twostage.hip — FFT engine at 1:2 / 2:1 + a short interpolated
+polyphase stage in LDS) against the oracle's float64 direct form ON ITS OWN BANK: random integer and float rate pairs in
+the style of the reference's tests/test_random.py:21-25 (seeded here), float32 and float64, mono and interleaved stereo, at
+size (0.4 - 3 M frames), white noise — the composite filter is the plan's own prototype, so no band-limiting is needed.
+Bars: float32 <= 1e-6 relative RMS (the engine's class), float64 <= 2e-9; the first and last outputs (whose second-stage
+support would leave the intermediate signal) come from the exact engine and must EQUAL it."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(seed, n):
+    r = random.Random(seed)
+    out = []
+    while len(out) < n:
+        a, b = (r.randint(8000, 96000), r.randint(8000, 96000)) if len(out) % 2 == 0 else (r.uniform(8000, 96000), r.uniform(8000, 96000))
+        if 0.26 < b / a < 12:        # (the two-stage form serves down-sampling to 4:1; steeper ratios stay on the exact engine)
+            out.append((a, b))
+    return out
+
+
+PAIRS = [(48000, 44101), (44101, 48000), (44100, 16001)] + _pairs(4, 5)
+
+
+def _rms(v):
+    return float(np.sqrt(np.mean(np.square(v, dtype=np.float64))))
+
+
+@pytest.mark.parametrize("in_rate,out_rate", PAIRS)
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 1e-6), (np.float64, 2e-9)])
+def test_two_stage_matches_the_oracle_direct_form(oracle, in_rate, out_rate, dtype, tol):
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(int(in_rate) % 1000 + 7)
+    ch = 2 if int(in_rate) % 2 else 1
+    frames = 400_000 if dtype == np.float64 else 1_200_000
+    x = (rng.standard_normal((frames, ch)) * 0.25).astype(dtype)
+    plan = dev.Plan(in_rate, out_rate, "VHQ")
+    assert plan.phases > 0                                   # an interpolated-phase plan: no exact bank for this ratio
+    xt = torch.from_numpy(x if ch > 1 else x[:, 0].copy()).cuda()
+    y = dev.resample_tensor(plan, xt).cpu().numpy().reshape(-1, ch)
+    ye = dev.resample_tensor(plan, xt, kernel=dev.KERNEL_EXACT).cpu().numpy().reshape(-1, ch)
+    assert y.shape == ye.shape == (plan.out_len(frames), ch)
+    if np.array_equal(y, ye):                                 # (a long polyphase table in float64 does not fit LDS: exact engine)
+        assert dtype == np.float64 and in_rate / out_rate > 2.5, "AUTO did not take the two-stage form"
+        return
+    assert np.array_equal(y[:8], ye[:8]) and np.array_equal(y[-8:], ye[-8:])   # the edges are the exact engine's
+    pl = oracle.plan(in_rate, out_rate, "VHQ")
+    c = ch - 1
+    # the oracle's float64 direct form on windows (its cost is 300-700 taps x a cubic per output): head, tail, three inside
+    n_out = y.shape[0]
+    for k0 in (0, n_out - 3000, n_out // 3, n_out // 2 + 777, (2 * n_out) // 3):
+        ref = oracle.resample_channel(pl, x[:, c].astype(np.float64), "ref", k0=k0, n_out=3000)
+        got = y[k0:k0 + 3000, c].astype(np.float64)
+        assert _rms(got - ref) <= tol * max(_rms(ref), 0.05), (k0, _rms(got - ref) / max(_rms(ref), 0.05))
+    # and the whole signal against the exact engine (same prototype, canonical order)
+    assert _rms(y.astype(np.float64) - ye) <= tol * _rms(ye), _rms(y.astype(np.float64) - ye) / _rms(ye)
+
+
+def test_two_stage_is_not_taken_where_it_does_not_apply():
+    """Steep down-sampling (> 4:1), the 16-bit recipes, small jobs, integer I/O and KERNEL_EXACT stay on the canonical-order
+    engine: AUTO == EXACT bit for bit."""
+    import torch
+    from soxr_amd import device as dev
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    x = torch.randn(300000, device="cuda", generator=g) * 0.25
+    for a, b, q, t in ((96000, 8001, "VHQ", x), (48000, 44101, "MQ", x), (48000, 44101, "VHQ", x[:3000].contiguous()),
+                       (48000, 44101, "VHQ", (x * 20000).to(torch.int16))):
+        plan = dev.Plan(a, b, q)
+        assert torch.equal(dev.resample_tensor(plan, t), dev.resample_tensor(plan, t, kernel=dev.KERNEL_EXACT)), (a, b, q)
+
+
+def test_two_stage_batches_and_layouts(oracle):
+    """Several clips x channels in one job, interleaved and planar, float32: every column within 1e-6 of the exact engine."""
+    import torch
+    from soxr_amd import device as dev
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    plan = dev.Plan(44100, 48001, "HQ")
+    x = torch.randn((3, 200000, 4), device="cuda", generator=g) * 0.25          # [clips, frames, channels] interleaved
+    for t in (x, x.permute(0, 2, 1).contiguous().permute(0, 2, 1)):            # ... and the same values planar
+        y = dev.resample_tensor(plan, t)
+        ye = dev.resample_tensor(plan, t, kernel=dev.KERNEL_EXACT)
+        d = (y.double() - ye.double())
+        rel = (d.pow(2).mean(dim=1).sqrt() / ye.double().pow(2).mean(dim=1).sqrt()).max().item()
+        assert 0 < rel <= 1e-6, rel

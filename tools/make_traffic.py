@@ -3,7 +3,7 @@
 HBM traffic per launch (FETCH_SIZE x 2 — the gfx950 correction of MI355X_MICROARCH.md §HBM for wide coalesced reads —
 plus WRITE_SIZE, both in KiB) and VALU wave-instructions per launch for the three bench workloads, keyed by the SHA-256
 of the kernel sources they were collected on (bench.py `measured_counters` refuses a record whose hash has gone stale).
-    python tools/make_traffic.py gpurun_out/prof profiles/r03_traffic.json"""
+    python tools/make_traffic.py gpurun_out/prof profiles/r04_traffic.json"""
 import collections
 import json
 import os
@@ -45,8 +45,37 @@ def pick(agg, sub, counter, want_threads=None):
     return sum(vals) / len(vals) if vals else None
 
 
+def trace_avg_us(prof_dir):
+    """kernel name -> (grid threads -> average duration in us) from the kernel-trace pass (the figure bench.py prints as
+    roofline.rocprof_avg_us beside its own HIP-event time)."""
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    try:
+        c = sqlite3.connect(_db(prof_dir, "trace"))
+        rows = c.execute("select name, grid_x * grid_y * grid_z, (end - start) from kernels").fetchall()
+    except (sqlite3.Error, SystemExit):
+        try:
+            rows = c.execute("select kernel_name, grid_size, (end_timestamp - start_timestamp) from kernel_dispatch").fetchall()  # (other rocpd schema)
+        except Exception:
+            return out
+    for name, gs, ns in rows:
+        out[name][gs].append(ns / 1e3)
+    return out
+
+
+def pick_us(tr, sub, want_threads=None):
+    vals = []
+    for name, d in tr.items():
+        if sub in name:
+            for gs, v in d.items():
+                if want_threads is None or gs == want_threads:
+                    vals.extend(v)
+    vals = vals[len(vals) // 10:]            # (the first launches run at a ramping clock)
+    return round(sum(vals) / len(vals), 3) if vals else None
+
+
 def main(prof_dir, out_path):
     p1, p3, p4 = counters(_db(prof_dir, "pmc1")), counters(_db(prof_dir, "pmc3")), counters(_db(prof_dir, "pmc4"))
+    tr = trace_avg_us(prof_dir)
     threads = {"configs1": None, "batch_shard": 128 * 50 * 384, "configs2": None, "float64": None, "arith_f64": None, "exact_engine": None}
     rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_INSTS_VALU passes (separate runs) of bench.py (tools/prof_bench.sh); "
                      "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE uncorrected; KiB",
@@ -57,19 +86,7 @@ def main(prof_dir, out_path):
             continue
         traffic = int((2 * f + w) * 1024)
         rec["workloads"][wl] = {"kernel": sub, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": traffic, "algorithmic_bytes": algo,
-                                "ratio": round(traffic / algo, 4), "valu_wave_insts": v}
-    # configs[2] with the walking channel-pair kernel (experiment build, HIPSOXR_DEBUG_WALK=3): passes pmc5 / pmc6
-    try:
-        p5, p6 = counters(_db(prof_dir, "pmc5")), counters(_db(prof_dir, "pmc6"))
-        sub, algo = "k_fft_strided2<hipsoxr::PairSpec<4410, 1600", WORKLOADS["configs2"][2]
-        f, w = pick(p5, sub, "FETCH_SIZE"), pick(p6, sub, "WRITE_SIZE")
-        if f is not None and w is not None:
-            traffic = int((2 * f + w) * 1024)
-            rec["workloads"]["configs2_walk3"] = {"kernel": sub + " (K = 3, -DFFT_EXPERIMENTS build, HIPSOXR_DEBUG_WALK=3)", "FETCH_SIZE_KiB": f,
-                                                  "WRITE_SIZE_KiB": w, "traffic_bytes": traffic, "algorithmic_bytes": algo,
-                                                  "ratio": round(traffic / algo, 4), "valu_wave_insts": None}
-    except SystemExit:
-        pass
+                                "ratio": round(traffic / algo, 4), "valu_wave_insts": v, "rocprof_avg_us": pick_us(tr, sub, threads[wl])}
     with open(out_path, "w") as fo:
         json.dump(rec, fo, indent=1)
     print(json.dumps(rec, indent=1))

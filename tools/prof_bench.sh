@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over bench.py: kernel trace + stats, then PMC passes (counters in their own runs: gpurun refuses --pmc
-# combined with other trace domains).  Round 3: the traffic record is made by tools/make_traffic.py from pmc1/pmc3/pmc4;
-# pmc5/6 repeat the traffic passes on configs[2] with the walking channel-pair kernel (HIPSOXR_DEBUG_WALK=3).
+# combined with other trace domains).  The traffic record (and the per-kernel average duration of the trace pass) is made
+# by tools/make_traffic.py from trace / pmc1 / pmc3 / pmc4.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
@@ -13,10 +13,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py $ARGS
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python bench.py $SHORT > $OUT/pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- python bench.py $SHORT > $OUT/pmc3.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- python bench.py $SHORT > $OUT/pmc4.log 2>&1
-if [ -f $R/python-soxr_amd/_variants/exp/libhipsoxr.so ]; then # (the walking kernel exists only in -DFFT_EXPERIMENTS builds)
-HIPSOXR_DEBUG_WALK=3 tools/with_variant.sh exp rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc5 -o p -- python tools/run_workload.py c2 5 > $OUT/pmc5.log 2>&1
-HIPSOXR_DEBUG_WALK=3 tools/with_variant.sh exp rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc6 -o p -- python tools/run_workload.py c2 5 > $OUT/pmc6.log 2>&1
-fi
 python tools/pmc_summary.py $OUT/trace/*.db $OUT/pmc*/*.db > $OUT/summary.txt 2>&1
 grep -h '"metric"' $OUT/bench_trace.log > $OUT/bench_line.json
 python tools/make_traffic.py $OUT $OUT/traffic.json > $OUT/traffic.log 2>&1
