@@ -2422,6 +2422,18 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
                 }
             }
         }
+        // HIPSOXR_DEBUG_TILE_FORM (debug builds): 1 = 64 periods whole, 2 = 64 split, 3 = 32 whole, 4 = 32 split — what
+        // tests/test_gpu_launch_forms.py::test_chosen_form_is_near_the_best compares the rule above against.
+        // (Round 4 also built a fifth form — 512 workgroups each WALKING an equal share of a column's units, slab after
+        //  slab — on the theory that 282 slabs on 256 CUs lose a fifth to layer quantisation.  They do not any more: the
+        //  split forms already give every SIMD its 6-7 units, all resident at once; walk 33.7 us vs 28.9 (32 split) on the
+        //  60 s clip, never ahead at any of eight sizes — profiles/r04_ab_experiments.txt §6.  Removed.)
+        const int force = switches().dbg_tile_form;
+        if (force >= 1 && force <= 4) {
+            best_pb = force <= 2 ? 64 : 32;
+            const int units = (best_pb / 32) * g.n_rt;
+            best_split = (force & 1) ? 1 : (units + 3) / 4;
+        }
         f32_split = best_split;
         if (best_pb == 32) {
             g.pb = 32;

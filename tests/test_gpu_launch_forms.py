@@ -82,3 +82,18 @@ def test_general_period_kernel_forms(oracle, tmp_path, a, b, dt, frames, ch):
         rng = np.random.default_rng(frames)
         for k0 in [0, len(yc) - 200] + [int(k) for k in rng.integers(0, len(yc) - 200, 3)]:
             assert np.array_equal(yc[k0:k0 + 200], oracle.resample_channel(pl, xc, mode, k0=k0, n_out=200)), k0
+
+
+def test_chosen_form_is_near_the_best():
+    """`launch_tile` picks slab size and unit split from a cost model fitted to one box's sweep; a clock or driver change could
+    de-tune it silently.  For eight job sizes (150 .. 1500 slabs of 64 periods, one and several columns) every form is forced in
+    turn (HIPSOXR_DEBUG_TILE_FORM, debug-switch build: tools/exact_forms.py): the rule's own choice must be within 10 % of the
+    best forced form, and every form must give the same bits."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exact_forms.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l for l in r.stdout.splitlines() if "chosen/best" in l]
+    assert len(rows) == 8, r.stdout[-2000:]
+    for l in rows:
+        ratio = float(l.split("chosen/best")[1].split()[0])
+        assert ratio <= 1.10, l
+        assert l.rstrip().endswith("bit-identical True"), l
