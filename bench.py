@@ -40,7 +40,7 @@ for p in (ROOT, os.path.join(ROOT, "python-soxr_amd")):
         sys.path.insert(0, p)
 
 IN_RATE, OUT_RATE, QUALITY = 48000, 44100, "VHQ"
-KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, second-generation paired-block kernel, for large float32 device jobs)",
+KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, paired-block kernel, for large float32 device jobs)",
                 1: "k_gather<float,float>", 2: "k_tile_mfma_p<float>", 3: "k_tile<float,float,16,true>",
                 4: "k_tile_mfma_p<float>", 5: "k_fft_pair2<.., float>", 6: "k_tile_mfma_p<float> (EXACT: canonical-order engine)"}
 # HBM traffic and VALU wave-instructions per launch come from rocprofv3 PMC passes (bench.py cannot collect counters
@@ -700,6 +700,23 @@ def main():
             del x2, y2, plan2
         except RuntimeError as e:  # context only
             result["configs2"] = {"error": str(e)}
+
+    # ---- a ratio without an exact bank (reference tests/test_random.py:21-25 draws such rates): 48000 -> 44101 stereo 60 s
+    #      as a float32 device job — the two-stage form (FFT engine at 2:1 + a short polyphase stage) against the exact engine
+    if not args.no_batch and world == 1 and args.kernel == 0:
+        try:
+            plan3 = dev.Plan(48000, 44101, QUALITY)
+            x3 = torch.randn((IN_RATE * args.seconds, 2), device=device, dtype=torch.float32, generator=g) * 0.25
+            _, k3, y3 = time_workload(plan3, x3, max(5, args.steps // 10), 2, world, device, 0, windows=10)
+            _, k3e, _ = time_workload(plan3, x3, 5, 2, world, device, 6, windows=4)
+            bytes3 = 4.0 * (x3.numel() + y3.numel())
+            result["arbitrary_ratio"] = {"workload": f"VHQ 48000->44101 float32, {args.seconds} s stereo interleaved, device-resident (interpolated-phase plan: {plan3.phases} intervals x {plan3.taps} taps)",
+                                         "launch_us": k3 * 1e6, "kernel": "two-stage: k_poly<float, T2> + k_fft (2:1) + exact edges (csrc/twostage.hip)",
+                                         "value": x3.numel() / k3 / 1e6, "unit": "Msamples/s", "hbm_frac": bytes3 / k3 / 1e9 / HBM_PEAK_GBS,
+                                         "exact_engine_launch_us": k3e * 1e6, "speedup_over_exact": k3e / k3}
+            del x3, y3, plan3
+        except RuntimeError as e:  # context only
+            result["arbitrary_ratio"] = {"error": str(e)}
 
     # the canonical-order (bit-exact) engine on the same workloads, for reference
     if args.kernel == 0 and world == 1:

@@ -168,3 +168,54 @@ def test_small_chunk_stream_after_a_large_chunk_stream_still_gets_the_host_ring(
     t_after = min(t for t, _ in after)
     assert all(np.array_equal(y_fresh, y) for _, y in fresh + after)
     assert t_after < 1.35 * t_fresh + 2e-6, (t_fresh, t_after)
+
+
+def test_default_streams_never_park_a_kernel_and_auto_ones_do_so_only_while_fed(soxr):
+    """ADVICE (round 3): the path that turns resident by itself is OPT-IN now.  A stream created without a flag, fed small
+    chunks back to back, leaves nothing spinning on the GPU: a device-wide synchronisation right behind it returns at once.
+    With resident="auto" the same feed turns the path on (and the frames stay the synchronous stream's, call for call); while
+    another thread keeps feeding, device-wide synchronisations from this thread still return (bounded by the idle time plus a
+    relaunch, not for ever); once the feed stops — a gap in the run — the stream drops back by itself."""
+    import threading
+    import torch
+    x = _signal(np.int16, 44100 * 2, 1, 43)
+    ref = _run(soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ"), x, [441])
+    # no flag: nothing resident
+    rs = soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ")
+    waits = []
+    for rep in range(5):
+        for a in range(0, 441 * 40, 441):
+            rs.resample_chunk(x[a:a + 441])
+        t0 = time.perf_counter(); torch.cuda.synchronize(); waits.append(time.perf_counter() - t0)
+    assert sorted(waits)[2] < 0.5e-3, waits              # (a resident instance holds a device sync for its 1 ms idle time)
+    # opt-in: same frames in the same calls
+    auto = soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ", resident="auto")
+    got = _run(auto, x, [441])
+    assert [len(p) for p in got] == [len(p) for p in ref] and np.array_equal(np.concatenate(got), np.concatenate(ref))
+    # concurrent device-wide synchronisations while another thread feeds an auto stream
+    feeder_done, sync_times = threading.Event(), []
+    auto2 = soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ", resident="auto")
+    out2 = []
+
+    def feed():
+        try:
+            out2.extend(_run(auto2, x, [441]))
+        finally:
+            feeder_done.set()
+
+    th = threading.Thread(target=feed); th.start()
+    while not feeder_done.is_set():
+        t0 = time.perf_counter(); torch.cuda.synchronize(); sync_times.append(time.perf_counter() - t0)
+        time.sleep(0.002)
+    th.join()
+    assert np.array_equal(np.concatenate(out2), np.concatenate(ref))
+    assert sync_times and max(sync_times) < 0.25, max(sync_times)    # never starved: every synchronisation came back
+    # the feed has stopped: after a gap the stream has dropped back — a device sync behind one more small call is immediate
+    time.sleep(0.01)
+    auto3 = soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ", resident="auto")
+    for a in range(0, 441 * 40, 441):
+        auto3.resample_chunk(x[a:a + 441])                           # (turned resident by now)
+    time.sleep(0.01)                                                 # the run breaks
+    auto3.resample_chunk(x[:441])                                    # ordinary path again
+    t0 = time.perf_counter(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    assert dt < 0.5e-3, dt
