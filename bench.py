@@ -565,6 +565,7 @@ def main():
     ap.add_argument("--windows", type=int, default=50, help="extra timing windows of K launches (median -> launch_us)")
     ap.add_argument("--sustained-s", type=float, default=3.0, help="wall seconds of the sustained batch leg")
     ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true", help="device-kernel legs only (profiling target: no host API / stream / CPU / ceiling legs)")
     args = ap.parse_args()
 
     import torch
@@ -738,7 +739,7 @@ def main():
             result["arith_f64"] = {"error": str(e)}
 
     if rank == 0:
-        ceil = hbm_ceiling(device)
+        ceil = hbm_ceiling(device) if not args.kernels_only else {"skipped": "--kernels-only"}
         result["hbm_ceiling"] = ceil
         # the north star words its target against the HBM *read* roofline: input bytes only
         result["roofline"]["read_frac"] = 4.0 * n_in / kern / 1e9 / HBM_PEAK_GBS
@@ -756,15 +757,16 @@ def main():
                                              "traffic": br["traffic"], "launch_us": br["launch_us"]}
     if rank == 0 and world == 1 and not args.no_batch:
         result["dtype_matrix"] = dtype_matrix(plan, device, args.seconds, args.steps)
-        result["configs4"] = configs4_stream()
-    if rank == 0 and world == 1:
+        if not args.kernels_only:
+            result["configs4"] = configs4_stream()
+    if rank == 0 and world == 1 and not args.kernels_only:
         result["host_api"] = host_api_timings()
-    if rank == 0 and world == 1 and not args.no_batch:
+    if rank == 0 and world == 1 and not args.no_batch and not args.kernels_only:
         try:
             result["host_batch"] = host_batch()
         except Exception as e:  # context only
             result["host_batch"] = {"error": str(e)}
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.kernels_only:
         result["cpu_baseline"] = cpu_baseline(args.seconds)
     elif rank == 0:
         result["cpu_baseline"] = None
