@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 A/B on one box: [variant|-] [ENV=1 ...] per line of the CONFIGS array; prints headline / batch / configs[2] launch times.
-#   tools/ab3.sh "<variant or -> <env assignments>" ...       e.g.  tools/ab3.sh "- " "- HIPSOXR_FFT_NO_PERSIST=1" "noearly HIPSOXR_FFT_NO_PERSIST=1"
+#   tools/ab3.sh "<variant or -> <env assignments>" ...       e.g.  tools/ab3.sh "- " "- HIPSOXR_FFT_NO_PAIR=1" "x2 HIPSOXR_FFT_X2=1"
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 line() { python -c "

@@ -18,8 +18,8 @@ WORKLOADS = {  # name -> (kernel-name substring, grid predicate, algorithmic byt
     "configs1": ("k_fft_pair2<hipsoxr::PairSpec<2560, 2352", lambda gx, gy: gy == 1, 4 * (2880000 + 2646000)),
     "batch_shard": ("k_fft_pair2<hipsoxr::PairSpec<5120, 4704", lambda gx, gy: gy == 128, 4 * 128 * (480000 + 441000)),
     "configs2": ("k_fft_strided2<hipsoxr::PairSpec<4410, 1600", lambda gx, gy: True, 4 * 8 * (2646000 + 960000)),
-    "float64": ("double, double>", lambda gx, gy: True, 8 * (2880000 + 2646000)),
-    "arith_f64": ("double, float>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
+    "float64": ("double, double, 1>", lambda gx, gy: True, 8 * (2880000 + 2646000)),
+    "arith_f64": ("double, float, 1>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
     "exact_engine": ("k_tile_mfma_p<float>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
 }
 
