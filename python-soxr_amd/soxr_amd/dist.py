@@ -210,12 +210,15 @@ class _HostPipe:
          d2h(k)     packed device result -> pinned output slot                 (stream `sout`, behind run(k))
          unstage(k) CPU copies the slot into the caller's result arrays        (host thread B, behind d2h(k))
     so that the H2D copy of block k+1, the launch of block k and the D2H copy of block k-1 are in flight together and
-    the two CPU copies run beside them.  Blocks hold whole clips, about `block_bytes` of input each."""
+    the two CPU copies run beside them.  Blocks hold whole clips, about `block_bytes` of input each.
+    With `pinned_results` d2h(k) lands in a pinned buffer of the block's own (from torch's caching host allocator) and the
+    result arrays ARE views of it: no unstage copy — half of the CPU work of the path, which is what bounds it."""
     SLOTS = 3
 
-    def __init__(self, plan, device, dtype, ch, kernel, block_bytes):
+    def __init__(self, plan, device, dtype, ch, kernel, block_bytes, pinned_results=False):
         import torch
         self.torch, self.plan, self.device, self.kernel, self.ch = torch, plan, device, kernel, ch
+        self.pinned_results = pinned_results
         self.tdtype = dtype
         self.sin, self.sc, self.sout = (torch.cuda.Stream(device=device) for _ in range(3))
         self.block_bytes = block_bytes
@@ -232,8 +235,10 @@ class _HostPipe:
             self.dev_in = [torch.empty(n_in_el, dtype=self.tdtype, device=self.device) for _ in range(self.SLOTS)]
         if n_out_el > self.cap_out:
             self.cap_out = n_out_el
-            self.pin_out = [torch.empty(n_out_el, dtype=self.tdtype, pin_memory=True) for _ in range(self.SLOTS)]
+            self.pin_out = None
             self.dev_out = [torch.empty(n_out_el, dtype=self.tdtype, device=self.device) for _ in range(self.SLOTS)]
+        if not self.pinned_results and (self.pin_out is None or self.pin_out[0].numel() < self.cap_out):
+            self.pin_out = [torch.empty(self.cap_out, dtype=self.tdtype, pin_memory=True) for _ in range(self.SLOTS)]
 
     def run(self, clips, results, idx):
         """clips: numpy arrays of this device (all the same dtype / channel count); results[idx[i]] = resampled clips[i]."""
@@ -254,6 +259,7 @@ class _HostPipe:
         ev_out = [None] * len(blocks)       # d2h(k) done
         ev_run = [None] * len(blocks)       # run(k) done
         free_out = [threading.Semaphore(1) for _ in range(self.SLOTS)]   # the output slot has been unstaged
+        own_out = [None] * len(blocks)      # pinned_results: the block's own pinned result buffer
         staged = [threading.Event() for _ in blocks]
         issued = [threading.Event() for _ in blocks]
         err = []
@@ -267,12 +273,20 @@ class _HostPipe:
                         if err:
                             return
                         ev_free_in[s].synchronize()
-                    view, pos, jobs = self.pin_in[s].numpy(), 0, []
-                    for i in b:
+                    view, pos, runs = self.pin_in[s].numpy(), 0, [[] for _ in range(self.copy_threads)]
+                    share, t = sum(n_in[i] for i in b) * ch / self.copy_threads, 0
+                    for i in b:                       # one task per copy thread: a run of clips of about equal bytes
                         n = n_in[i] * ch
-                        jobs.append(pool.submit(np.copyto, view[pos:pos + n], clips[i].reshape(-1), "no"))
+                        if pos >= (t + 1) * share and t + 1 < self.copy_threads:
+                            t += 1
+                        runs[t].append((pos, n, i))
                         pos += n
-                    for f in jobs:
+
+                    def put(run):
+                        for pos, n, i in run:
+                            np.copyto(view[pos:pos + n], clips[i].reshape(-1), casting="no")
+
+                    for f in [pool.submit(put, r) for r in runs if r]:
                         f.result()
                     staged[k].set()
             except Exception as e:  # pragma: no cover
@@ -288,6 +302,14 @@ class _HostPipe:
                         return
                     ev_out[k].synchronize()
                     s = k % self.SLOTS
+                    if own_out[k] is not None:        # the results are views of the block's pinned buffer (which they keep alive)
+                        view, pos = own_out[k].numpy(), 0
+                        for i in b:
+                            n = n_out[i] * ch
+                            results[idx[i]] = view[pos:pos + n].reshape((n_out[i],) if clips[i].ndim == 1 else (n_out[i], ch))
+                            pos += n
+                        own_out[k] = None
+                        continue
                     view, pos, jobs = self.pin_out[s].numpy(), 0, []
 
                     def take(i, pos, n):   # (allocation included: the first touch of a fresh result array is most of its cost)
@@ -335,7 +357,10 @@ class _HostPipe:
                 j.in_frames, j.out_frames = int(ni.max()), int(no.max())
                 j.clip_table, j.clip_table_dev = table.ctypes.data, None
                 j.dither = int(self.tdtype == torch.int16)
-                free_out[s].acquire()                 # the result slot of block k - SLOTS has been copied out
+                if self.pinned_results:
+                    own_out[k] = torch.empty(max(tot_out, 1), dtype=self.tdtype, pin_memory=True)
+                else:
+                    free_out[s].acquire()             # the result slot of block k - SLOTS has been copied out
                 self.sc.wait_event(e_in)
                 if k >= self.SLOTS:
                     self.sc.wait_event(ev_out[k - self.SLOTS])   # ... and its device buffer read by d2h(k - SLOTS)
@@ -345,7 +370,7 @@ class _HostPipe:
                 ev_run[k] = e_c
                 with torch.cuda.stream(self.sout):
                     self.sout.wait_event(e_c)
-                    self.pin_out[s][:tot_out].copy_(self.dev_out[s][:tot_out], non_blocking=True)
+                    (own_out[k] if self.pinned_results else self.pin_out[s])[:tot_out].copy_(self.dev_out[s][:tot_out], non_blocking=True)
                     e_o = torch.cuda.Event(); e_o.record(self.sout)
                 ev_out[k] = e_o
                 issued[k].set()
@@ -361,7 +386,11 @@ class _HostPipe:
 _PIPES = {}
 
 
-def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel=_n.KERNEL_AUTO, block_bytes=64 << 20):
+PINNED_RESULTS_MAX = 8 << 30     # host results up to this many bytes per call are returned in pinned memory by default
+
+
+def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel=_n.KERNEL_AUTO, block_bytes=64 << 20,
+                   pinned_results=None):
     """Resample independent clips on the GPUs of this node from ONE process.
 
     clips    : sequence of arrays, each [frames] or [frames, channels] — numpy (host) or torch tensors (any
@@ -374,6 +403,10 @@ def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel
                current stream on the computing device waits for the results.
                Host arrays: a pinned staging ring per device, blocks of about `block_bytes` of input, with the H2D
                copy of block k+1, the launch of block k and the D2H copy of block k-1 in flight together.
+    pinned_results : host results as views of page-locked buffers the D2H copies land in (one buffer per block, kept
+               alive by its arrays, recycled by torch's caching host allocator once they are all dropped) instead of
+               fresh pageable arrays filled by one more CPU copy.  None: yes while the call's results stay under
+               PINNED_RESULTS_MAX bytes.  The arrays are ordinary writable numpy arrays either way.
     kernel   : engine selector for the device jobs (AUTO: the frequency-domain engine for large float jobs,
                1e-6-class; KERNEL_EXACT: the canonical-order engine, bit-identical to `soxr_amd.resample`).
     Returns a list of arrays of the same kind (numpy in -> numpy out; tensor in -> tensor on the device that
@@ -391,6 +424,9 @@ def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel
         raise ValueError("no devices")
     bank0 = _plan_on(devices[0], in_rate, out_rate, quality).bank() if len(devices) > 1 else None
     results = [None] * len(clips)
+    if pinned_results is None:
+        r = float(out_rate) / float(in_rate)
+        pinned_results = sum(c.nbytes for c in clips if isinstance(c, np.ndarray)) * r <= PINNED_RESULTS_MAX
     parts = shard_by_frames([int(c.shape[0]) for c in clips], len(devices))
 
     def work(i):
@@ -407,10 +443,10 @@ def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel
                 c0 = clips[host[0]]
                 ch = 1 if c0.ndim == 1 else c0.shape[1]
                 tdt = torch.from_numpy(np.empty(0, c0.dtype)).dtype
-                key = (d, i, tdt, ch, int(kernel), int(block_bytes))   # (one pipe per device SLOT: the same device listed twice runs two)
+                key = (d, i, tdt, ch, int(kernel), int(block_bytes), bool(pinned_results))   # (one pipe per device SLOT: the same device listed twice runs two)
                 pipe = _PIPES.get(key)
                 if pipe is None:
-                    pipe = _PIPES[key] = _HostPipe(plan, dev_t, tdt, ch, kernel, block_bytes)
+                    pipe = _PIPES[key] = _HostPipe(plan, dev_t, tdt, ch, kernel, block_bytes, bool(pinned_results))
                 pipe.plan = plan
                 pipe.run([np.ascontiguousarray(clips[k]) for k in host], results, host)
             if dev:

@@ -135,9 +135,19 @@ def test_host_corpus_goes_through_the_staging_pipeline(oracle):
     from soxr_amd import dist as sdist, device as dev
     rng = np.random.default_rng(77)
     clips = [(rng.standard_normal(30000 + 4001 * (i % 7)) * 0.25).astype(np.float32) for i in range(23)]
-    outs = sdist.resample_batch(clips, 48000, 44100, "VHQ", devices=[0, 0], kernel=dev.KERNEL_EXACT, block_bytes=400000)
-    for c, o in zip(clips, outs):
-        assert isinstance(o, np.ndarray) and np.array_equal(o, soxr.resample(c, 48000, 44100, quality="VHQ"))
+    for pinned in (None, True, False):      # results as views of the pinned D2H buffers (the default at this size) / copied out
+        outs = sdist.resample_batch(clips, 48000, 44100, "VHQ", devices=[0, 0], kernel=dev.KERNEL_EXACT, block_bytes=400000,
+                                    pinned_results=pinned)
+        for c, o in zip(clips, outs):
+            assert isinstance(o, np.ndarray) and o.flags.writeable and np.array_equal(o, soxr.resample(c, 48000, 44100, quality="VHQ"))
+    # pinned results own their buffers: a second batch through the same pipes must not touch the first one's arrays
+    outs_pinned = sdist.resample_batch(clips, 48000, 44100, "VHQ", devices=[0], kernel=dev.KERNEL_EXACT, block_bytes=400000, pinned_results=True)
+    keep = [o.copy() for o in outs_pinned]
+    sdist.resample_batch([c[::-1].copy() for c in clips], 48000, 44100, "VHQ", devices=[0], kernel=dev.KERNEL_EXACT, block_bytes=400000,
+                         pinned_results=True)
+    for a, b in zip(outs_pinned, keep):
+        assert np.array_equal(a, b)
+    outs_pinned[0][:] = 0                   # ... and are ordinary writable arrays
     ci = [(rng.standard_normal((9000 + 501 * i, 2)) * 5000).astype(np.int16) for i in range(9)]
     oi = sdist.resample_batch(ci, 44100, 16000, "HQ", devices=[0], kernel=dev.KERNEL_EXACT, block_bytes=100000)
     for c, o in zip(ci, oi):
