@@ -374,6 +374,7 @@ struct FftArgs {
     uint32_t n_clips, n_channels;
     int64_t ics, ifs, ichs, ocs, ofs, ochs;
     int64_t in_frames, out_frames;
+    int64_t in_lo;           // the column holds samples [in_lo, in_frames) (hipsoxr_job_t::in_abs0: `in` points at sample 0, zero outside); 0 for ragged batches
     const int64_t *clip_tab; // ragged batch (hipsoxr_job_t::clip_table_dev): [n_clips][4] = in offset, in frames, out offset, out frames; k_fft_pair2 only
     int32_t chpair;          // k_fft_strided2: 1 = pair neighbouring channels of interleaved data instead of blocks
     int64_t pairs_per_col;   // xcd_map: work items (blocks, or pairs of blocks) per channel unit
@@ -422,8 +423,8 @@ __global__ void __launch_bounds__(256, 2) k_fft_block(FftArgs a)
     // ---- load: z[n] = x[2n] + i x[2n+1], zero outside the signal; forward complex FFT of length A
     for (int n = threadIdx.x; n < A; n += blockDim.x) {
         const int64_t l = in0 + 2 * (int64_t)n;
-        float re = (l >= 0 && l < a.in_frames) ? xin[l * a.ifs] : 0.f;
-        float im = (l + 1 >= 0 && l + 1 < a.in_frames) ? xin[(l + 1) * a.ifs] : 0.f;
+        float re = (l >= a.in_lo && l < a.in_frames) ? xin[l * a.ifs] : 0.f;
+        float im = (l + 1 >= a.in_lo && l + 1 < a.in_frames) ? xin[(l + 1) * a.ifs] : 0.f;
         cur[n] = make_float2(re, im);
     }
     __syncthreads();
@@ -634,7 +635,7 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
     auto lds_store = [&](int p, int n, C v) { buf(p)[n] = v; };
 
     // ---- forward: z_p[n] = x_{2p}[n] + i x_{2p+1}[n], first pass straight from HBM ------------------
-    if (ina >= 0) {
+    if (ina >= a.in_lo) {
         const int64_t left = (in_frames - ina) * ES; // bytes from the first block's first sample to the end of the column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             uniform_ptr((void *)(xin + ina)), 0, __builtin_amdgcn_readfirstlane((int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left)), 0x00020000);
@@ -645,7 +646,7 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
     } else { // the first item of a column reaches before its start: explicit zero-extension
         Spec::template fwd<P>(FFT_STAMP_ARGS buf, PairTabs<Real>::wa(a), [&](int p, int n, int) -> C {
             const int64_t la = ina + 2 * p * hop_in + n, lb = la + hop_in;
-            return C((la >= 0 && la < in_frames) ? (Real)xin[la] : (Real)0, (lb >= 0 && lb < in_frames) ? (Real)xin[lb] : (Real)0);
+            return C((la >= a.in_lo && la < in_frames) ? (Real)xin[la] : (Real)0, (lb >= a.in_lo && lb < in_frames) ? (Real)xin[lb] : (Real)0);
         }, lds_store);
     }
     const Real *Hr = PairTabs<Real>::hr(a);
@@ -805,7 +806,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
     const int64_t ina = pa * a.M, outa = pa * a.L;
 
     // ---- forward: z[n] = x_c[n] + i x_{c+1}[n]  (CP)  or  x_a[n] + i x_b[n]  (two blocks), first pass straight from HBM
-    if (ina >= 0) {
+    if (ina >= a.in_lo) {
         const int64_t left = (a.in_frames - ina) * (int64_t)ifb; // bytes from the block's first frame to the end of the column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             uniform_ptr((void *)(xin + ina * a.ifs)), 0, __builtin_amdgcn_readfirstlane((int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left)), 0x00020000);
@@ -819,10 +820,10 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
             const int64_t l = ina + n, lb = l + hop_in;
             if constexpr (CP) {
                 C v = C((Real)0, (Real)0);
-                if (l >= 0 && l < a.in_frames) v = C(xin[l * a.ifs], xin[l * a.ifs + 1]);
+                if (l >= a.in_lo && l < a.in_frames) v = C(xin[l * a.ifs], xin[l * a.ifs + 1]);
                 return v;
             } else {
-                return C((l >= 0 && l < a.in_frames) ? xin[l * a.ifs] : (Real)0, (lb >= 0 && lb < a.in_frames) ? xin[lb * a.ifs] : (Real)0);
+                return C((l >= a.in_lo && l < a.in_frames) ? xin[l * a.ifs] : (Real)0, (lb >= a.in_lo && lb < a.in_frames) ? xin[lb * a.ifs] : (Real)0);
             }
         }, lds_store);
     }
@@ -1030,6 +1031,8 @@ bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &j)
            j.out_k0 == 0 && (uint64_t)j.out_frames <= plan_out_len(p, (uint64_t)j.in_frames);
 }
 
+// (job.in_abs0 != 0 — in[0] is sample in_abs0 of a column that is zero outside [in_abs0, in_abs0 + in_frames) — is served
+// for the two-stage form's inner calls; the public paths come here through fft_job_eligible, which wants 0.)
 const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *handled)
 {
     *handled = false;
@@ -1143,7 +1146,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
             }
             if (use) {
                 FftArgs a;
-                a.in = j.in; a.out = j.out;
+                a.in = (const char *)j.in - j.in_abs0 * j.in_frame_stride * (int64_t)(j.elem == HIPSOXR_F64 ? 8 : 4); a.out = j.out; // (sample 0 of the columns)
                 a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
                 a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
                 a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
@@ -1155,7 +1158,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 a.n_clips = j.n_clips; a.n_channels = j.n_channels;
                 a.ics = j.in_clip_stride; a.ifs = j.in_frame_stride; a.ichs = j.in_chan_stride;
                 a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
-                a.in_frames = j.in_frames; a.out_frames = j.out_frames;
+                a.in_lo = j.in_abs0; a.in_frames = j.in_abs0 + j.in_frames; a.out_frames = j.out_frames;
                 a.clip_tab = j.clip_table_dev;
                 const int64_t n_blocks = (j.out_frames + g.hop_out - 1) / g.hop_out;
                 if (n_blocks > 2147483647LL) return "job too long for one launch";
@@ -1259,7 +1262,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     }
     if (!g.ok) return nullptr;
     FftArgs a;
-    a.in = j.in; a.out = j.out;
+    a.in = (const char *)j.in - j.in_abs0 * j.in_frame_stride * 4; a.out = j.out;
     a.WA = g.dev; a.WB = a.WA + g.A; a.P = a.WB + g.B; a.Q = a.P + (g.A + 1); a.Hs = a.Q + g.B;
     a.WA2 = a.Hs + (g.B + 1); a.WB2 = a.WA2 + g.N_in;
     a.Hr = reinterpret_cast<const float *>(a.WB2 + g.N_out); a.trace = nullptr;
@@ -1272,7 +1275,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     a.n_clips = j.n_clips; a.n_channels = j.n_channels;
     a.ics = j.in_clip_stride; a.ifs = j.in_frame_stride; a.ichs = j.in_chan_stride;
     a.ocs = j.out_clip_stride; a.ofs = j.out_frame_stride; a.ochs = j.out_chan_stride;
-    a.in_frames = j.in_frames; a.out_frames = j.out_frames;
+    a.in_lo = j.in_abs0; a.in_frames = j.in_abs0 + j.in_frames; a.out_frames = j.out_frames;
     const int64_t n_blocks = (j.out_frames + g.hop_out - 1) / g.hop_out;
     const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
     if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";

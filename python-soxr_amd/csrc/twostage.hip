@@ -17,8 +17,10 @@
 // not only band-limited ones: <= 1e-6 of the oracle's float64 direct form (tests/test_gpu_random_rates.py).
 // The polyphase stage's cubic table ([P2][T2] records of 16 bytes: 12-50 KB) lives in LDS, which ends the 423 MB stream of
 // coefficient records through the scalar cache that bounds k_interp_tile.
-// Edges: an intermediate signal exists only on [0, its length), so the few outputs whose second-stage support reaches
-// past either end (E per end: tens to ~150) come from the exact engine instead (two small launches).
+// Ends: the intermediate signal is produced a few samples PAST both ends of the job (as far as the second stage reads it;
+// hipsoxr_job_t::in_abs0 places it for the FFT engine), so every output, the first and last included, is the composite
+// filter's response to the zero-extended signal: two launches in all.  A thread of k_poly keeps its source window in
+// registers from one output to the next (see MQ), so the table records are the stage's only per-tap LDS traffic.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,10 +41,9 @@ namespace hipsoxr {
 struct TwoStage {
     bool ok = false, up = false;
     Plan fft;                 // the FFT stage's plan: L/M = 2/1 (up) or 1/2 (down), bank from the owner's prototype
-    int32_t T2 = 0, P2 = 0, row = 0; // polyphase stage: taps, table intervals, records per table row (T2 + 1: bank spreading)
+    int32_t T2 = 0, P2 = 0, P2f = 0, row = 0; // polyphase stage: taps, table intervals (float64 / float32 table), records per table row (T2 + 1: bank spreading)
     int64_t Ls = 1, Ms = 1;   // polyphase stage: output k sits at k * Ms / Ls of ITS input samples
-    int64_t edge = 0;         // outputs per end taken from the exact engine
-    void *tab_f = nullptr, *tab_d = nullptr; // device: [P2][row] float4 / double4 records (a0..a3 of the cubic in x in [0, 1))
+    void *tab_f = nullptr, *tab_d = nullptr; // device: [P2f][row] float4 / [P2][row] double4 records (a0..a3 of the cubic in x in [0, 1))
 };
 
 void twostage_release(Plan *p)
@@ -107,7 +108,10 @@ static const char *twostage_build(Plan *p)
     for (int t : {8, 12, 16, 20, 24, 28, 32, 40, 48, 56}) // (HIPSOXR_POLY_TAPS: the kernel's instances)
         if (!ts->T2 && t >= (int)std::ceil(n_taps)) ts->T2 = t;
     if (!ts->T2) return nullptr;
-    ts->P2 = 128; // (the float32 table could do with 64 intervals — 1.5e-8 — at half the LDS: not needed so far)
+    // intervals of the cubic table: the interpolation error of a Chebyshev cubic over 1/P of a sample of this prototype is
+    // about 0.03 / P^4 of full scale: 1.2e-10 at 128 (float64 table), 1.9e-9 at 64 (float32 table: two orders under the
+    // float32 engine's floor, half the LDS — which is what lets several workgroups share a CU)
+    ts->P2 = 128; ts->P2f = 64;
     ts->row = ts->T2 + 1;
     if ((size_t)ts->P2 * ts->row * 16 > 100 * 1024) return nullptr;
     // output k of the polyphase stage at k * Ms / Ls input samples: up: from 2 f_in to f_out: 2 M / L; down: from f_in to
@@ -128,29 +132,30 @@ static const char *twostage_build(Plan *p)
     // cubic per (interval, tap) through the four Chebyshev nodes of the interval, monomials in x in [0, 1) (plan.cpp)
     double node[4];
     for (int c = 0; c < 4; ++c) node[c] = .5 - .5 * std::cos((double)(2 * c + 1) * M_PI / 8.);
-    std::vector<double> tab((size_t)ts->P2 * ts->row * 4, 0.);
-    for (int i = 0; i < ts->P2; ++i)
-        for (int j = 0; j < ts->T2; ++j) {
-            double v[4];
-            for (int c = 0; c < 4; ++c) v[c] = h(((double)i + node[c]) / ts->P2 + (double)(ts->T2 / 2 - 1 - j));
-            const double d01 = (v[1] - v[0]) / (node[1] - node[0]), d12 = (v[2] - v[1]) / (node[2] - node[1]), d23 = (v[3] - v[2]) / (node[3] - node[2]);
-            const double d012 = (d12 - d01) / (node[2] - node[0]), d123 = (d23 - d12) / (node[3] - node[1]);
-            const double d3 = (d123 - d012) / (node[3] - node[0]);
-            double *a = &tab[((size_t)i * ts->row + j) * 4];
-            a[3] = d3;
-            a[2] = d012 - d3 * (node[0] + node[1] + node[2]);
-            a[1] = d01 - d012 * (node[0] + node[1]) + d3 * (node[0] * node[1] + node[0] * node[2] + node[1] * node[2]);
-            a[0] = v[0] - d01 * node[0] + d012 * node[0] * node[1] - d3 * node[0] * node[1] * node[2];
-        }
-    std::vector<float> tabf(tab.size());
-    for (size_t i = 0; i < tab.size(); ++i) tabf[i] = (float)tab[i];
+    auto build = [&](int P) {
+        std::vector<double> tab((size_t)P * ts->row * 4, 0.);
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < ts->T2; ++j) {
+                double v[4];
+                for (int c = 0; c < 4; ++c) v[c] = h(((double)i + node[c]) / P + (double)(ts->T2 / 2 - 1 - j));
+                const double d01 = (v[1] - v[0]) / (node[1] - node[0]), d12 = (v[2] - v[1]) / (node[2] - node[1]), d23 = (v[3] - v[2]) / (node[3] - node[2]);
+                const double d012 = (d12 - d01) / (node[2] - node[0]), d123 = (d23 - d12) / (node[3] - node[1]);
+                const double d3 = (d123 - d012) / (node[3] - node[0]);
+                double *a = &tab[((size_t)i * ts->row + j) * 4];
+                a[3] = d3;
+                a[2] = d012 - d3 * (node[0] + node[1] + node[2]);
+                a[1] = d01 - d012 * (node[0] + node[1]) + d3 * (node[0] * node[1] + node[0] * node[2] + node[1] * node[2]);
+                a[0] = v[0] - d01 * node[0] + d012 * node[0] * node[1] - d3 * node[0] * node[1] * node[2];
+            }
+        return tab;
+    };
+    const std::vector<double> tab = build(ts->P2), tab64 = build(ts->P2f);
+    std::vector<float> tabf(tab64.size());
+    for (size_t i = 0; i < tab64.size(); ++i) tabf[i] = (float)tab64[i];
     HIP_TRY(hipMalloc(&ts->tab_f, tabf.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(ts->tab_f, tabf.data(), tabf.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&ts->tab_d, tab.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(ts->tab_d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    // edges (outputs of the JOB per end): up: second-stage support T2/2 u-samples = T2/4 input samples; down: the FFT
-    // stage's support f.T/2 v-samples = f.T/4 outputs
-    ts->edge = ts->up ? (int64_t)std::ceil((ts->T2 / 4. + 2.) * (double)p->L / (double)p->M) + 2 : f.T / 4 + 4;
     ts->ok = true;
     return nullptr;
 }
@@ -165,18 +170,28 @@ struct PolyArgs {
     const void *src; void *dst; const void *tab;
     int32_t T, P, row, R, span_max;
     int64_t Ls, Ms, Mq, Mr; // Ms = Mq * Ls + Mr
-    int64_t n_src, k_lo, n_out;
+    int64_t n_lo, n_src, k_lo, n_out; // the source column holds samples [n_lo, n_src) (src points at sample 0; zero outside); outputs [k_lo, k_lo + n_out), k_lo may be < 0
     int64_t scs, sfs, schs, dcs, dfs, dchs;
     uint32_t n_channels;
 };
 
 // tap counts the polyphase kernel is instantiated for (twostage_build rounds its design up to the next one)
 #define HIPSOXR_POLY_TAPS(X) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56)
+__device__ __forceinline__ int64_t floor_div(int64_t q, int64_t d) // d > 0
+{
+    const int64_t n = q / d;
+    return n * d > q ? n - 1 : n;
+}
 template <typename Real> struct Rec4;
 template <> struct Rec4<float> { typedef float4 type; };
 template <> struct Rec4<double> { typedef double4 type; };
 
-template <typename Real, int TT> // TT = taps (compile time: the tap loop unrolls and every LDS read of an output is in flight at once)
+// TT = taps (compile time: the tap loop unrolls and every LDS read of an output is in flight at once).
+// MQ = floor(Ms / Ls) when that is 0 or 1 (every ratio the two-stage form takes but down-sampling beyond 2:1): consecutive
+// outputs' source windows then differ by MQ or MQ + 1 samples, and the thread keeps its window in REGISTERS, shifted by
+// v_cndmask between outputs, with two fresh samples read per output instead of TT — the table records are then the only
+// per-tap LDS traffic.  MQ = -1: the window is re-read from LDS for every output.
+template <typename Real, int TT, int MQ>
 __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
 {
     typedef typename Rec4<Real>::type R4;
@@ -197,22 +212,27 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t kA = a.k_lo + tile * per_tile;
         const int64_t kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
-        // (k < 2^31 and Ms <= 2^31: the products fit 64 bits — launch_two_stage admits no larger job)
-        const int64_t nA = (int64_t)(((uint64_t)kA * (uint64_t)a.Ms) / (uint64_t)a.Ls) - (H - 1);
-        const int64_t nB = (int64_t)(((uint64_t)kB * (uint64_t)a.Ms) / (uint64_t)a.Ls) + H;
+        // (|k| < 2^31 and Ms <= 2^31: the products fit 64 bits — launch_two_stage admits no larger job)
+        const int64_t nA = floor_div(kA * a.Ms, a.Ls) - (H - 1);
+        const int64_t nB = floor_div(kB * a.Ms, a.Ls) + H;
         const int span = (int)(nB - nA + 1);
         __syncthreads(); // (the tile before has been read; first trip: the table is complete behind the barrier below)
         for (int i = tid; i < span; i += 256) {
             const int64_t n = nA + i;
-            xs[i] = (n >= 0 && n < a.n_src) ? src[n * a.sfs] : (Real)0;
+            xs[i] = (n >= a.n_lo && n < a.n_src) ? src[n * a.sfs] : (Real)0;
         }
         __syncthreads();
         const int64_t k1 = kA + (int64_t)tid * a.R;
         if (k1 <= kB) {
-            const uint64_t q = (uint64_t)k1 * (uint64_t)a.Ms;
-            int64_t n = (int64_t)(q / (uint64_t)a.Ls);
-            int64_t rem = (int64_t)(q % (uint64_t)a.Ls);
+            int64_t n = floor_div(k1 * a.Ms, a.Ls);
+            int64_t rem = k1 * a.Ms - n * a.Ls;
             const double invL = 1. / (double)a.Ls;
+            Real u[TT];
+            if constexpr (MQ >= 0) {
+                const Real *w = xs + (n - nA - (H - 1));
+#pragma unroll
+                for (int j = 0; j < TT; ++j) u[j] = w[j];
+            }
             for (int r = 0; r < a.R && k1 + r <= kB; ++r) {
                 const double fP = (double)rem * invL * (double)a.P;
                 int i = (int)fP;
@@ -224,38 +244,51 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
 #pragma unroll
                 for (int j0 = 0; j0 < TT; j0 += CH) {
                     R4 c[CH];
-                    Real u[CH];
+                    Real v[CH];
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) { c[j] = row[j0 + j]; u[j] = w[j0 + j]; }
+                    for (int j = 0; j < CH; ++j) {
+                        c[j] = row[j0 + j];
+                        if constexpr (MQ >= 0) v[j] = u[j0 + j];
+                        else v[j] = w[j0 + j];
+                    }
 #pragma unroll
                     for (int j = 0; j < CH; j += 2) {
-                        acc0 += (((c[j].w * x + c[j].z) * x + c[j].y) * x + c[j].x) * u[j];
-                        acc1 += (((c[j + 1].w * x + c[j + 1].z) * x + c[j + 1].y) * x + c[j + 1].x) * u[j + 1];
+                        acc0 += (((c[j].w * x + c[j].z) * x + c[j].y) * x + c[j].x) * v[j];
+                        acc1 += (((c[j + 1].w * x + c[j + 1].z) * x + c[j + 1].y) * x + c[j + 1].x) * v[j + 1];
                     }
                 }
                 dst[(k1 + r - a.k_lo) * a.dfs] = acc0 + acc1;
                 n += a.Mq; rem += a.Mr;
-                if (rem >= a.Ls) { rem -= a.Ls; ++n; }
+                const bool adv = rem >= a.Ls;
+                if (adv) { rem -= a.Ls; ++n; }
+                if constexpr (MQ >= 0) { // the window moves on by MQ or MQ + 1 samples (the span has 4 spare words behind the last window)
+                    const Real *wn = xs + (n - nA - (H - 1));
+                    const Real e0 = wn[TT - 2], e1 = wn[TT - 1];
+#pragma unroll
+                    for (int j = 0; j < TT - 2; ++j) u[j] = adv ? u[j + MQ + 1] : u[j + MQ];
+                    u[TT - 2] = e0; u[TT - 1] = e1;
+                }
             }
         }
     }
 }
 
 template <typename Real>
-static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, int64_t n_src, int64_t k_lo, int64_t n_out, uint32_t n_clips, uint32_t n_channels,
+static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, int64_t n_lo, int64_t n_src, int64_t k_lo, int64_t n_out, uint32_t n_clips, uint32_t n_channels,
                                const int64_t sstr[3], const int64_t dstr[3], hipStream_t st)
 {
     if (n_out <= 0) return nullptr;
     PolyArgs a;
     a.src = src; a.dst = dst; a.tab = sizeof(Real) == 4 ? ts.tab_f : ts.tab_d;
-    a.T = ts.T2; a.P = ts.P2; a.row = ts.row;
+    const int P = sizeof(Real) == 4 ? ts.P2f : ts.P2;
+    a.T = ts.T2; a.P = P; a.row = ts.row;
     a.Ls = ts.Ls; a.Ms = ts.Ms; a.Mq = ts.Ms / ts.Ls; a.Mr = ts.Ms % ts.Ls;
-    a.n_src = n_src; a.k_lo = k_lo; a.n_out = n_out;
+    a.n_lo = n_lo; a.n_src = n_src; a.k_lo = k_lo; a.n_out = n_out;
     a.scs = sstr[0]; a.sfs = sstr[1]; a.schs = sstr[2]; a.dcs = dstr[0]; a.dfs = dstr[1]; a.dchs = dstr[2];
     a.n_channels = n_channels;
     // outputs per thread: as many as keep the tile's source span within the LDS left beside the table (<= 8)
-    const size_t tab_bytes = (size_t)ts.P2 * ts.row * 4 * sizeof(Real);
-    const size_t lds_cap = (sizeof(Real) == 4 ? 64 : 96) * 1024; // two (float) / one (double) workgroups per CU
+    const size_t tab_bytes = (size_t)P * ts.row * 4 * sizeof(Real);
+    const size_t lds_cap = (sizeof(Real) == 4 ? (tab_bytes > 40 * 1024 ? 78 : 52) : 96) * 1024; // three or two (float) / one (double) workgroups per CU
     const double ratio = (double)ts.Ms / (double)ts.Ls;
     int Rmax = 12;
     while (Rmax > 1 && tab_bytes + (size_t)(256. * Rmax * ratio + ts.T2 + 4) * sizeof(Real) > lds_cap) --Rmax;
@@ -275,7 +308,7 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
                     int cnt[16] = {0}, mx = 0;
                     for (int l = g0; l < g0 + 16; ++l) {
                         const double f = ph / 16. + (double)l * r * step;
-                        const int i = (int)((f - std::floor(f)) * ts.P2) % ts.P2;
+                        const int i = (int)((f - std::floor(f)) * P) % P;
                         mx = std::max(mx, ++cnt[(ts.row * i) & 15]);
                     }
                     cost += mx; // one cycle per group and distinct quad
@@ -293,11 +326,11 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     if (cols > 65535) return "two-stage: too many columns";
     const int64_t n_tiles = (n_out + 256LL * R - 1) / (256LL * R);
     // workgroups walk tiles: the table is loaded once per workgroup, so no more workgroups than the chip holds twice over
-    const int64_t want = std::max<int64_t>(1, 1024 / (int64_t)cols);
+    const int64_t want = std::max<int64_t>(1, 1280 / (int64_t)cols);
     const unsigned gx = (unsigned)std::min<int64_t>(n_tiles, want);
     void (*kern)(PolyArgs) = nullptr;
     switch (ts.T2) {
-#define HIPSOXR_POLY_T(t) case t: kern = k_poly<Real, t>; break;
+#define HIPSOXR_POLY_T(t) case t: kern = a.Mq == 0 ? k_poly<Real, t, 0> : a.Mq == 1 ? k_poly<Real, t, 1> : k_poly<Real, t, -1>; break;
         HIPSOXR_POLY_TAPS(HIPSOXR_POLY_T)
 #undef HIPSOXR_POLY_T
     }
@@ -308,7 +341,7 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     return nullptr;
 }
 
-// Whole-signal float job on an interpolated-phase plan: FFT stage + polyphase stage + exact edges.  *handled = false
+// Whole-signal float job on an interpolated-phase plan: FFT stage + polyphase stage.  *handled = false
 // (nothing launched) when the plan or the job is not one the two-stage form serves: the caller's ordinary path takes it.
 const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool *handled)
 {
@@ -323,16 +356,24 @@ const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool
     const TwoStage &ts = *p->two;
     if (!ts.ok) return nullptr;
     const int64_t n = j.in_frames, n_out = j.out_frames;
-    if (n_out < 8 * ts.edge + 4096 || n >= (1LL << 30) || n_out >= (1LL << 30)) return nullptr;
+    if (n_out < 8192 || n < 8192 || n >= (1LL << 30) || n_out >= (1LL << 30)) return nullptr;
     const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
     if (cols > 65535) return nullptr;
     const size_t es = j.elem == HIPSOXR_F32 ? 4 : 8;
     // the polyphase table and one tile's source span must fit LDS in the job's precision (long stages in float64 do not:
     // the exact engine keeps those)
-    if ((size_t)ts.P2 * ts.row * 4 * es + (size_t)(512. * (double)ts.Ms / (double)ts.Ls + ts.T2 + 4) * es > 150u * 1024u) return nullptr;
+    if ((size_t)(es == 4 ? ts.P2f : ts.P2) * ts.row * 4 * es + (size_t)(512. * (double)ts.Ms / (double)ts.Ls + ts.T2 + 4) * es > 150u * 1024u) return nullptr;
     hipStream_t st = (hipStream_t)stream;
-    // intermediate signal: planar [clip][channel][frames], stream-ordered allocation
-    const int64_t n_mid = ts.up ? 2 * n : 2 * n_out;
+    // The intermediate signal runs PAST both ends of the job, as far as the second stage reads it: `pad` samples of it
+    // before sample 0 and after the last one (a multiple of 8: 16-byte phases of the columns are kept).  The stage that
+    // writes it produces those samples like any others (its own input zero-extended), the stage that reads it sees zeros
+    // beyond them — so the composite is the prototype's response to the zero-extended signal at EVERY output, ends
+    // included, and no third engine patches the ends.
+    //   down: v[m], m in [-pad, 2 n_out + pad): pad >= polyphase half-width in v samples
+    //   up:   u[m], m in [-pad, 2 n + pad):     pad >= polyphase half-width (T2 / 2 u samples)
+    const double half_mid = ts.up ? .5 * ts.T2 : .5 * ts.T2 * (double)ts.Ls / (double)ts.Ms;
+    const int64_t pad = ((int64_t)std::ceil(half_mid) + 4 + 7) / 8 * 8;
+    const int64_t n_core = ts.up ? 2 * n : 2 * n_out, n_mid = n_core + 2 * pad;
     void *mid = nullptr;
     HIP_TRY(hipMallocAsync(&mid, (size_t)cols * (size_t)n_mid * es, st));
     const int64_t mstr[3] = {n_mid * (int64_t)j.n_channels, 1, n_mid};
@@ -344,35 +385,29 @@ const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool
     fj.clip_counter = nullptr; fj.dither = 0;
     bool fft_done = false;
     const char *err = nullptr;
+    void *mid0 = (char *)mid + (size_t)pad * es; // sample 0 of the first column
+    if ((err = device_bank_ensure(&p->two->fft, engine_prec(j.elem)))) return fail(err);
     if (ts.up) {
+        // 1:2 over the input delayed by pad / 2 samples: its output m' is u[m' - pad]
+        fj.in_abs0 = pad / 2;
         fj.out = mid; fj.out_clip_stride = mstr[0]; fj.out_frame_stride = mstr[1]; fj.out_chan_stride = mstr[2];
         fj.in_frames = n; fj.out_frames = n_mid;
-        if ((err = device_bank_ensure(&p->two->fft, engine_prec(j.elem)))) return fail(err);
         if ((err = launch_fft(&p->two->fft, fj, stream, &fft_done))) return fail(err);
         if (!fft_done) { (void)hipFreeAsync(mid, st); return nullptr; }
-        err = j.elem == HIPSOXR_F32 ? launch_poly<float>(ts, mid, j.out, n_mid, 0, n_out, j.n_clips, j.n_channels, mstr, ostr, st)
-                                    : launch_poly<double>(ts, mid, j.out, n_mid, 0, n_out, j.n_clips, j.n_channels, mstr, ostr, st);
+        err = j.elem == HIPSOXR_F32 ? launch_poly<float>(ts, mid0, j.out, -pad, n_core + pad, 0, n_out, j.n_clips, j.n_channels, mstr, ostr, st)
+                                    : launch_poly<double>(ts, mid0, j.out, -pad, n_core + pad, 0, n_out, j.n_clips, j.n_channels, mstr, ostr, st);
         if (err) return fail(err);
     } else {
-        err = j.elem == HIPSOXR_F32 ? launch_poly<float>(ts, j.in, mid, n, 0, n_mid, j.n_clips, j.n_channels, istr, mstr, st)
-                                    : launch_poly<double>(ts, j.in, mid, n, 0, n_mid, j.n_clips, j.n_channels, istr, mstr, st);
+        err = j.elem == HIPSOXR_F32 ? launch_poly<float>(ts, j.in, mid, 0, n, -pad, n_mid, j.n_clips, j.n_channels, istr, mstr, st)
+                                    : launch_poly<double>(ts, j.in, mid, 0, n, -pad, n_mid, j.n_clips, j.n_channels, istr, mstr, st);
         if (err) return fail(err);
-        fj.in = mid; fj.in_clip_stride = mstr[0]; fj.in_frame_stride = mstr[1]; fj.in_chan_stride = mstr[2];
+        fj.in = mid; fj.in_abs0 = -pad; fj.in_clip_stride = mstr[0]; fj.in_frame_stride = mstr[1]; fj.in_chan_stride = mstr[2];
         fj.in_frames = n_mid; fj.out_frames = n_out;
-        if ((err = device_bank_ensure(&p->two->fft, engine_prec(j.elem)))) return fail(err);
         if ((err = launch_fft(&p->two->fft, fj, stream, &fft_done))) return fail(err);
-        if (!fft_done) { (void)hipFreeAsync(mid, st); return nullptr; } // (the ordinary path recomputes everything)
+        if (!fft_done) return fail("two-stage: the frequency-domain engine declined the second stage"); // (the first stage is already queued)
     }
     (void)hipFreeAsync(mid, st);
-    // the outputs whose second-stage support reaches past an end of the intermediate signal: exact engine
-    for (int side = 0; side < 2; ++side) {
-        hipsoxr_job_t ej = j;
-        ej.kernel = HIPSOXR_KERNEL_EXACT;
-        ej.out_k0 = side ? n_out - ts.edge : 0;
-        ej.out_frames = ts.edge;
-        ej.out = (char *)j.out + (size_t)(ej.out_k0 * j.out_frame_stride) * es;
-        if (const char *e = launch_job(p, ej, stream)) return e;
-    }
+    (void)mid0;
     *handled = true;
     return nullptr;
 }

@@ -2,8 +2,8 @@
 polyphase stage in LDS) against the oracle's float64 direct form ON ITS OWN BANK: random integer and float rate pairs in
 the style of the reference's tests/test_random.py:21-25 (seeded here), float32 and float64, mono and interleaved stereo, at
 size (0.4 - 3 M frames), white noise — the composite filter is the plan's own prototype, so no band-limiting is needed.
-Bars: float32 <= 1e-6 relative RMS (the engine's class), float64 <= 2e-9; the first and last outputs (whose second-stage
-support would leave the intermediate signal) come from the exact engine and must EQUAL it."""
+Bars: float32 <= 1e-6 relative RMS (the engine's class), float64 <= 2e-9 — on windows that include the first and the last
+outputs (the intermediate signal runs past both ends of the job: no output is patched by another engine)."""
 import random
 
 import numpy as np
@@ -47,7 +47,9 @@ def test_two_stage_matches_the_oracle_direct_form(oracle, in_rate, out_rate, dty
     if np.array_equal(y, ye):                                 # (a long polyphase table in float64 does not fit LDS: exact engine)
         assert dtype == np.float64 and in_rate / out_rate > 2.5, "AUTO did not take the two-stage form"
         return
-    assert np.array_equal(y[:8], ye[:8]) and np.array_equal(y[-8:], ye[-8:])   # the edges are the exact engine's
+    # the very ends (partial sums over the signal's first / last samples), against the exact engine: absolute, at the scale of the signal
+    for sl in (slice(0, 64), slice(-64, None)):
+        assert np.max(np.abs(y[sl].astype(np.float64) - ye[sl])) <= 8 * tol * 0.25, sl
     pl = oracle.plan(in_rate, out_rate, "VHQ")
     c = ch - 1
     # the oracle's float64 direct form on windows (its cost is 300-700 taps x a cubic per output): head, tail, three inside
