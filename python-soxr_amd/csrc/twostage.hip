@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "device.h"
@@ -43,6 +44,7 @@ struct TwoStage {
     Plan fft;                 // the FFT stage's plan: L/M = 2/1 (up) or 1/2 (down), bank from the owner's prototype
     int32_t T2 = 0, P2 = 0, P2f = 0, row = 0; // polyphase stage: taps, table intervals (float64 / float32 table), records per table row (T2 + 1: bank spreading)
     int64_t Ls = 1, Ms = 1;   // polyphase stage: output k sits at k * Ms / Ls of ITS input samples
+    mutable int sel[2][2] = {{0, 0}, {0, 0}}; // [float32 / float64]: outputs per thread R and lane multiplier of k_poly (launch_poly)
     void *tab_f = nullptr, *tab_d = nullptr; // device: [P2f][row] float4 / [P2][row] double4 records (a0..a3 of the cubic in x in [0, 1))
 };
 
@@ -168,7 +170,9 @@ static const char *twostage_build(Plan *p)
 // ---------------------------------------------------------------------------------------------
 struct PolyArgs {
     const void *src; void *dst; const void *tab;
-    int32_t T, P, row, R, span_max;
+    int32_t T, P, row, R, span_max, lane_mul, lgP;
+    uint64_t step_fx;  // frac(Ms / Ls) in units of 2^-64 (float32 path of k_poly)
+    double fx_per_rem; // 2^64 / Ls
     int64_t Ls, Ms, Mq, Mr; // Ms = Mq * Ls + Mr
     int64_t n_lo, n_src, k_lo, n_out; // the source column holds samples [n_lo, n_src) (src points at sample 0; zero outside); outputs [k_lo, k_lo + n_out), k_lo may be < 0
     int64_t scs, sfs, schs, dcs, dfs, dchs;
@@ -198,6 +202,7 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     R4 *tab = reinterpret_cast<R4 *>(smem);
     Real *xs = reinterpret_cast<Real *>(smem + (size_t)a.P * a.row * sizeof(R4));
+    Real *ys = xs + a.span_max; // the tile's outputs, staged so that they leave as whole lines whatever the lane order
     const uint32_t col = blockIdx.y, ch = col % a.n_channels, clip = col / a.n_channels;
     const Real *src = (const Real *)a.src + (int64_t)clip * a.scs + (int64_t)ch * a.schs;
     Real *dst = (Real *)a.dst + (int64_t)clip * a.dcs + (int64_t)ch * a.dchs;
@@ -216,13 +221,72 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
         const int64_t nA = floor_div(kA * a.Ms, a.Ls) - (H - 1);
         const int64_t nB = floor_div(kB * a.Ms, a.Ls) + H;
         const int span = (int)(nB - nA + 1);
-        __syncthreads(); // (the tile before has been read; first trip: the table is complete behind the barrier below)
         for (int i = tid; i < span; i += 256) {
             const int64_t n = nA + i;
             xs[i] = (n >= a.n_lo && n < a.n_src) ? src[n * a.sfs] : (Real)0;
         }
         __syncthreads();
-        const int64_t k1 = kA + (int64_t)tid * a.R;
+        const int64_t k1 = kA + (int64_t)((tid * a.lane_mul) & 255) * a.R;
+        if constexpr (sizeof(Real) == 4 && MQ >= 0) {
+            // float32, window in registers: the position is a 64-bit binary fraction stepped by frac(Ms / Ls) 2^64 (its
+            // carry moves the window on), the sums over taps are taken per cubic coefficient — S_d = sum_j a_d[j] u[j],
+            // two coefficients per v_pk_fma_f32 straight from the 16-byte record, the sample broadcast by op_sel — and
+            // y = S0 + x (S1 + x (S2 + x S3)): two packed instructions per tap instead of four scalar ones.
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            if (k1 <= kB) {
+                const int64_t n0 = floor_div(k1 * a.Ms, a.Ls);
+                const int64_t rem = k1 * a.Ms - n0 * a.Ls;
+                uint64_t phase = (uint64_t)((double)rem * a.fx_per_rem); // rem / Ls in units of 2^-64
+                const float *w = xs + (n0 - nA - (H - 1));
+                v2f u[TT / 2];
+#pragma unroll
+                for (int j = 0; j < TT / 2; ++j) { u[j].x = w[2 * j]; u[j].y = w[2 * j + 1]; }
+                const float *wtop = w + (TT - 2);
+                const v4f *tabv = reinterpret_cast<const v4f *>(tab);
+                float *yo = ys + (k1 - kA);
+                const int lg = a.lgP;
+                int left = (int)(kB - k1 + 1 < (int64_t)a.R ? kB - k1 + 1 : (int64_t)a.R);
+                for (; left > 0; --left) {
+                    const uint32_t hi = (uint32_t)(phase >> 32);
+                    const uint32_t i = hi >> (32 - lg);
+                    const float x = (float)(uint32_t)(hi << lg) * 0x1p-32f;
+                    const v4f *row = tabv + i * (uint32_t)a.row;
+                    v2f s01e = {0.f, 0.f}, s23e = {0.f, 0.f}, s01o = {0.f, 0.f}, s23o = {0.f, 0.f};
+#pragma unroll
+                    for (int j0 = 0; j0 < TT; j0 += CH) {
+                        v4f c[CH];
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) c[j] = row[j0 + j];
+#pragma unroll
+                        for (int j = 0; j < CH; j += 2) {
+                            const v2f a01 = __builtin_shufflevector(c[j], c[j], 0, 1), a23 = __builtin_shufflevector(c[j], c[j], 2, 3);
+                            const v2f b01 = __builtin_shufflevector(c[j + 1], c[j + 1], 0, 1), b23 = __builtin_shufflevector(c[j + 1], c[j + 1], 2, 3);
+                            const v2f up = u[(j0 + j) / 2];
+                            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(s01e) : "v"(a01), "v"(up), "v"(s01e));
+                            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(s23e) : "v"(a23), "v"(up), "v"(s23e));
+                            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(s01o) : "v"(b01), "v"(up), "v"(s01o));
+                            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(s23o) : "v"(b23), "v"(up), "v"(s23o));
+                        }
+                    }
+                    const float S0 = s01e.x + s01o.x, S1 = s01e.y + s01o.y, S2 = s23e.x + s23o.x, S3 = s23e.y + s23o.y;
+                    *yo++ = ((S3 * x + S2) * x + S1) * x + S0;
+                    const uint64_t next = phase + a.step_fx;
+                    const bool adv = next < phase; // the fraction wrapped: one more sample
+                    phase = next;
+                    wtop += MQ + (adv ? 1 : 0);
+                    const float e0 = wtop[0], e1 = wtop[1]; // (the span has 4 spare words behind the last window)
+                    float f[TT];
+#pragma unroll
+                    for (int j = 0; j < TT / 2; ++j) { f[2 * j] = u[j].x; f[2 * j + 1] = u[j].y; }
+#pragma unroll
+                    for (int j = 0; j < TT - 2; ++j) f[j] = adv ? f[j + MQ + 1] : f[j + MQ];
+                    f[TT - 2] = e0; f[TT - 1] = e1;
+#pragma unroll
+                    for (int j = 0; j < TT / 2; ++j) { u[j].x = f[2 * j]; u[j].y = f[2 * j + 1]; }
+                }
+            }
+        } else
         if (k1 <= kB) {
             int64_t n = floor_div(k1 * a.Ms, a.Ls);
             int64_t rem = k1 * a.Ms - n * a.Ls;
@@ -257,7 +321,7 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
                         acc1 += (((c[j + 1].w * x + c[j + 1].z) * x + c[j + 1].y) * x + c[j + 1].x) * v[j + 1];
                     }
                 }
-                dst[(k1 + r - a.k_lo) * a.dfs] = acc0 + acc1;
+                ys[k1 - kA + r] = acc0 + acc1;
                 n += a.Mq; rem += a.Mr;
                 const bool adv = rem >= a.Ls;
                 if (adv) { rem -= a.Ls; ++n; }
@@ -269,6 +333,12 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
                     u[TT - 2] = e0; u[TT - 1] = e1;
                 }
             }
+        }
+        __syncthreads(); // the tile's outputs are staged (and its source span is free for the next tile)
+        {
+            Real *yo = dst + (kA - a.k_lo) * a.dfs;
+            const int cnt = (int)(kB - kA + 1);
+            for (int i = tid; i < cnt; i += 256) yo[(int64_t)i * a.dfs] = ys[i];
         }
     }
 }
@@ -284,6 +354,10 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     a.T = ts.T2; a.P = P; a.row = ts.row;
     a.Ls = ts.Ls; a.Ms = ts.Ms; a.Mq = ts.Ms / ts.Ls; a.Mr = ts.Ms % ts.Ls;
     a.n_lo = n_lo; a.n_src = n_src; a.k_lo = k_lo; a.n_out = n_out;
+    a.lgP = 0;
+    while ((1 << a.lgP) < P) ++a.lgP;
+    a.step_fx = (uint64_t)((((unsigned __int128)(uint64_t)a.Mr) << 64) / (unsigned __int128)(uint64_t)a.Ls);
+    a.fx_per_rem = 18446744073709551616. / (double)a.Ls;
     a.scs = sstr[0]; a.sfs = sstr[1]; a.schs = sstr[2]; a.dcs = dstr[0]; a.dfs = dstr[1]; a.dchs = dstr[2];
     a.n_channels = n_channels;
     // outputs per thread: as many as keep the tile's source span within the LDS left beside the table (<= 8)
@@ -291,36 +365,52 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     const size_t lds_cap = (sizeof(Real) == 4 ? (tab_bytes > 40 * 1024 ? 78 : 52) : 96) * 1024; // three or two (float) / one (double) workgroups per CU
     const double ratio = (double)ts.Ms / (double)ts.Ls;
     int Rmax = 12;
-    while (Rmax > 1 && tab_bytes + (size_t)(256. * Rmax * ratio + ts.T2 + 4) * sizeof(Real) > lds_cap) --Rmax;
-    // Lanes of a wave own outputs R apart: their source windows start R Ms / Ls samples apart and their table intervals form
-    // an arithmetic progression of step frac(R Ms / Ls) P.  A 4-byte LDS read serves 32 lanes per cycle when they fall on
-    // 32 different banks (word address mod 32), a 16-byte read 16 lanes when their rows fall on 16 different bank quads
-    // ((row stride * interval) mod 16).  R = 8 at 48000 -> 44101 puts the windows 4.35 words apart — four lanes per bank.
-    // Pick the R whose two progressions collide least (simulated for a few starting phases).
-    int R = Rmax;
+    while (Rmax > 1 && tab_bytes + (size_t)(256. * Rmax * (ratio + 1.) + ts.T2 + 4) * sizeof(Real) > lds_cap) --Rmax; // (source span + staged outputs)
+    // Thread t owns R consecutive outputs starting ((t * lane_mul) mod 256) * R into the tile (lane_mul odd: a bijection).
+    // Lanes l, l + 1 of a wave are then lane_mul * R outputs apart and their table rows form the arithmetic progression
+    // floor(c + l s), s = frac(lane_mul R Ms / Ls) P.  A 16-byte LDS read serves a lane group in one cycle when its 16 lanes
+    // fall on 16 different bank quads — (row + tap) mod 16 with the table's odd row stride — and takes one more cycle per
+    // extra distinct record on a quad.  Random rows cost 2.5-3 cycles; s within ~0.02 of an odd integer costs 1.
+    // (R, lane_mul) is picked by simulating the four lane groups of the four waves over 16 starting phases.
+    int R = Rmax, lane_mul = 1;
     {
-        double best = 1e30;
-        const double step = (double)ts.Ms / (double)ts.Ls;
-        for (int r = std::max(2, Rmax / 3); r <= Rmax; ++r) {
-            double cost = 0.;
-            for (int ph = 0; ph < 16; ++ph) {
-                for (int g0 = 0; g0 < 64; g0 += 16) { // table records: groups of 16 lanes, 16 bank quads
-                    int cnt[16] = {0}, mx = 0;
-                    for (int l = g0; l < g0 + 16; ++l) {
-                        const double f = ph / 16. + (double)l * r * step;
-                        const int i = (int)((f - std::floor(f)) * P) % P;
-                        mx = std::max(mx, ++cnt[(ts.row * i) & 15]);
-                    }
-                    cost += mx; // one cycle per group and distinct quad
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        int *sel = ts.sel[sizeof(Real) == 8];
+        if (!sel[0]) {
+            static const int group[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                             {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+            const int halves = sizeof(Real) == 8 ? 2 : 1; // a double4 record is two 16-byte reads
+            double best = 1e30;
+            sel[0] = Rmax; sel[1] = 1;
+            for (int r = std::min(Rmax, std::max(2, Rmax / 3)); r <= Rmax; ++r)
+                for (int am = 1; am < 256; am += 2) {
+                    double cost = 0.;
+                    for (int ph = 0; ph < 16 && cost < best; ++ph)
+                        for (int wave = 0; wave < 4; ++wave)
+                            for (int g = 0; g < 4; ++g) {
+                                int rows[16][16], cnt[16] = {0}, mx = 1; // distinct rows seen per quad
+                                for (int q = 0; q < 16; ++q) {
+                                    const int tid = 64 * wave + group[g][q];
+                                    const double f = ph / 16. + .37 + (double)((tid * am) & 255) * r * ratio;
+                                    const int i = (int)((f - std::floor(f)) * P) % P;
+                                    const int quad = (halves * ts.row * i) & 15;
+                                    bool seen = false;
+                                    for (int z = 0; z < cnt[quad]; ++z) seen |= rows[quad][z] == i;
+                                    if (!seen) { rows[quad][cnt[quad]++] = i; mx = std::max(mx, cnt[quad]); }
+                                }
+                                cost += mx;
+                            }
+                    cost *= 1. + .02 * (Rmax - r); // (a shorter run per thread: more position divisions and tiles per output)
+                    if (cost < best) { best = cost; sel[0] = r; sel[1] = am; }
                 }
-            }
-            cost *= 1. + .02 * (Rmax - r); // (a shorter run per thread: more position divisions and tiles per output)
-            if (cost < best) { best = cost; R = r; }
         }
+        R = std::min(sel[0], Rmax); lane_mul = sel[1];
     }
+    a.lane_mul = lane_mul;
     a.R = R;
     a.span_max = (int)(256. * R * ratio + ts.T2 + 4);
-    const size_t lds = tab_bytes + (size_t)a.span_max * sizeof(Real);
+    const size_t lds = tab_bytes + ((size_t)a.span_max + 256u * (size_t)R) * sizeof(Real);
     if (lds > 160 * 1024) return "two-stage: polyphase tile does not fit LDS";
     const uint64_t cols = (uint64_t)n_clips * n_channels;
     if (cols > 65535) return "two-stage: too many columns";
@@ -362,7 +452,7 @@ const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool
     const size_t es = j.elem == HIPSOXR_F32 ? 4 : 8;
     // the polyphase table and one tile's source span must fit LDS in the job's precision (long stages in float64 do not:
     // the exact engine keeps those)
-    if ((size_t)(es == 4 ? ts.P2f : ts.P2) * ts.row * 4 * es + (size_t)(512. * (double)ts.Ms / (double)ts.Ls + ts.T2 + 4) * es > 150u * 1024u) return nullptr;
+    if ((size_t)(es == 4 ? ts.P2f : ts.P2) * ts.row * 4 * es + (size_t)(512. * ((double)ts.Ms / (double)ts.Ls + 1.) + ts.T2 + 4) * es > 150u * 1024u) return nullptr;
     hipStream_t st = (hipStream_t)stream;
     // The intermediate signal runs PAST both ends of the job, as far as the second stage reads it: `pad` samples of it
     // before sample 0 and after the last one (a multiple of 8: 16-byte phases of the columns are kept).  The stage that
