@@ -171,6 +171,7 @@ static const char *twostage_build(Plan *p)
 struct PolyArgs {
     const void *src; void *dst; const void *tab;
     int32_t T, P, row, R, span_max, lane_mul, lgP;
+    unsigned long long *trace; // -DPOLY_TRACE builds: per-wave cycle sums [workgroup][wave][8]
     uint64_t step_fx;  // frac(Ms / Ls) in units of 2^-64 (float32 path of k_poly)
     double fx_per_rem; // 2^64 / Ls
     int64_t Ls, Ms, Mq, Mr; // Ms = Mq * Ls + Mr
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     R4 *tab = reinterpret_cast<R4 *>(smem);
     Real *xs = reinterpret_cast<Real *>(smem + (size_t)a.P * a.row * sizeof(R4));
-    Real *ys = xs + a.span_max; // the tile's outputs, staged so that they leave as whole lines whatever the lane order
+    Real *ys = xs + a.span_max; // the tile's outputs, staged [R][257] so that they leave as whole lines whatever the lane order
     const uint32_t col = blockIdx.y, ch = col % a.n_channels, clip = col / a.n_channels;
     const Real *src = (const Real *)a.src + (int64_t)clip * a.scs + (int64_t)ch * a.schs;
     Real *dst = (Real *)a.dst + (int64_t)clip * a.dcs + (int64_t)ch * a.dchs;
@@ -214,19 +215,49 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
     const int64_t per_tile = 256LL * a.R, n_tiles = (a.n_out + per_tile - 1) / per_tile;
     constexpr int H = TT / 2;
     constexpr int CH = TT % 16 == 0 ? 16 : TT % 12 == 0 ? 12 : TT % 8 == 0 ? 8 : 4; // taps whose LDS reads are in flight together
+#ifdef POLY_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime();
+    const unsigned long long tq0 = tq;
+#define POLY_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr[i] += t_ - tq; tq = t_; } while (0)
+#else
+#define POLY_STAMP(i) ((void)0)
+#endif
+    constexpr bool FAST = sizeof(Real) == 4 && MQ >= 0;
+    // float32 path: output k sits at k_lo's exact position (one 64-bit division per thread and launch) plus (k - k_lo) steps of
+    // Ms / Ls as a 64.64 binary fraction (step_fx is truncated: at most 2^-33 of a sample short after 2^31 outputs); the tile's
+    // span and every thread's window come from the same arithmetic
+    int64_t nK0 = 0;
+    uint64_t phK0 = 0;
+    if constexpr (FAST) {
+        nK0 = floor_div(a.k_lo * a.Ms, a.Ls);
+        phK0 = (uint64_t)((double)(a.k_lo * a.Ms - nK0 * a.Ls) * a.fx_per_rem); // remainder / Ls in units of 2^-64
+    }
+    auto position = [&](int64_t k, uint64_t &ph) -> int64_t {
+        const uint64_t dk = (uint64_t)(k - a.k_lo), lo = dk * a.step_fx;
+        ph = phK0 + lo;
+        return nK0 + (int64_t)dk * a.Mq + (int64_t)__umul64hi(dk, a.step_fx) + (ph < lo ? 1 : 0);
+    };
+    const int slot = (tid * a.lane_mul) & 255; // this thread's run of R outputs within a tile
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t kA = a.k_lo + tile * per_tile;
         const int64_t kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
         // (|k| < 2^31 and Ms <= 2^31: the products fit 64 bits — launch_two_stage admits no larger job)
-        const int64_t nA = floor_div(kA * a.Ms, a.Ls) - (H - 1);
-        const int64_t nB = floor_div(kB * a.Ms, a.Ls) + H;
+        int64_t nA, nB;
+        if constexpr (FAST) {
+            uint64_t ph;
+            nA = position(kA, ph) - (H - 1); nB = position(kB, ph) + H;
+        } else {
+            nA = floor_div(kA * a.Ms, a.Ls) - (H - 1); nB = floor_div(kB * a.Ms, a.Ls) + H;
+        }
         const int span = (int)(nB - nA + 1);
         for (int i = tid; i < span; i += 256) {
             const int64_t n = nA + i;
             xs[i] = (n >= a.n_lo && n < a.n_src) ? src[n * a.sfs] : (Real)0;
         }
+        POLY_STAMP(0); // span staged (loads issued and written)
         __syncthreads();
-        const int64_t k1 = kA + (int64_t)((tid * a.lane_mul) & 255) * a.R;
+        POLY_STAMP(1); // barrier
+        const int64_t k1 = kA + (int64_t)slot * a.R;
         if constexpr (sizeof(Real) == 4 && MQ >= 0) {
             // float32, window in registers: the position is a 64-bit binary fraction stepped by frac(Ms / Ls) 2^64 (its
             // carry moves the window on), the sums over taps are taken per cubic coefficient — S_d = sum_j a_d[j] u[j],
@@ -235,16 +266,15 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
             typedef float v2f __attribute__((ext_vector_type(2)));
             typedef float v4f __attribute__((ext_vector_type(4)));
             if (k1 <= kB) {
-                const int64_t n0 = floor_div(k1 * a.Ms, a.Ls);
-                const int64_t rem = k1 * a.Ms - n0 * a.Ls;
-                uint64_t phase = (uint64_t)((double)rem * a.fx_per_rem); // rem / Ls in units of 2^-64
+                uint64_t phase;
+                const int64_t n0 = position(k1, phase);
                 const float *w = xs + (n0 - nA - (H - 1));
                 v2f u[TT / 2];
 #pragma unroll
                 for (int j = 0; j < TT / 2; ++j) { u[j].x = w[2 * j]; u[j].y = w[2 * j + 1]; }
                 const float *wtop = w + (TT - 2);
                 const v4f *tabv = reinterpret_cast<const v4f *>(tab);
-                float *yo = ys + (k1 - kA);
+                float *yo = ys + slot; // staged [run index][slot] with rows of 257: conflict-free writes
                 const int lg = a.lgP;
                 int left = (int)(kB - k1 + 1 < (int64_t)a.R ? kB - k1 + 1 : (int64_t)a.R);
                 for (; left > 0; --left) {
@@ -270,7 +300,8 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
                         }
                     }
                     const float S0 = s01e.x + s01o.x, S1 = s01e.y + s01o.y, S2 = s23e.x + s23o.x, S3 = s23e.y + s23o.y;
-                    *yo++ = ((S3 * x + S2) * x + S1) * x + S0;
+                    *yo = ((S3 * x + S2) * x + S1) * x + S0;
+                    yo += 257;
                     const uint64_t next = phase + a.step_fx;
                     const bool adv = next < phase; // the fraction wrapped: one more sample
                     phase = next;
@@ -321,7 +352,7 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
                         acc1 += (((c[j + 1].w * x + c[j + 1].z) * x + c[j + 1].y) * x + c[j + 1].x) * v[j + 1];
                     }
                 }
-                ys[k1 - kA + r] = acc0 + acc1;
+                ys[r * 257 + slot] = acc0 + acc1;
                 n += a.Mq; rem += a.Mr;
                 const bool adv = rem >= a.Ls;
                 if (adv) { rem -= a.Ls; ++n; }
@@ -334,13 +365,27 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
                 }
             }
         }
+        POLY_STAMP(2); // outputs computed
         __syncthreads(); // the tile's outputs are staged (and its source span is free for the next tile)
+        POLY_STAMP(3); // barrier
         {
             Real *yo = dst + (kA - a.k_lo) * a.dfs;
             const int cnt = (int)(kB - kA + 1);
-            for (int i = tid; i < cnt; i += 256) yo[(int64_t)i * a.dfs] = ys[i];
+            const float invR = 1.f / (float)a.R;
+            for (int i = tid; i < cnt; i += 256) {
+                const int sl = (int)(((float)i + .5f) * invR), r = i - sl * a.R; // output i of the tile: run index r of slot sl
+                yo[(int64_t)i * a.dfs] = ys[r * 257 + sl];
+            }
         }
+        POLY_STAMP(4); // outputs stored
     }
+#ifdef POLY_TRACE
+    if (a.trace && (tid & 63) == 0) {
+        unsigned long long *o = a.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid / 64) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = tr[i];
+        o[5] = tq0; o[6] = tq; o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); // HW_ID, XCC_ID
+    }
+#endif
 }
 
 template <typename Real>
@@ -365,7 +410,7 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     const size_t lds_cap = (sizeof(Real) == 4 ? (tab_bytes > 40 * 1024 ? 78 : 52) : 96) * 1024; // three or two (float) / one (double) workgroups per CU
     const double ratio = (double)ts.Ms / (double)ts.Ls;
     int Rmax = 12;
-    while (Rmax > 1 && tab_bytes + (size_t)(256. * Rmax * (ratio + 1.) + ts.T2 + 4) * sizeof(Real) > lds_cap) --Rmax; // (source span + staged outputs)
+    while (Rmax > 1 && tab_bytes + (size_t)(256. * Rmax * ratio + 257. * Rmax + ts.T2 + 4) * sizeof(Real) > lds_cap) --Rmax; // (source span + staged outputs)
     // Thread t owns R consecutive outputs starting ((t * lane_mul) mod 256) * R into the tile (lane_mul odd: a bijection).
     // Lanes l, l + 1 of a wave are then lane_mul * R outputs apart and their table rows form the arithmetic progression
     // floor(c + l s), s = frac(lane_mul R Ms / Ls) P.  A 16-byte LDS read serves a lane group in one cycle when its 16 lanes
@@ -410,14 +455,11 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     a.lane_mul = lane_mul;
     a.R = R;
     a.span_max = (int)(256. * R * ratio + ts.T2 + 4);
-    const size_t lds = tab_bytes + ((size_t)a.span_max + 256u * (size_t)R) * sizeof(Real);
+    const size_t lds = tab_bytes + ((size_t)a.span_max + 257u * (size_t)R) * sizeof(Real);
     if (lds > 160 * 1024) return "two-stage: polyphase tile does not fit LDS";
     const uint64_t cols = (uint64_t)n_clips * n_channels;
     if (cols > 65535) return "two-stage: too many columns";
     const int64_t n_tiles = (n_out + 256LL * R - 1) / (256LL * R);
-    // workgroups walk tiles: the table is loaded once per workgroup, so no more workgroups than the chip holds twice over
-    const int64_t want = std::max<int64_t>(1, 1280 / (int64_t)cols);
-    const unsigned gx = (unsigned)std::min<int64_t>(n_tiles, want);
     void (*kern)(PolyArgs) = nullptr;
     switch (ts.T2) {
 #define HIPSOXR_POLY_T(t) case t: kern = a.Mq == 0 ? k_poly<Real, t, 0> : a.Mq == 1 ? k_poly<Real, t, 1> : k_poly<Real, t, -1>; break;
@@ -426,8 +468,33 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     }
     if (!kern) return "two-stage: no polyphase instance for this tap count";
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // workgroups walk tiles (the table is loaded once per workgroup): exactly as many as the chip holds at once — a
+    // partly filled second round of workgroups would double the launch
+    int per_cu = 0, dev = 0, n_cu = 256;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 256, lds));
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t want = std::max<int64_t>(1, (int64_t)std::max(per_cu, 1) * n_cu / (int64_t)cols);
+    const unsigned gx = (unsigned)std::min<int64_t>(n_tiles, want);
+    a.trace = nullptr;
+#ifdef POLY_TRACE
+    const size_t trace_n = (size_t)gx * cols * 4 * 8;
+    if (switches().dbg_trace) {
+        HIP_TRY(hipMalloc((void **)&a.trace, trace_n * 8));
+        HIP_TRY(hipMemset(a.trace, 0, trace_n * 8));
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(gx, (unsigned)cols, 1), dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
+#ifdef POLY_TRACE
+    if (a.trace) { // debugging aid only: synchronous dump of the per-wave cycle sums
+        std::vector<unsigned long long> h(trace_n);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h.data(), a.trace, trace_n * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(switches().dbg_trace, "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
+        (void)hipFree(a.trace);
+    }
+#endif
     return nullptr;
 }
 
@@ -452,7 +519,7 @@ const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool
     const size_t es = j.elem == HIPSOXR_F32 ? 4 : 8;
     // the polyphase table and one tile's source span must fit LDS in the job's precision (long stages in float64 do not:
     // the exact engine keeps those)
-    if ((size_t)(es == 4 ? ts.P2f : ts.P2) * ts.row * 4 * es + (size_t)(512. * ((double)ts.Ms / (double)ts.Ls + 1.) + ts.T2 + 4) * es > 150u * 1024u) return nullptr;
+    if ((size_t)(es == 4 ? ts.P2f : ts.P2) * ts.row * 4 * es + (size_t)(512. * ((double)ts.Ms / (double)ts.Ls + 1.01) + ts.T2 + 4) * es > 150u * 1024u) return nullptr;
     hipStream_t st = (hipStream_t)stream;
     // The intermediate signal runs PAST both ends of the job, as far as the second stage reads it: `pad` samples of it
     // before sample 0 and after the last one (a multiple of 8: 16-byte phases of the columns are kept).  The stage that
