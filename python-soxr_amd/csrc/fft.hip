@@ -58,17 +58,44 @@ namespace hipsoxr {
 typedef float2 cf;
 typedef double2 cd;
 template <typename C> using real_of = decltype(C().x);
-#ifdef FFT_PK_ADD // experiment: complex add / subtract as one packed instruction (v_pk_add_f32) through native vector types
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return __builtin_bit_cast(float2, __builtin_bit_cast(v2f_t, a) + __builtin_bit_cast(v2f_t, b)); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return __builtin_bit_cast(float2, __builtin_bit_cast(v2f_t, a) - __builtin_bit_cast(v2f_t, b)); }
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return double2(a.x - b.x, a.y - b.y); }
-#else
 template <typename C> __device__ __forceinline__ C cadd(C a, C b) { return C(a.x + b.x, a.y + b.y); }
 template <typename C> __device__ __forceinline__ C csub(C a, C b) { return C(a.x - b.x, a.y - b.y); }
-#endif
 template <typename C> __device__ __forceinline__ C cmul(C a, C b) { return C(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <typename C> __device__ __forceinline__ C cmulk(C a, C k) { return C(a.x * k.x - a.y * k.y, a.x * k.y + a.y * k.x); } // k: a compile-time constant (literal operands)
+// a + SIGN i b,  a - SIGN i b
+template <int SIGN, typename C> __device__ __forceinline__ C cadd_i(C a, C b) { return SIGN > 0 ? C(a.x - b.y, a.y + b.x) : C(a.x + b.y, a.y - b.x); }
+template <int SIGN, typename C> __device__ __forceinline__ C csub_i(C a, C b) { return cadd_i<-SIGN>(a, b); }
+#ifdef FFT_PK // experiment: float32 complex arithmetic on the packed instructions, one (re, im) register pair per operand
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+#define FFT_V2(x) __builtin_bit_cast(v2f_t, x)
+__device__ __forceinline__ float2 cadd(float2 a, float2 b)
+{
+    v2f_t d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b)));
+    return __builtin_bit_cast(float2, d);
+}
+__device__ __forceinline__ float2 csub(float2 a, float2 b)
+{
+    v2f_t d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b)));
+    return __builtin_bit_cast(float2, d);
+}
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    v2f_t t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(FFT_V2(a)), "v"(FFT_V2(b)));                                     // (a.x b.x, a.y b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b)), "v"(t)); // (-a.y b.y + t.x, a.x b.y + t.y)
+    return __builtin_bit_cast(float2, d);
+}
+template <int SIGN> __device__ __forceinline__ float2 cadd_i(float2 a, float2 b)
+{
+    v2f_t d;
+    if (SIGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b))); // (a.x - b.y, a.y + b.x)
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b)));          // (a.x + b.y, a.y - b.x)
+    return __builtin_bit_cast(float2, d);
+}
+template <int SIGN> __device__ __forceinline__ float2 csub_i(float2 a, float2 b) { return cadd_i<-SIGN>(a, b); }
+#endif
 template <typename C> __device__ __forceinline__ C cconj(C a) { return C(a.x, -a.y); }
 // multiply by SIGN * i
 template <int SIGN, typename C> __device__ __forceinline__ C cmuli(C a)
@@ -82,8 +109,8 @@ template <int SIGN, typename C> __device__ __forceinline__ void dft2(C &a, C &b)
 }
 template <int SIGN, typename C> __device__ __forceinline__ void dft4(C &a0, C &a1, C &a2, C &a3)
 {
-    C s0 = cadd(a0, a2), d0 = csub(a0, a2), s1 = cadd(a1, a3), d1 = cmuli<SIGN>(csub(a1, a3));
-    a0 = cadd(s0, s1); a2 = csub(s0, s1); a1 = cadd(d0, d1); a3 = csub(d0, d1);
+    C s0 = cadd(a0, a2), d0 = csub(a0, a2), s1 = cadd(a1, a3), d1 = csub(a1, a3);
+    a0 = cadd(s0, s1); a2 = csub(s0, s1); a1 = cadd_i<SIGN>(d0, d1); a3 = csub_i<SIGN>(d0, d1);
 }
 template <int SIGN, typename C> __device__ __forceinline__ void dft8(C *u)
 {
@@ -95,11 +122,10 @@ template <int SIGN, typename C> __device__ __forceinline__ void dft8(C *u)
     dft4<SIGN>(o0, o1, o2, o3);
     // twiddles w8^m, m = 0..3 : 1, (1 + SIGN i)/sqrt2, SIGN i, (-1 + SIGN i)/sqrt2
     C t1 = C(h * (o1.x - sg * o1.y), h * (o1.y + sg * o1.x));
-    C t2 = cmuli<SIGN>(o2);
     C t3 = C(h * (-o3.x - sg * o3.y), h * (-o3.y + sg * o3.x));
     u[0] = cadd(e0, o0); u[4] = csub(e0, o0);
     u[1] = cadd(e1, t1); u[5] = csub(e1, t1);
-    u[2] = cadd(e2, t2); u[6] = csub(e2, t2);
+    u[2] = cadd_i<SIGN>(e2, o2); u[6] = csub_i<SIGN>(e2, o2);
     u[3] = cadd(e3, t3); u[7] = csub(e3, t3);
 }
 template <int SIGN, typename C> __device__ __forceinline__ void dft16(C *u)
@@ -117,9 +143,9 @@ template <int SIGN, typename C> __device__ __forceinline__ void dft16(C *u)
     // twiddle x[a][b] *= w16^(a*b), w16 = exp(SIGN * 2 pi i / 16)
     const C w1 = C(c1, sg * s1), w2 = C(h, sg * h), w3 = C(s1, sg * c1);
     const C w4 = C((T)0, sg), w6 = C(-h, sg * h), w9 = C(-c1, -sg * s1);
-    x[1][1] = cmul(x[1][1], w1); x[1][2] = cmul(x[1][2], w2); x[1][3] = cmul(x[1][3], w3);
-    x[2][1] = cmul(x[2][1], w2); x[2][2] = cmul(x[2][2], w4); x[2][3] = cmul(x[2][3], w6);
-    x[3][1] = cmul(x[3][1], w3); x[3][2] = cmul(x[3][2], w6); x[3][3] = cmul(x[3][3], w9);
+    x[1][1] = cmulk(x[1][1], w1); x[1][2] = cmulk(x[1][2], w2); x[1][3] = cmulk(x[1][3], w3);
+    x[2][1] = cmulk(x[2][1], w2); x[2][2] = cmulk(x[2][2], w4); x[2][3] = cmulk(x[2][3], w6);
+    x[3][1] = cmulk(x[3][1], w3); x[3][2] = cmulk(x[3][2], w6); x[3][3] = cmulk(x[3][3], w9);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         C v0 = x[0][b], v1 = x[1][b], v2 = x[2][b], v3 = x[3][b];
@@ -152,9 +178,8 @@ template <int R, int SIGN, typename C> __device__ __forceinline__ void dft_odd(C
             A.x += c * s[t - 1].x; A.y += c * s[t - 1].y;
             B.x += sn * d[t - 1].x; B.y += sn * d[t - 1].y;
         }
-        C iB = cmuli<SIGN>(B); // SIGN*i*B
-        out[m] = cadd(A, iB);
-        out[R - m] = csub(A, iB);
+        out[m] = cadd_i<SIGN>(A, B);     // A + SIGN i B
+        out[R - m] = csub_i<SIGN>(A, B);
     }
 #pragma unroll
     for (int m = 0; m < R; ++m) u[m] = out[m];
