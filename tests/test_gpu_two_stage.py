@@ -88,3 +88,40 @@ def test_two_stage_batches_and_layouts(oracle):
         d = (y.double() - ye.double())
         rel = (d.pow(2).mean(dim=1).sqrt() / ye.double().pow(2).mean(dim=1).sqrt()).max().item()
         assert 0 < rel <= 1e-6, rel
+
+
+def _edge_pairs():
+    r = random.Random(77)
+    fixed = [(48000, 48001), (48001, 48000), (44100, 44100.5), (8000, 31999), (8000, 32001), (96000, 24001), (96000, 23999.5),
+             (48000, 95999), (48000, 96001), (44100, 22051), (44100, 22049), (11025, 44101), (32000, 12345.678), (12345.678, 32000),
+             (44100, 48000.01), (48000.01, 44100), (22050, 88201.5), (50000, 20001), (16000, 16001), (37800, 44056.5)]
+    rnd = []
+    while len(rnd) < 28:
+        a, b = r.uniform(8000, 96000), r.uniform(8000, 96000)
+        if 0.26 < b / a < 12:
+            rnd.append((a, b) if len(rnd) % 3 else (int(a), int(b) | 1))
+    return fixed + rnd
+
+
+@pytest.mark.parametrize("quality", ["VHQ", "HQ"])
+def test_two_stage_over_many_ratios(quality):
+    """48 rate pairs — ratios a hair off 1, 1/2, 2, 4, 1/4, float rates, near-coprime integers — stereo float32, 0.3 M frames:
+    AUTO (two-stage wherever the plan is interpolated) within 1e-6 relative RMS of the canonical-order engine on every pair,
+    the first and last 256 outputs included at the same absolute scale."""
+    import torch
+    from soxr_amd import device as dev
+    g = torch.Generator(device="cuda"); g.manual_seed(31)
+    x = torch.randn((300000, 2), device="cuda", generator=g) * 0.25
+    worst = 0.0
+    for a, b in _edge_pairs():
+        plan = dev.Plan(a, b, quality)
+        y = dev.resample_tensor(plan, x)
+        ye = dev.resample_tensor(plan, x, kernel=dev.KERNEL_EXACT)
+        assert y.shape == ye.shape, (a, b)
+        d = (y.double() - ye.double())
+        scale = float(ye.double().pow(2).mean().sqrt())
+        rel = float(d.pow(2).mean().sqrt()) / scale
+        ends = max(float(d[:256].abs().max()), float(d[-256:].abs().max())) / scale
+        assert rel <= 1e-6 and ends <= 8e-6, (a, b, quality, plan.phases, rel, ends)
+        worst = max(worst, rel)
+    assert worst > 0        # (at least one pair took the two-stage form)
