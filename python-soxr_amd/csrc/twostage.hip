@@ -428,8 +428,9 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
             const int halves = sizeof(Real) == 8 ? 2 : 1; // a double4 record is two 16-byte reads
             double best = 1e30;
             sel[0] = Rmax; sel[1] = 1;
-            for (int r = std::min(Rmax, std::max(2, Rmax / 3)); r <= Rmax; ++r)
-                for (int am = 1; am < 256; am += 2) {
+            bool ideal = false; // (every group in one cycle: nothing better to look for — the usual outcome, a few ms of host time once per plan)
+            for (int r = Rmax; r >= std::min(Rmax, std::max(2, Rmax / 3)) && !ideal; --r)
+                for (int am = 1; am < 256 && !ideal; am += 2) {
                     double cost = 0.;
                     for (int ph = 0; ph < 16 && cost < best; ++ph)
                         for (int wave = 0; wave < 4; ++wave)
@@ -446,7 +447,8 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
                                 }
                                 cost += mx;
                             }
-                    cost *= 1. + .02 * (Rmax - r); // (a shorter run per thread: more position divisions and tiles per output)
+                    ideal = cost == 16. * 16. * halves;
+                    cost *= 1. + .02 * (Rmax - r); // (a shorter run per thread: more tiles per output)
                     if (cost < best) { best = cost; sel[0] = r; sel[1] = am; }
                 }
         }
