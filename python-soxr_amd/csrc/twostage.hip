@@ -535,7 +535,11 @@ const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool
     const int64_t n_core = ts.up ? 2 * n : 2 * n_out, n_mid = n_core + 2 * pad;
     void *mid = nullptr;
     HIP_TRY(hipMallocAsync(&mid, (size_t)cols * (size_t)n_mid * es, st));
-    const int64_t mstr[3] = {n_mid * (int64_t)j.n_channels, 1, n_mid};
+    // intermediate layout [clip][channel][frames] — or [clip][frames][channel] when the job's own data is interleaved with an
+    // even channel count: the FFT stage then takes its channel-pair form (one complex word per frame and pair, contiguous
+    // for stereo) instead of pairing blocks over strided columns
+    const bool inter = j.n_channels % 2 == 0 && j.in_chan_stride == 1 && j.out_chan_stride == 1;
+    const int64_t mstr[3] = {n_mid * (int64_t)j.n_channels, inter ? (int64_t)j.n_channels : 1, inter ? 1 : n_mid};
     const int64_t istr[3] = {j.in_clip_stride, j.in_frame_stride, j.in_chan_stride};
     const int64_t ostr[3] = {j.out_clip_stride, j.out_frame_stride, j.out_chan_stride};
     auto fail = [&](const char *e) { (void)hipFreeAsync(mid, st); return e; };
@@ -544,7 +548,7 @@ const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool
     fj.clip_counter = nullptr; fj.dither = 0;
     bool fft_done = false;
     const char *err = nullptr;
-    void *mid0 = (char *)mid + (size_t)pad * es; // sample 0 of the first column
+    void *mid0 = (char *)mid + (size_t)(pad * mstr[1]) * es; // sample 0 of the first column
     if ((err = device_bank_ensure(&p->two->fft, engine_prec(j.elem)))) return fail(err);
     if (ts.up) {
         // 1:2 over the input delayed by pad / 2 samples: its output m' is u[m' - pad]
