@@ -238,6 +238,20 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
         return nK0 + (int64_t)dk * a.Mq + (int64_t)__umul64hi(dk, a.step_fx) + (ph < lo ? 1 : 0);
     };
     const int slot = (tid * a.lane_mul) & 255; // this thread's run of R outputs within a tile
+    constexpr int NPF = FAST ? 8 : 0; // float32 path: samples per thread of the NEXT tile's span held in registers
+    Real pf[NPF > 0 ? NPF : 1];
+    auto fetch = [&](int64_t tile) {
+        const int64_t kA = a.k_lo + tile * per_tile, kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
+        uint64_t ph;
+        const int64_t nA = position(kA, ph) - (H - 1), nB = position(kB, ph) + H;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int64_t n = nA + q * 256 + tid;
+            pf[q] = (n <= nB && n >= a.n_lo && n < a.n_src) ? src[n * a.sfs] : (Real)0;
+        }
+    };
+    if constexpr (FAST)
+        if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t kA = a.k_lo + tile * per_tile;
         const int64_t kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
@@ -250,13 +264,20 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
             nA = floor_div(kA * a.Ms, a.Ls) - (H - 1); nB = floor_div(kB * a.Ms, a.Ls) + H;
         }
         const int span = (int)(nB - nA + 1);
-        for (int i = tid; i < span; i += 256) {
+        if constexpr (FAST) { // the first NPF * 256 samples were fetched while the tile before was being computed
+#pragma unroll
+            for (int q = 0; q < NPF; ++q)
+                if (q * 256 + tid < span) xs[q * 256 + tid] = pf[q];
+        }
+        for (int i = NPF * 256 + tid; i < span; i += 256) {
             const int64_t n = nA + i;
             xs[i] = (n >= a.n_lo && n < a.n_src) ? src[n * a.sfs] : (Real)0;
         }
         POLY_STAMP(0); // span staged (loads issued and written)
         __syncthreads();
         POLY_STAMP(1); // barrier
+        if constexpr (FAST)
+            if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x); // in flight behind this tile's arithmetic
         const int64_t k1 = kA + (int64_t)slot * a.R;
         if constexpr (sizeof(Real) == 4 && MQ >= 0) {
             // float32, window in registers: the position is a 64-bit binary fraction stepped by frac(Ms / Ls) 2^64 (its
