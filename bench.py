@@ -48,7 +48,7 @@ KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, paire
 # `measured_counters()` hands a figure out only while that hash still matches the sources in this checkout — a stale
 # constant is reported as null with the reason, never silently.
 TRAFFIC_FILE = "r04_traffic.json"
-KERNEL_SOURCES = ("python-soxr_amd/csrc/fft.hip", "python-soxr_amd/csrc/kernels.hip")
+KERNEL_SOURCES = ("python-soxr_amd/csrc/fft.hip", "python-soxr_amd/csrc/kernels.hip", "python-soxr_amd/csrc/twostage.hip")
 
 
 def kernel_sources_sha16():

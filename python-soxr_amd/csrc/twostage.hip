@@ -171,6 +171,7 @@ static const char *twostage_build(Plan *p)
 struct PolyArgs {
     const void *src; void *dst; const void *tab;
     int32_t T, P, row, R, span_max, lane_mul, lgP;
+    int32_t lg_cg;     // a workgroup takes 2^lg_cg neighbouring channels of a tile one after the other (interleaved data: their parts of a line meet in one L2)
     unsigned long long *trace; // -DPOLY_TRACE builds: per-wave cycle sums [workgroup][wave][8]
     uint64_t step_fx;  // frac(Ms / Ls) in units of 2^-64 (float32 path of k_poly)
     double fx_per_rem; // 2^64 / Ls
@@ -204,8 +205,9 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
     R4 *tab = reinterpret_cast<R4 *>(smem);
     Real *xs = reinterpret_cast<Real *>(smem + (size_t)a.P * a.row * sizeof(R4));
     Real *ys = xs + a.span_max; // the tile's outputs, staged [R][257] so that they leave as whole lines whatever the lane order
-    const uint32_t col = blockIdx.y, ch = col % a.n_channels, clip = col / a.n_channels;
-    const Real *src = (const Real *)a.src + (int64_t)clip * a.scs + (int64_t)ch * a.schs;
+    const int cg = 1 << a.lg_cg;
+    const uint32_t col = blockIdx.y << a.lg_cg, ch = col % a.n_channels, clip = col / a.n_channels; // first channel of the group
+    const Real *src0 = (const Real *)a.src + (int64_t)clip * a.scs + (int64_t)ch * a.schs;
     Real *dst = (Real *)a.dst + (int64_t)clip * a.dcs + (int64_t)ch * a.dchs;
     const int tid = (int)threadIdx.x;
     {
@@ -240,7 +242,8 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
     const int slot = (tid * a.lane_mul) & 255; // this thread's run of R outputs within a tile
     constexpr int NPF = FAST ? 8 : 0; // float32 path: samples per thread of the NEXT tile's span held in registers
     Real pf[NPF > 0 ? NPF : 1];
-    auto fetch = [&](int64_t tile) {
+    auto fetch = [&](int64_t tile, int c) {
+        const Real *src = src0 + (int64_t)c * a.schs;
         const int64_t kA = a.k_lo + tile * per_tile, kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
         uint64_t ph;
         const int64_t nA = position(kA, ph) - (H - 1), nB = position(kB, ph) + H;
@@ -251,8 +254,14 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
         }
     };
     if constexpr (FAST)
-        if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x, 0);
+    // work items: (tile, channel of the group), channels innermost
+    for (int64_t item = 0;; ++item) {
+        const int64_t tile = blockIdx.x + (item >> a.lg_cg) * gridDim.x;
+        if (tile >= n_tiles) break;
+        const int c = (int)(item & (cg - 1));
+        const Real *src = src0 + (int64_t)c * a.schs;
+        Real *ysc = ys;
         const int64_t kA = a.k_lo + tile * per_tile;
         const int64_t kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
         // (|k| < 2^31 and Ms <= 2^31: the products fit 64 bits — launch_two_stage admits no larger job)
@@ -276,8 +285,10 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
         POLY_STAMP(0); // span staged (loads issued and written)
         __syncthreads();
         POLY_STAMP(1); // barrier
-        if constexpr (FAST)
-            if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x); // in flight behind this tile's arithmetic
+        if constexpr (FAST) { // the next item's span: in flight behind this item's arithmetic
+            const int64_t tn = blockIdx.x + ((item + 1) >> a.lg_cg) * gridDim.x;
+            if (tn < n_tiles) fetch(tn, (int)((item + 1) & (cg - 1)));
+        }
         const int64_t k1 = kA + (int64_t)slot * a.R;
         if constexpr (sizeof(Real) == 4 && MQ >= 0) {
             // float32, window in registers: the position is a 64-bit binary fraction stepped by frac(Ms / Ls) 2^64 (its
@@ -295,7 +306,7 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
                 for (int j = 0; j < TT / 2; ++j) { u[j].x = w[2 * j]; u[j].y = w[2 * j + 1]; }
                 const float *wtop = w + (TT - 2);
                 const v4f *tabv = reinterpret_cast<const v4f *>(tab);
-                float *yo = ys + slot; // staged [run index][slot] with rows of 257: conflict-free writes
+                float *yo = ysc + slot; // staged [run index][slot] with rows of 257: conflict-free writes
                 const int lg = a.lgP;
                 int left = (int)(kB - k1 + 1 < (int64_t)a.R ? kB - k1 + 1 : (int64_t)a.R);
                 for (; left > 0; --left) {
@@ -373,7 +384,7 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
                         acc1 += (((c[j + 1].w * x + c[j + 1].z) * x + c[j + 1].y) * x + c[j + 1].x) * v[j + 1];
                     }
                 }
-                ys[r * 257 + slot] = acc0 + acc1;
+                ysc[r * 257 + slot] = acc0 + acc1;
                 n += a.Mq; rem += a.Mr;
                 const bool adv = rem >= a.Ls;
                 if (adv) { rem -= a.Ls; ++n; }
@@ -389,8 +400,8 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
         POLY_STAMP(2); // outputs computed
         __syncthreads(); // the tile's outputs are staged (and its source span is free for the next tile)
         POLY_STAMP(3); // barrier
-        {
-            Real *yo = dst + (kA - a.k_lo) * a.dfs;
+        { // (the channels of a group leave one after the other from the same workgroup: their halves of a line meet in its XCD's L2)
+            Real *yo = dst + (kA - a.k_lo) * a.dfs + (int64_t)c * a.dchs;
             const int cnt = (int)(kB - kA + 1);
             const float invR = 1.f / (float)a.R;
             for (int i = tid; i < cnt; i += 256) {
@@ -426,6 +437,9 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     a.fx_per_rem = 18446744073709551616. / (double)a.Ls;
     a.scs = sstr[0]; a.sfs = sstr[1]; a.schs = sstr[2]; a.dcs = dstr[0]; a.dfs = dstr[1]; a.dchs = dstr[2];
     a.n_channels = n_channels;
+    // channels per workgroup: neighbouring channels of interleaved data (source or destination) share their lines
+    a.lg_cg = (sstr[2] == 1 || dstr[2] == 1) ? (n_channels % 4 == 0 ? 2 : n_channels % 2 == 0 ? 1 : 0) : 0;
+    const int cg = 1 << a.lg_cg;
     // outputs per thread: as many as keep the tile's source span within the LDS left beside the table (<= 8)
     const size_t tab_bytes = (size_t)P * ts.row * 4 * sizeof(Real);
     const size_t lds_cap = (sizeof(Real) == 4 ? (tab_bytes > 40 * 1024 ? 78 : 52) : 96) * 1024; // three or two (float) / one (double) workgroups per CU
@@ -480,7 +494,7 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     a.span_max = (int)(256. * R * ratio + ts.T2 + 4);
     const size_t lds = tab_bytes + ((size_t)a.span_max + 257u * (size_t)R) * sizeof(Real);
     if (lds > 160 * 1024) return "two-stage: polyphase tile does not fit LDS";
-    const uint64_t cols = (uint64_t)n_clips * n_channels;
+    const uint64_t cols = (uint64_t)n_clips * n_channels / (uint64_t)cg; // channel groups
     if (cols > 65535) return "two-stage: too many columns";
     const int64_t n_tiles = (n_out + 256LL * R - 1) / (256LL * R);
     void (*kern)(PolyArgs) = nullptr;
@@ -498,7 +512,8 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t want = std::max<int64_t>(1, (int64_t)std::max(per_cu, 1) * n_cu / (int64_t)cols);
-    const unsigned gx = (unsigned)std::min<int64_t>(n_tiles, want);
+    unsigned gx = (unsigned)std::min<int64_t>(n_tiles, want);
+    if (gx > 8) gx &= ~7u; // columns' workgroups of one tile index on ONE XCD (workgroup b -> XCD b mod 8): interleaved channels share their lines in its L2
     a.trace = nullptr;
 #ifdef POLY_TRACE
     const size_t trace_n = (size_t)gx * cols * 4 * 8;

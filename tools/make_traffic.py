@@ -21,6 +21,9 @@ WORKLOADS = {  # name -> (kernel-name substring, grid predicate, algorithmic byt
     "float64": ("double, double, 1>", lambda gx, gy: True, 8 * (2880000 + 2646000)),
     "arith_f64": ("double, float, 1>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
     "exact_engine": ("k_tile_mfma_p<float>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
+    # the two kernels of the arbitrary-ratio job (48000 -> 44101 stereo 60 s): bytes each kernel has to move
+    "two_stage_poly": ("k_poly<float, 16, 0>", lambda gx, gy: True, 4 * 2 * (2880000 + 2 * 2646060)),
+    "two_stage_fft": ("k_fft_strided2<hipsoxr::PairSpec<4096, 2048", lambda gx, gy: True, 4 * 2 * (2 * 2646060 + 2646060)),
 }
 
 
@@ -81,12 +84,12 @@ def main(prof_dir, out_path):
                      "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE uncorrected; KiB",
            "kernel_sources": list(bench.KERNEL_SOURCES), "kernel_sources_sha16": bench.kernel_sources_sha16(), "workloads": {}}
     for wl, (sub, _, algo) in WORKLOADS.items():
-        f, w, v = pick(p3, sub, "FETCH_SIZE", threads[wl]), pick(p4, sub, "WRITE_SIZE", threads[wl]), pick(p1, sub, "SQ_INSTS_VALU", threads[wl])
+        f, w, v = pick(p3, sub, "FETCH_SIZE", threads.get(wl)), pick(p4, sub, "WRITE_SIZE", threads.get(wl)), pick(p1, sub, "SQ_INSTS_VALU", threads.get(wl))
         if f is None or w is None:
             continue
         traffic = int((2 * f + w) * 1024)
         rec["workloads"][wl] = {"kernel": sub, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": traffic, "algorithmic_bytes": algo,
-                                "ratio": round(traffic / algo, 4), "valu_wave_insts": v, "rocprof_avg_us": pick_us(tr, sub, threads[wl])}
+                                "ratio": round(traffic / algo, 4), "valu_wave_insts": v, "rocprof_avg_us": pick_us(tr, sub, threads.get(wl))}
     with open(out_path, "w") as fo:
         json.dump(rec, fo, indent=1)
     print(json.dumps(rec, indent=1))

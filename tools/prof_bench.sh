@@ -9,10 +9,10 @@ rm -rf $OUT && mkdir -p $OUT
 cd $R
 ARGS="${BENCH_ARGS:---steps 20 --warmup 3 --kernels-only --windows 6 --sustained-s 0.5}"
 SHORT="--steps 3 --warmup 1 --kernels-only --windows 2 --no-sustained"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python bench.py $SHORT > $OUT/pmc1.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- python bench.py $SHORT > $OUT/pmc3.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- python bench.py $SHORT > $OUT/pmc4.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc1 -o p -- python bench.py $SHORT > $OUT/pmc1.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- python bench.py $SHORT > $OUT/pmc3.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- python bench.py $SHORT > $OUT/pmc4.log 2>&1
 python tools/pmc_summary.py $OUT/trace/*.db $OUT/pmc*/*.db > $OUT/summary.txt 2>&1
 grep -h '"metric"' $OUT/bench_trace.log > $OUT/bench_line.json
 python tools/make_traffic.py $OUT $OUT/traffic.json > $OUT/traffic.log 2>&1
