@@ -603,7 +603,7 @@ const char *launch_two_stage(Plan *p, const hipsoxr_job_t &j, void *stream, bool
         fj.in = mid; fj.in_abs0 = -pad; fj.in_clip_stride = mstr[0]; fj.in_frame_stride = mstr[1]; fj.in_chan_stride = mstr[2];
         fj.in_frames = n_mid; fj.out_frames = n_out;
         if ((err = launch_fft(&p->two->fft, fj, stream, &fft_done))) return fail(err);
-        if (!fft_done) return fail("two-stage: the frequency-domain engine declined the second stage"); // (the first stage is already queued)
+        if (!fft_done) { (void)hipFreeAsync(mid, st); return nullptr; } // (declined: the queued first stage wrote the intermediate only; the ordinary path computes the job)
     }
     (void)hipFreeAsync(mid, st);
     (void)mid0;

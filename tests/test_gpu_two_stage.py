@@ -80,14 +80,15 @@ def test_two_stage_batches_and_layouts(oracle):
     import torch
     from soxr_amd import device as dev
     g = torch.Generator(device="cuda"); g.manual_seed(9)
-    plan = dev.Plan(44100, 48001, "HQ")
-    x = torch.randn((3, 200000, 4), device="cuda", generator=g) * 0.25          # [clips, frames, channels] interleaved
-    for t in (x, x.permute(0, 2, 1).contiguous().permute(0, 2, 1)):            # ... and the same values planar
-        y = dev.resample_tensor(plan, t)
-        ye = dev.resample_tensor(plan, t, kernel=dev.KERNEL_EXACT)
-        d = (y.double() - ye.double())
-        rel = (d.pow(2).mean(dim=1).sqrt() / ye.double().pow(2).mean(dim=1).sqrt()).max().item()
-        assert 0 < rel <= 1e-6, rel
+    for ch, a, b in ((4, 44100, 48001), (3, 44100, 48001), (8, 48000, 44101), (2, 32000, 11025.5), (6, 22050, 48000.5)):
+        plan = dev.Plan(a, b, "HQ")
+        x = torch.randn((3, 200000, ch), device="cuda", generator=g) * 0.25     # [clips, frames, channels] interleaved
+        for t in (x, x.permute(0, 2, 1).contiguous().permute(0, 2, 1)):        # ... and the same values planar
+            y = dev.resample_tensor(plan, t)
+            ye = dev.resample_tensor(plan, t, kernel=dev.KERNEL_EXACT)
+            d = (y.double() - ye.double())
+            rel = (d.pow(2).mean(dim=1).sqrt() / ye.double().pow(2).mean(dim=1).sqrt()).max().item()
+            assert 0 < rel <= 1e-6, (ch, a, b, rel)
 
 
 def _edge_pairs():
