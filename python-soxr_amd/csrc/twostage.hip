@@ -452,6 +452,7 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     // fall on 16 different bank quads — (row + tap) mod 16 with the table's odd row stride — and takes one more cycle per
     // extra distinct record on a quad.  Random rows cost 2.5-3 cycles; s within ~0.02 of an odd integer costs 1.
     // (R, lane_mul) is picked by simulating the four lane groups of the four waves over 16 starting phases.
+    if (switches().dbg_poly_r > 0) Rmax = std::min(Rmax, switches().dbg_poly_r);
     int R = Rmax, lane_mul = 1;
     {
         static std::mutex mu;
