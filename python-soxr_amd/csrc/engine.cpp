@@ -74,7 +74,11 @@ struct hipsoxr_stream {
     bool own_plan = false;
     unsigned ch = 1;
     int elem = HIPSOXR_F32;
-    bool split = false;
+    bool split = false;       // layout of the stream's OWN buffers and jobs: one plane per channel
+    // A split-layout stream whose first chunk is small runs interleaved inside (host ring, resident kernel, deferred output:
+    // everything the small-chunk path has) behind an adapter at the call boundary: split_io says what the caller's pointers are
+    bool split_io = false, adapt = false, adapt_decided = false;
+    std::vector<char> ad_in, ad_out;
     unsigned long flags = 0;
     bool ended = false;
     uint64_t n_in_total = 0, k_done = 0;
@@ -1044,7 +1048,7 @@ static const char *stream_new(hipsoxr_plan *plan, bool own, unsigned ch, hipsoxr
     hipsoxr_stream *s = new (std::nothrow) hipsoxr_stream();
     if (!s) return "out of memory";
     s->plan = plan; s->own_plan = own; s->ch = ch;
-    s->elem = (int)io & 3; s->split = ((int)io & 4) != 0; s->flags = flags;
+    s->elem = (int)io & 3; s->split = s->split_io = ((int)io & 4) != 0; s->flags = flags;
     s->defer = (flags & HIPSOXR_DEFER) && !(flags & HIPSOXR_VR) && !s->split;
     s->resident = ((flags & HIPSOXR_RESIDENT) || switches().resident) && !s->defer && !s->split;
     s->resident_auto_ok = !s->resident && !s->defer && !s->split && ((flags & HIPSOXR_AUTO_RESIDENT) || switches().auto_resident);
@@ -1172,12 +1176,65 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
     delete s;
 }
 
+static const char *stream_process_inner(hipsoxr_stream *s, const void *in, size_t ilen, void *out, size_t olen, size_t *odone);
+
 hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size_t ilen, void *out,
                                        size_t olen, size_t *odone)
 {
     if (!s || !odone) return "null argument";
     DeviceGuard guard(s->device);
     *odone = 0;
+    if (s->split_io && !s->adapt_decided && in && ilen) {
+        // first chunk of a split-layout stream: a small one puts the stream on the interleaved small-chunk path for good
+        // (its per-channel planes are woven / unwoven at this boundary: a few hundred frames per call); a large one keeps
+        // the planar device ring, where every channel moves with one copy
+        s->adapt_decided = true;
+        if (s->n_in_total == 0 && ilen * s->ch * esz(s) <= kHostRingChunk && !switches().no_host_ring) {
+            s->adapt = true; s->split = false;
+            s->defer = (s->flags & HIPSOXR_DEFER) && !(s->flags & HIPSOXR_VR);
+            s->resident = ((s->flags & HIPSOXR_RESIDENT) || switches().resident) && !s->defer;
+            s->resident_auto_ok = !s->resident && !s->defer && ((s->flags & HIPSOXR_AUTO_RESIDENT) || switches().auto_resident);
+            if (s->d_in && !s->ring_on_host) { (void)hipFree(s->d_in); s->d_in = nullptr; s->in_cap = 0; } // (a planar ring inherited from the pool)
+            if (s->d_in_alt && !s->ring_on_host) { (void)hipFree(s->d_in_alt); s->d_in_alt = nullptr; s->alt_cap = 0; }
+            if (s->d_out) { (void)hipFree(s->d_out); s->d_out = nullptr; s->out_cap = 0; }
+        }
+    }
+    if (!s->adapt) return stream_process_inner(s, in, ilen, out, olen, odone);
+    if (s->ch == 1) // one plane IS the interleaved signal
+        return stream_process_inner(s, in ? ((const void *const *)in)[0] : nullptr, ilen, out ? ((void *const *)out)[0] : nullptr, olen, odone);
+    const size_t e = esz(s), ch = s->ch;
+    const void *in_i = nullptr;
+    if (in) {
+        s->ad_in.resize(std::max<size_t>(ilen * ch * e, 1));
+        const void *const *planes = (const void *const *)in;
+        for (size_t c = 0; c < ch; ++c) {
+            const char *src = (const char *)planes[c];
+            char *dst = s->ad_in.data() + c * e;
+            if (e == 4) for (size_t f = 0; f < ilen; ++f) std::memcpy(dst + f * ch * 4, src + f * 4, 4);
+            else if (e == 2) for (size_t f = 0; f < ilen; ++f) std::memcpy(dst + f * ch * 2, src + f * 2, 2);
+            else for (size_t f = 0; f < ilen; ++f) std::memcpy(dst + f * ch * 8, src + f * 8, 8);
+        }
+        in_i = s->ad_in.data();
+    }
+    void *out_i = nullptr;
+    if (out && olen) { s->ad_out.resize(olen * ch * e); out_i = s->ad_out.data(); }
+    if (const char *err = stream_process_inner(s, in_i, ilen, out_i, olen, odone)) return err;
+    if (out_i && *odone) {
+        void *const *planes = (void *const *)out;
+        const size_t n = *odone;
+        for (size_t c = 0; c < ch; ++c) {
+            char *dst = (char *)planes[c];
+            const char *src = s->ad_out.data() + c * e;
+            if (e == 4) for (size_t f = 0; f < n; ++f) std::memcpy(dst + f * 4, src + f * ch * 4, 4);
+            else if (e == 2) for (size_t f = 0; f < n; ++f) std::memcpy(dst + f * 2, src + f * ch * 2, 2);
+            else for (size_t f = 0; f < n; ++f) std::memcpy(dst + f * 8, src + f * ch * 8, 8);
+        }
+    }
+    return nullptr;
+}
+
+static const char *stream_process_inner(hipsoxr_stream *s, const void *in, size_t ilen, void *out, size_t olen, size_t *odone)
+{
     if (s->defer && out && olen) {
         if (in != nullptr) return stream_process_deferred(s, in, ilen, out, olen, odone);
         // End of input: what the last launch produced first, then — in the SAME call — the synchronous flush for
