@@ -27,6 +27,15 @@ def test_fft_engine_random_cases_within_tolerance():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
 
 
+def test_two_stage_random_cases_within_tolerance():
+    """tests/fuzz/fuzz_two_stage.py: random integer / float / near-rational rate pairs, recipes, float32 / float64, channel
+    counts, batches and layouts through the device API (AUTO / FFT) against the canonical-order engine: 1e-6 (float64:
+    3e-9) relative RMS over every column, the ends included."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_two_stage.py"), "160", "41"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_variable_rate_random_schedules_bit_identical():
     """tests/fuzz/fuzz_vr.py: random largest ratio, recipe, dtype, chunk sizes and ratio changes (jumps and
     slews, also during a slew), against the oracle driven by tests/vr_sim.py — bit for bit per chunk."""
