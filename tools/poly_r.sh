@@ -10,9 +10,10 @@ sys.path.insert(0, "python-soxr_amd")
 import torch
 from soxr_amd import device as dev
 out = []
-for a, b in ((48000, 44101), (44101, 48000), (44100, 16001)):
+for a, b, fr, ch in ((48000, 44101, 2880000, 2), (44101, 48000, 2880000, 2), (44100, 16001, 2880000, 2), (48000, 44101, 2880000, 1), (48000, 44101, 960000, 2), (48000, 44101, 480000, 1)):
     plan = dev.Plan(a, b, "VHQ")
-    x = torch.randn((2880000, 2), device="cuda") * 0.25
+    x = torch.randn((fr, ch), device="cuda") * 0.25
+    if ch == 1: x = x[:, 0].contiguous()
     y = dev.resample_tensor(plan, x)
     job = dev.PreparedJob(plan, x, y)
     for _ in range(5): job.launch()
@@ -21,7 +22,7 @@ for a, b in ((48000, 44101), (44101, 48000), (44100, 16001)):
     e0.record()
     for _ in range(100): job.launch()
     e1.record(); torch.cuda.synchronize()
-    out.append("%d->%d %.1f us" % (a, b, e0.elapsed_time(e1) * 10))
+    out.append("%d->%d/%dk/%dch %.1f" % (a, b, fr // 1000, ch, e0.elapsed_time(e1) * 10))
 print("  ".join(out))
 PY
 done
