@@ -95,6 +95,7 @@ struct Switches {
     bool no_xcd_split = false;    // HIPSOXR_NO_XCD_SPLIT     k_tile_mfma_p unit split on grid.z instead of XCD-aware ids
     bool no_tile_split = false;   // HIPSOXR_NO_TILE_SPLIT    k_tile / k_tile_mfma: never spread a slab's row tiles over several workgroups
     bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp
+    bool no_interp_wave = false;  // HIPSOXR_NO_INTERP_WAVE   mid-size interpolated / variable-rate launches on lane-per-output k_interp
     bool no_two_stage = false;    // HIPSOXR_NO_TWO_STAGE     float device jobs of interpolated-phase plans stay on the exact engine
     // timing experiments on the tile kernels (results may be wrong with dbg_flags != 0)
     int dbg_flags = 0;            // HIPSOXR_DEBUG_FLAGS      1 no staging, 2 no LDS reads, 4 no coefficient loads, 8 no stores

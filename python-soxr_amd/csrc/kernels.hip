@@ -46,6 +46,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "device.h"
@@ -68,6 +69,7 @@ const Switches &switches()
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX");
         w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT");
         w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE"); w.no_two_stage = on("HIPSOXR_NO_TWO_STAGE");
+        w.no_interp_wave = on("HIPSOXR_NO_INTERP_WAVE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
         w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD");
@@ -430,6 +432,152 @@ __device__ __forceinline__ InterpPos<Real> interp_locate_local(const InterpArgs 
     const uint64_t lo = divmod_small((uint64_t)rem2 << (SH / 2), L, invL, &rem);
     p.xq = (hi << (SH / 2)) | lo;
     return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_interp_wave — mid-size interpolated-phase and variable-rate launches (a stream's 96 000-frame chunk)
+// ---------------------------------------------------------------------------------------------
+// k_interp gives every output one lane: 64 lanes in 64 different phase intervals fetch 64 different 16-byte cubic
+// records per tap (each pulling a 128-byte line through the texture path for 16 bytes of use), a chunk of 35 000
+// outputs is one wave per SIMD at best, and every wave walks its T taps through ~T/8 serialised round trips to the L2:
+// 227 us for 34 830 outputs x 736 taps (44.1k -> 16k VHQ, variable rate).  Here a half-chain — the canonical order has
+// exactly two per output — is a QUAD of lanes:
+//   * lane k of the quad fetches the record of tap 4s + k of step s and evaluates its cubic: a quad reads 64 contiguous
+//     bytes of its row per step (128 in float64), a wave 16 such runs — no over-fetch, no transposition, a quarter of
+//     the cubic arithmetic per lane, and eight times the waves of k_interp (16 half-chains per wave instead of 64
+//     outputs), each a quarter as long;
+//   * the chain itself — the only serial part — takes the four coefficients in order out of the quad's lanes by DPP
+//     (`quad_perm` broadcast, folded into v_fmac_f32_dpp where the compiler can): acc = fma(c_k, x, acc), k = 0..3,
+//     computed by all four lanes alike;
+//   * records are requested U steps ahead (a register is refilled as soon as its cubic is taken);
+//   * the input span of a workgroup's 32 consecutive outputs (<= 31 steps + T samples) is staged once in LDS, converted,
+//     zero-extended; a quad's four samples per step are one broadcast LDS read.
+// Per output the arithmetic is k_interp's to the letter (cubic by three fma, then the chain fma, accL + accR), so results
+// are bit-identical to it and to the oracle, however the outputs spread over the phase intervals (a constant step of
+// exactly 2.0 puts every output in ONE interval, a generic step in all of them).
+struct InterpWaveArgs {
+    InterpArgs ia;
+    int32_t span_cap; // staged samples per workgroup (>= 31 steps + T)
+    uint32_t *done_words; // (optional, pinned host memory) completion words, as ChainArgs::done_words
+    uint32_t done_seq;
+};
+
+template <int K> __device__ __forceinline__ float quad_bcast_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+template <int K> __device__ __forceinline__ double quad_bcast_f(double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)u, K * 0x55, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), K * 0x55, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+template <typename IO, typename Real, bool VR>
+__global__ void __launch_bounds__(256) k_interp_wave(InterpWaveArgs wa)
+{
+    typedef typename Vec4<Real>::type V4;
+    constexpr int U = 8; // steps (of four taps) requested ahead
+    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ int64_t s_loc[4]; // first / last window start of the two output groups
+    const InterpArgs &ia = wa.ia;
+    const GatherArgs &a = ia.g;
+    const int lane = threadIdx.x & 63, k = lane & 3, quad = lane >> 2;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), half = wave & 1, grp = wave >> 1;
+    Real *xs = reinterpret_cast<Real *>(smem_raw);
+    Real *accx = xs + wa.span_cap; // [32] the second half-chains' sums
+    const int32_t T = a.T, H = T / 2, NS = H / 4; // T is a multiple of 8
+    const uint32_t col = blockIdx.y;
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+
+    const int64_t o = (int64_t)blockIdx.x * 32 + grp * 16 + quad;
+    const int64_t oc = o < a.out_frames ? o : a.out_frames - 1; // (quads past the end repeat the last output and store nothing)
+    const InterpPos<Real> pos = interp_locate<Real, VR>(ia, oc);
+    const Real xx = (Real)pos.xq * (Real)(1. / (double)(1ULL << SH));
+    const int64_t loc0 = pos.n0 - a.in_abs0;
+    // positions grow with the output index: the first quad of group 0 holds the span's first sample, the last quad of group 1 its last window
+    if (half == 0 && (lane == 0 || lane == 63)) s_loc[grp * 2 + (lane ? 1 : 0)] = loc0;
+    __syncthreads();
+    const int64_t base = s_loc[0];
+    int32_t span = (int32_t)(s_loc[3] - base) + T;
+    if (span > wa.span_cap) span = wa.span_cap; // (never: the host sized span_cap from the launch's largest step)
+    const int32_t rel = (int32_t)(loc0 - base);
+    for (int m = (int)threadIdx.x; m < span; m += 256) {
+        const int64_t l = base + m;
+        xs[m] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+    }
+    __syncthreads();
+
+    const unsigned char *row = (const unsigned char *)ia.tab + (size_t)pos.iv * (size_t)T * sizeof(V4);
+    Real acc = 0;
+    auto run = [&](auto half_c) {
+        constexpr bool HALF = decltype(half_c)::value;
+        // step s: taps 4s .. 4s+3 of the first half-chain (upwards), T-1-4s .. T-4-4s of the second (downwards);
+        // lane k holds tap 4s + k / T-4-4s + k — ascending in memory either way
+        const V4 *rp = reinterpret_cast<const V4 *>(row) + (HALF ? T - 4 + k : k);
+        const Real *xp = xs + rel + (HALF ? T - 1 : 0);
+        // (every load below is unconditional — a load under a condition merges with the register's old value, and the
+        //  copy that merge needs waits for the load at once: 380 cycles per step, measured — so indices are clamped
+        //  to the last step instead, and the loop is cut where the look-ahead reaches the end)
+        auto at = [&](int s_) { return rp[HALF ? -4 * s_ : 4 * s_]; };
+        V4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = at(u < NS ? u : NS - 1);
+        auto chain = [&](const V4 v, int s_) {
+            const Real c = fma_r(fma_r(fma_r(v.w, xx, v.z), xx, v.y), xx, v.x);
+            const Real *xq = HALF ? xp - 4 * s_ : xp + 4 * s_;
+            if (!HALF) {
+                acc = fma_r(quad_bcast_f<0>(c), xq[0], acc);
+                acc = fma_r(quad_bcast_f<1>(c), xq[1], acc);
+                acc = fma_r(quad_bcast_f<2>(c), xq[2], acc);
+                acc = fma_r(quad_bcast_f<3>(c), xq[3], acc);
+            } else {
+                acc = fma_r(quad_bcast_f<3>(c), xq[0], acc);
+                acc = fma_r(quad_bcast_f<2>(c), xq[-1], acc);
+                acc = fma_r(quad_bcast_f<1>(c), xq[-2], acc);
+                acc = fma_r(quad_bcast_f<0>(c), xq[-3], acc);
+            }
+        };
+        int s0 = 0;
+        for (; s0 + 2 * U <= NS; s0 += U) { // the look-ahead stays inside the half-chain: immediate offsets
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const V4 v = r[u];
+                r[u] = at(s0 + u + U);
+                chain(v, s0 + u);
+            }
+        }
+        if (s0 + U <= NS) { // the last full group: its look-ahead is the tail (clamped)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const V4 v = r[u];
+                const int sn = s0 + u + U;
+                r[u] = at(sn < NS ? sn : NS - 1);
+                chain(v, s0 + u);
+            }
+            s0 += U;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) // the tail: fewer than U steps, already requested
+            if (s0 + u < NS) chain(r[u], s0 + u);
+    };
+    if (half) run(std::integral_constant<bool, true>());
+    else run(std::integral_constant<bool, false>());
+    if (half && k == 0) accx[grp * 16 + quad] = acc;
+    __syncthreads();
+    if (!half && k == 0 && o < a.out_frames) {
+        IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + o * a.ofs + (int64_t)ch * a.ochs;
+        store_out<Real>(yo, acc + accx[grp * 16 + quad], a.oc, ch, a.out_k0 + o);
+    }
+    if (wa.done_words) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&wa.done_words[blockIdx.y * gridDim.x + blockIdx.x], wa.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 template <typename IO, typename Real, bool VR>
@@ -2175,9 +2323,30 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             }
             grid = dim3((unsigned)((nf + 255) / 256), (unsigned)cols, 1);
         }
-        // small launches (streaming chunks): the low-latency chain kernel
+        // k_interp_wave (in place of lane-per-output k_interp): needs a (clip, channel) grid dimension and LDS for the
+        // span of 32 consecutive outputs at the launch's largest step
+        constexpr double kWaveUsPerTap = 1.0e-6; // us per output x tap, 256 CUs
+        bool wave_ok = false;
+        int64_t wave_span = 0;
+        size_t wave_lds = 0;
+        if (p->phases && !switches().no_interp_wave && (uint64_t)j.n_clips * j.n_channels <= 65535) {
+            double step = (double)p->M / (double)p->L;
+            if (vr) {
+                const double two64 = 18446744073709551616.;
+                const double s0 = (double)vr->s_hi + (double)vr->s_lo / two64;
+                const double dd = (double)(int64_t)vr->d_hi + (double)vr->d_lo / two64;
+                step = std::max(s0, s0 + dd * (double)(done + nf)) * (1. + 1e-9);
+            }
+            if (step < 1e6) {
+                wave_span = ((int64_t)std::ceil(31. * step) + p->T + 4 + 3) & ~(int64_t)3;
+                wave_lds = (size_t)(wave_span + 32) * sizeof(Real);
+                wave_ok = wave_lds <= 64 * 1024;
+            }
+        }
+        // small launches (streaming chunks): the low-latency chain kernel (interpolated plans above 512 outputs: k_interp_wave —
+        // 4410-frame variable-rate calls 29.0 -> 27.0 us; 441-frame calls are 2.5 us faster here: 20 short workgroups against 5)
         const bool no_chain = switches().no_chain;
-        if (!no_chain && nf < 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
+        if (!no_chain && nf < 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535 && !(wave_ok && !res && nf > 512)) {
             // few outputs per workgroup: the staging loop is then two or three trips of 16 loads per
             // thread (its latency is the kernel's latency), and there are enough workgroups anyway
             // (above 512 outputs 32 per workgroup: at most 64 workgroups then read their span over PCIe, poll the mailbox
@@ -2284,6 +2453,18 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             // (input span + 2 bytes of bookkeeping per output), at least ~32 outputs per interval
             const bool no_itile = switches().no_interp_tile;
             int64_t KO = 0, span_cap = 0;
+            // position of this launch's first output on the variable-rate clock: (T0, S0) advanced by `done` outputs
+            auto vr_advance = [&](InterpArgs &x) {
+                typedef unsigned __int128 u128;
+                const u128 T0 = ((u128)vr->t_hi << 64) | vr->t_lo, S0 = ((u128)vr->s_hi << 64) | vr->s_lo,
+                           D = ((u128)vr->d_hi << 64) | vr->d_lo;
+                const u128 n = (u128)(uint64_t)done, m = n * (n - 1) / 2;
+                const u128 T1 = T0 + n * S0 + D * (done ? m : 0), S1 = S0 + D * n;
+                x.t_hi = (uint64_t)(T1 >> 64); x.t_lo = (uint64_t)T1;
+                x.s_hi = (uint64_t)(S1 >> 64); x.s_lo = (uint64_t)S1;
+                x.d_hi = vr->d_hi; x.d_lo = vr->d_lo;
+            };
+            if (vr && (1 << ia.lgP) != ia.P) return "variable-rate needs a power-of-two phase count";
             if (!no_itile && nf >= 4096 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
                 double step = (double)p->M / (double)p->L; // input samples per output
                 if (vr) {
@@ -2318,9 +2499,25 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 if (KO) {
                     const double cols = (double)j.n_clips * j.n_channels, wgs = (double)((nf + KO - 1) / KO) * cols;
                     const double t_tile = std::ceil(wgs / 256.) * (double)KO * p->T * (vr ? 2.9e-4 : 6.3e-5);
-                    const double t_lane = 2.5e-6 * (double)nf * cols * p->T;
+                    const double t_lane = (wave_ok ? kWaveUsPerTap : 2.5e-6) * (double)nf * cols * p->T;
                     if (t_lane < t_tile) KO = 0;
                 }
+            }
+            if (!KO && wave_ok) { // a half-chain per quad of lanes (k_interp_wave)
+                InterpWaveArgs wa;
+                wa.ia = ia; wa.span_cap = (int32_t)wave_span; wa.done_words = nullptr; wa.done_seq = 0;
+                if (vr) vr_advance(wa.ia);
+                {
+                    const uint64_t wgs = (uint64_t)((nf + 31) / 32) * ((uint64_t)j.n_clips * j.n_channels);
+                    if (cd && done == 0 && nf == j.out_frames && wgs <= cd->cap) { // the whole job is this launch
+                        wa.done_words = cd->words; wa.done_seq = cd->seq;
+                        cd->n_wgs = (uint32_t)wgs;
+                    }
+                }
+                void (*wk)(InterpWaveArgs) = vr ? k_interp_wave<IO, Real, true> : k_interp_wave<IO, Real, false>;
+                hipLaunchKernelGGL(wk, dim3((unsigned)((nf + 31) / 32), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1), dim3(256), wave_lds, st, wa);
+                HIP_TRY(hipGetLastError());
+                continue;
             }
             if (KO) {
                 InterpTileArgs ta;

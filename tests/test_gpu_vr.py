@@ -48,6 +48,50 @@ def test_vr_stream_bit_exact_vs_oracle(soxr, oracle, dtype, quality):
     assert rs.delay() < 2
 
 
+LARGE = [  # chunks of >= 4096 outputs (k_interp_wave): generic steps, a slew across launches, steps of exactly 2 and 1
+    (30000, None), (20000, (44100, 22050, 3000)), (30000, None), (24001, (5, 2, 0)), (96000, (1, 1, 500)), (20000, (44100, 16000, 0)),
+    (40000, None)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16, np.int32])
+@pytest.mark.parametrize("quality", ["VHQ", "HQ", "LQ"])
+def test_vr_large_chunks_bit_exact_vs_oracle(soxr, oracle, dtype, quality):
+    """Round 4: launches of 4096 outputs and more run k_interp_wave (an output's two half-chains on two lanes, cubic
+    records fetched coalesced and transposed through LDS).  Same arithmetic per output as before: every chunk equals the
+    oracle driven by the independent clock of tests/vr_sim.py bit for bit — for steps that spread the outputs over all
+    phase intervals, for a step of exactly 2.0 / 1.0 (every output in ONE interval) and for slews that run across calls."""
+    rng = np.random.default_rng(11)
+    rs = soxr.ResampleStream(44100, 16000, 1, dtype=dtype, quality=quality, vr=True)
+    sim = VrSim(oracle, 44100, 16000, quality, dtype)
+    total = 0
+    for i, (n, change) in enumerate(LARGE):
+        x = _signal(rng, n, dtype)
+        last = i == len(LARGE) - 1
+        y = rs.resample_chunk(x, last=last)
+        want = sim.feed(x, last=last)
+        assert y.dtype == np.dtype(dtype) and len(y) == len(want), f"chunk {i}"
+        assert np.array_equal(y, want), f"chunk {i}"
+        total += len(y)
+        if change:
+            rs.set_io_ratio(change[0], change[1], change[2])
+            sim.set_io_ratio(change[0] / change[1], change[2])
+    assert total > 100000
+
+
+def test_vr_large_chunk_channels_share_the_kernel(soxr, oracle):
+    """Interleaved channels of a large variable-rate chunk: each column equals the mono oracle."""
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((50000, 4)) * 5000).astype(np.int16)
+    rs = soxr.ResampleStream(44100, 16000, 4, dtype="int16", quality="VHQ", vr=True)
+    rs.set_io_ratio(44100, 20000, 0)
+    y = rs.resample_chunk(x, last=True)
+    for c in range(4):
+        sim = VrSim(oracle, 44100, 16000, "VHQ", np.int16)
+        sim.set_io_ratio(44100 / 20000, 0)
+        assert np.array_equal(y[:, c], sim.feed(x[:, c], last=True, channel=c)), c
+    assert y.shape[1] == 4 and abs(len(y) - 50000 * 20000 / 44100) < 3
+
+
 @pytest.mark.parametrize("chunk", [441, 4410])
 def test_configs4_variable_rate_int16_44k1_to_16k_chunked(soxr, oracle, chunk):
     """BASELINE configs[4]: ResampleStream variable-rate 44100 -> 16000 int16, chunked input, state
