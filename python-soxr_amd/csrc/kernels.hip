@@ -28,7 +28,11 @@
 //   k_chain_resident  the same body as a RESIDENT kernel: launched once, fed through a mailbox (pinned host
 //                   memory, or device memory the CPU stores into on large-BAR systems) — no HIP call per chunk.
 //   k_interp(_tile) interpolated-phase plans (arbitrary ratios) and variable rate: per tap a cubic in
-//                   the fractional position (Horner FMAs), small / large launches.
+//                   the fractional position (Horner FMAs); lane per output (fallback) / outputs sorted by phase
+//                   interval, large launches.
+//   k_interp_wave   the same for launches between 512 outputs and what fills the chip (a stream's 96 000-frame
+//                   chunk, 1 s clips), and every large variable-rate launch: a half-chain per QUAD of lanes —
+//                   lane k fetches and evaluates tap 4s + k, the chain takes the four coefficients by DPP.
 //   k_tile          period-tiled VALU kernel: 64 (32, 16 where LDS demands) periods of one column staged in LDS, a wave = 16
 //                   output phases whose coefficients travel on the scalar path (s_load -> SGPR operands
 //                   of v_pk_fma_f32).  The f64 engine (float64 / int32 I/O); f32 A/B reference.

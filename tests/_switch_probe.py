@@ -33,6 +33,11 @@ out["host_f32"] = sha(soxr.resample(x1, 48000, 44100, quality="VHQ"))
 xi = (rng.standard_normal((9000, 2)) * 5000).astype(np.int16)
 out["host_i16"] = sha(soxr.resample(xi, 44100, 16000, quality="HQ"))
 out["host_interp"] = sha(soxr.resample(x1[:8000], 48000, 44101.5, quality="HQ"))
+out["host_interp_2ch"] = sha(soxr.resample(xi, 44100, 16000.5, quality="VHQ"))       # 3265 outputs x 2 channels
+vs = soxr.ResampleStream(44100, 16000, 1, dtype="float32", quality="VHQ", vr=True)        # chunks of 7256 and ~10 000 outputs
+v0 = vs.resample_chunk(x1[:20000])
+vs.set_io_ratio(44100, 22050, 700)
+out["stream_vr"] = sha(np.concatenate([v0, vs.resample_chunk(x1[20000:], last=True)]))
 for name, kw in (("stream", {}), ("stream_resident", {"resident": True}), ("stream_deferred", {"deferred": True})):
     rs = soxr.ResampleStream(44100, 16000, 1, dtype="int16", quality="VHQ", **kw)
     parts = [rs.resample_chunk(xi[a:a + 441, 0].copy(), last=(a + 441 >= len(xi))) for a in range(0, len(xi), 441)]
