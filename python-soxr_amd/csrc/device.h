@@ -111,7 +111,6 @@ struct Switches {
     bool dbg_mfma64_split = false; // HIPSOXR_DEBUG_MFMA64_SPLIT k_tile_mfma64_p: units of 16 periods even where 4 divides the tile count
     size_t dbg_mfma64_lds = 0;    // HIPSOXR_DEBUG_MFMA64_LDS LDS budget (bytes) that picks the float64 MFMA kernel's slab: 64, 32 or 16 periods
     size_t dbg_fft_lds = 0;       // HIPSOXR_DEBUG_FFT_LDS    the same for the frequency-domain kernels
-    int dbg_itile_per = 0;        // HIPSOXR_DEBUG_ITILE_PER  k_interp_tile: largest mean bucket (outputs per phase interval and workgroup) the launcher may pick (default 128)
     int dbg_poly_r = 0;           // HIPSOXR_DEBUG_POLY_R     k_poly: force the outputs per thread and tile
     int dbg_tile_form = 0;        // HIPSOXR_DEBUG_TILE_FORM  k_tile_mfma_p: force launch form 1..4 (slab 64 whole / 64 split / 32 whole / 32 split)
     const char *dbg_trace = nullptr; // HIPSOXR_DEBUG_TRACE   path for per-wave s_memtime stamps (k_tile_mfma_p; k_fft_pair2 with -DFFT2_TRACE)

@@ -73,7 +73,7 @@ const Switches &switches()
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX");
         w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT");
         w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE"); w.no_two_stage = on("HIPSOXR_NO_TWO_STAGE");
-        w.no_interp_wave = on("HIPSOXR_NO_INTERP_WAVE"); w.dbg_itile_per = num("HIPSOXR_DEBUG_ITILE_PER");
+        w.no_interp_wave = on("HIPSOXR_NO_INTERP_WAVE");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
         w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD");
@@ -680,14 +680,12 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
         const int iv = __builtin_amdgcn_readfirstlane(iv_);
         const uint32_t b0 = __builtin_amdgcn_readfirstlane(off[iv]), b1 = __builtin_amdgcn_readfirstlane(off[iv + 1]);
         CPtr16 row = (CPtr16)((const Real *)ia.tab + (size_t)iv * T * 4); // row[b] = taps 4b .. 4b+3
-        // A group walks its interval's whole row (T records, 16 T bytes) through the scalar cache, and the kernel's time
-        // goes with the number of such walks (round 3).  So a walk serves TWO sets of up to 64 outputs where the bucket
-        // holds more than 64 (round 4; the host sizes buckets up to 128 in float32): every s_load_dwordx16 feeds 32
-        // FMAs instead of 16 — 48000 -> 44101 stereo 60 s: see profiles/NOTES_r04.md §7.
-        auto sort64 = [&](uint32_t key) {
-            // 64 outputs sorted by index across the lanes (bitonic, in registers): consecutive lanes then read input
-            // windows a near-constant distance apart, which keeps the per-tap ds_read_b32 spread over the LDS banks
-            // (the counting sort scatters within a bucket in arrival order)
+        for (uint32_t g = b0; g < b1; g += 64) {
+            // the 64 outputs of this group, sorted by index across the lanes (bitonic, in registers):
+            // consecutive lanes then read input windows a near-constant distance apart, which keeps
+            // the per-tap ds_read_b32 spread over the LDS banks (the counting sort scatters within a
+            // bucket in arrival order)
+            uint32_t key = g + lane < b1 ? order[g + lane] : 0xFFFFu;
 #pragma unroll
             for (int k = 2; k <= 64; k <<= 1)
 #pragma unroll
@@ -696,73 +694,29 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
                     const bool take_min = ((lane & k) == 0) == ((lane & jj) == 0);
                     key = take_min ? (key < other ? key : other) : (key > other ? key : other);
                 }
-            return key;
-        };
-        for (uint32_t g = b0; g < b1; g += 128) {
-            const uint32_t key = sort64(g + lane < b1 ? order[g + lane] : 0xFFFFu);
             const bool live = key != 0xFFFFu;
             const int i = live ? (int)key : (int)order[b0];
             const InterpPos<Real> rc = locate(i);
             const Real *xl = xs + (uint32_t)(rc.n0 - n_first);
             const Real xx = (Real)(uint32_t)rc.xq * (Real)(1. / (double)(1ULL << SH));
             Real accL = 0, accR = 0;
-            if (g + 64 < b1) { // a second set rides on the same walk
-                const uint32_t key2 = sort64(g + 64 + lane < b1 ? order[g + 64 + lane] : 0xFFFFu);
-                const bool live2 = key2 != 0xFFFFu;
-                const int i2 = live2 ? (int)key2 : (int)order[b0];
-                const InterpPos<Real> rc2 = locate(i2);
-                const Real *xl2 = xs + (uint32_t)(rc2.n0 - n_first);
-                const Real xx2 = (Real)(uint32_t)rc2.xq * (Real)(1. / (double)(1ULL << SH));
-                Real accL2 = 0, accR2 = 0;
 #pragma unroll 2
-                for (int b = 0; b < H / 4; ++b) {
-                    const RealX16 c = row[b];
-                    const Real *x4 = xl + 4 * b, *y4 = xl2 + 4 * b;
-                    accL = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accL);
-                    accL2 = fma_r(fma_r(fma_r(fma_r(c[3], xx2, c[2]), xx2, c[1]), xx2, c[0]), y4[0], accL2);
-                    accL = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accL);
-                    accL2 = fma_r(fma_r(fma_r(fma_r(c[7], xx2, c[6]), xx2, c[5]), xx2, c[4]), y4[1], accL2);
-                    accL = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accL);
-                    accL2 = fma_r(fma_r(fma_r(fma_r(c[11], xx2, c[10]), xx2, c[9]), xx2, c[8]), y4[2], accL2);
-                    accL = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accL);
-                    accL2 = fma_r(fma_r(fma_r(fma_r(c[15], xx2, c[14]), xx2, c[13]), xx2, c[12]), y4[3], accL2);
-                }
+            for (int b = 0; b < H / 4; ++b) { // T is a multiple of 8: H is a multiple of 4
+                const RealX16 c = row[b];
+                const Real *x4 = xl + 4 * b;
+                accL = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accL);
+                accL = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accL);
+                accL = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accL);
+                accL = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accL);
+            }
 #pragma unroll 2
-                for (int b = T / 4 - 1; b >= H / 4; --b) { // descending taps
-                    const RealX16 c = row[b];
-                    const Real *x4 = xl + 4 * b, *y4 = xl2 + 4 * b;
-                    accR = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accR);
-                    accR2 = fma_r(fma_r(fma_r(fma_r(c[15], xx2, c[14]), xx2, c[13]), xx2, c[12]), y4[3], accR2);
-                    accR = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accR);
-                    accR2 = fma_r(fma_r(fma_r(fma_r(c[11], xx2, c[10]), xx2, c[9]), xx2, c[8]), y4[2], accR2);
-                    accR = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accR);
-                    accR2 = fma_r(fma_r(fma_r(fma_r(c[7], xx2, c[6]), xx2, c[5]), xx2, c[4]), y4[1], accR2);
-                    accR = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accR);
-                    accR2 = fma_r(fma_r(fma_r(fma_r(c[3], xx2, c[2]), xx2, c[1]), xx2, c[0]), y4[0], accR2);
-                }
-                if (live2) {
-                    const int64_t idx2 = o_base + i2;
-                    store_out<Real>(yo + idx2 * a.ofs, accL2 + accR2, a.oc, ch, a.out_k0 + idx2);
-                }
-            } else {
-#pragma unroll 2
-                for (int b = 0; b < H / 4; ++b) { // T is a multiple of 8: H is a multiple of 4
-                    const RealX16 c = row[b];
-                    const Real *x4 = xl + 4 * b;
-                    accL = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accL);
-                    accL = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accL);
-                    accL = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accL);
-                    accL = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accL);
-                }
-#pragma unroll 2
-                for (int b = T / 4 - 1; b >= H / 4; --b) { // descending taps
-                    const RealX16 c = row[b];
-                    const Real *x4 = xl + 4 * b;
-                    accR = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accR);
-                    accR = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accR);
-                    accR = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accR);
-                    accR = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accR);
-                }
+            for (int b = T / 4 - 1; b >= H / 4; --b) { // descending taps
+                const RealX16 c = row[b];
+                const Real *x4 = xl + 4 * b;
+                accR = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accR);
+                accR = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accR);
+                accR = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accR);
+                accR = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accR);
             }
             if (live) {
                 const int64_t idx = o_base + i;
@@ -2530,16 +2484,14 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 //  of which the second is a third full; 41 per interval are 506)
                 double best_cost = 1e300;
                 const double cols_ = (double)j.n_clips * j.n_channels;
-                const int per_max = switches().dbg_itile_per ? switches().dbg_itile_per : 128; // (above 64: two sets of outputs per row walk)
-                for (int per = per_max; per >= 15; --per) {
+                for (int per = 64; per >= 15; --per) {
                     const int64_t k = (int64_t)per * p->phases;
                     if (k > 16384 || k > nf) continue;
                     const int64_t sc = (int64_t)std::ceil((double)k * step) + p->T + 8;
                     const int64_t bytes = sc * (int64_t)sizeof(Real) + k * 2 + (2 * p->phases + 2) * 4 + 64;
                     if (bytes > 150 * 1024) continue;
                     const double wgs_ = std::ceil((double)nf / (double)k) * cols_;
-                    // per workgroup: one row walk per interval and 128 outputs of its bucket (priced as 64 outputs' arithmetic), plus the outputs
-                    const double cost = std::ceil(wgs_ / 256.) * ((double)p->phases * std::ceil(per / 128.) * 64. + (double)k) * (per >= 30 ? 1. : 30. / per); // (thin buckets: idle lanes)
+                    const double cost = std::ceil(wgs_ / 256.) * (double)k * (per >= 30 ? 1. : 30. / per); // (thin buckets: idle lanes)
                     if (cost < best_cost) { best_cost = cost; KO = k; span_cap = sc; }
                 }
                 // ... which pays off once the launch fills the chip.  A workgroup of it is long (KO outputs x T taps one
