@@ -439,6 +439,28 @@ def configs4_stream(seconds=20):
                     while time.perf_counter() - t2 < 300e-6:
                         pass
                 out[key]["us_in_call_when_spaced"] = inside / 300 * 1e6
+    # the same stream with the chunks already in HBM (soxr_amd.device.TensorStream): pending input stays on the device,
+    # a call is one asynchronous launch on the current stream — no PCIe, no host synchronisation inside the call
+    try:
+        import torch
+        from soxr_amd import device as dev
+        xd = torch.from_numpy(x).cuda()
+        for chunk in (441, 4410, 96000):
+            ts = dev.TensorStream(44100, 16000, 1, dtype=torch.int16, quality="VHQ")
+            ts.resample_chunk(xd[:chunk])
+            ts.clear()
+            torch.cuda.synchronize()
+            n_calls = 0
+            t0 = time.perf_counter()
+            for a in range(0, len(x), chunk):
+                ts.resample_chunk(xd[a:a + chunk], last=(a + chunk >= len(x)))
+                n_calls += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[f"device_chunk{chunk}"] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls, "Msamples_per_s": len(x) / dt / 1e6,
+                                           "note": "chunks and results are device tensors; one sync after the last call"}
+    except Exception as e:  # noqa: BLE001
+        out["device_stream"] = {"error": str(e)}
     return out
 
 
