@@ -217,6 +217,17 @@ HIPSOXR_API hipsoxr_error_t hipsoxr_stream_create_with_plan(hipsoxr_plan_t *, un
  * All of `ilen` is always consumed.  At most `olen` frames are written; *odone = frames written. */
 HIPSOXR_API hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *, const void *in, size_t ilen,
                                                    void *out, size_t olen, size_t *odone);
+/* The same call on DEVICE buffers (round 4; version 0.4.1): `in` / `out` are device pointers (interleaved streams only),
+ * the chunk is appended to the stream's ring by a device-to-device copy and every output the input so far determines is
+ * written straight into `out`, all enqueued on `hip_stream` (a hipStream_t; NULL = default stream) — asynchronous, no
+ * copy over PCIe, no host synchronisation; *odone is known at once (it is a function of the counts alone).  The caller
+ * keeps `in` valid until the copy has run and orders its own use of `out` on `hip_stream`.  Same contract otherwise
+ * (in == NULL: end of input; variable-rate streams and hipsoxr_stream_set_io_ratio included); frames and call
+ * boundaries are those of hipsoxr_stream_process on the same input.  What CSoxr::process (src/soxr_ext.cpp:129-187)
+ * would be for a caller whose audio already lives in HBM.  Not for streams created with HIPSOXR_DEFER / HIPSOXR_RESIDENT
+ * flags or the split layout. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_stream_process_device(hipsoxr_stream_t *, const void *in, size_t ilen,
+                                                          void *out, size_t olen, size_t *odone, void *hip_stream);
 HIPSOXR_API void hipsoxr_stream_delete(hipsoxr_stream_t *);
 HIPSOXR_API hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *);
 HIPSOXR_API double hipsoxr_stream_delay(hipsoxr_stream_t *);

@@ -117,7 +117,9 @@ struct Switches {
 };
 const Switches &switches();
 
-// measurement helper: mode 0 = copy src -> dst, 1 = read src only (dst: >= 4 bytes)
+// device-to-device copy as an ordinary kernel launch on `stream` (a stream's chunk appended to its ring: hipMemcpyAsync costs
+// ~2x the API time and queues behind a barrier packet)
+const char *launch_copy(void *dst, const void *src, size_t bytes, void *stream);
 
 // frequency-domain engine (fft.hip): whole-signal float32 jobs
 bool fft_job_eligible(const Plan &p, const hipsoxr_job_t &job);

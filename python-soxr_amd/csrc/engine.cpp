@@ -95,6 +95,10 @@ struct hipsoxr_stream {
     size_t out_cap = 0; // frames
     uint64_t *d_clips = nullptr;
     hipStream_t st = nullptr;
+    // device chunks (hipsoxr_stream_process_device) run on the CALLER's HIP stream: the last one used, whether work of such
+    // calls may still be in flight there, and whether host-pointer calls have used the stream's own since
+    hipStream_t ext_st = nullptr;
+    bool ext_pending = false, own_used = false;
     // pinned bounce buffers for small chunks: a pageable hipMemcpyAsync is staged by the runtime
     // with a blocking hand-shake per call (~30 us each way); a memcpy into pinned memory + a true
     // async copy costs a few us
@@ -320,7 +324,7 @@ static void plan_release(hipsoxr_plan *h)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *hipsoxr_version(void) { return "hipsoxr-0.4.0 (gfx950)"; }
+const char *hipsoxr_version(void) { return "hipsoxr-0.4.1 (gfx950)"; }
 
 int hipsoxr_device_count(void) { return device_count(); }
 
@@ -1138,10 +1142,19 @@ hipsoxr_error_t hipsoxr_stream_create_with_plan(hipsoxr_plan_t *plan, unsigned n
     return stream_new(plan, false, num_channels, io_type, flags, out);
 }
 
+// Device calls of this stream may still be in flight on the caller's HIP stream: wait for them (before a host-pointer
+// call, clear, delete or a counter read touches what they use).
+static void ext_sync(hipsoxr_stream *s)
+{
+    if (s->ext_pending && s->ext_st) (void)hipStreamSynchronize(s->ext_st);
+    s->ext_pending = false;
+}
+
 void hipsoxr_stream_delete(hipsoxr_stream_t *s)
 {
     if (!s) return;
     DeviceGuard guard(s->device);
+    ext_sync(s);
     resident_stop(s);
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->res.box) (void)hipHostFree(s->res.box);
@@ -1178,12 +1191,116 @@ void hipsoxr_stream_delete(hipsoxr_stream_t *s)
 
 static const char *stream_process_inner(hipsoxr_stream *s, const void *in, size_t ilen, void *out, size_t olen, size_t *odone);
 
+// ---- device chunks (hipsoxr_stream_process_device) -----------------------------------------------------------------
+// Same counters, ring, clock and launch as the host path; the chunk arrives by a device-to-device copy, the outputs go
+// straight to the caller's device buffer, and everything is enqueued on the caller's HIP stream (for the duration of
+// the call it stands in for the stream's own).  Nothing waits.
+static const char *device_emit_once(hipsoxr_stream *s, void *d_out, size_t olen, size_t *odone)
+{
+    const Plan &p = s->plan->p;
+    VrState &v = s->vr;
+    if (v.on && v.n_slew && s->k_done >= v.k_s + v.n_slew) { // slew finished: renormalise to a constant segment
+        const uint64_t k1 = v.k_s + v.n_slew;
+        v.t_s = v.pos(k1); v.k_s = k1; v.s0 = v.s1; v.delta = 0; v.n_slew = 0;
+    }
+    const uint64_t k_end = v.on ? vr_k_limit(s, s->ended)
+                                : s->ended ? plan_out_len(p, s->n_in_total) : k_avail(p, s->n_in_total);
+    size_t n = 0;
+    if (k_end > s->k_done) n = (size_t)std::min<uint64_t>(k_end - s->k_done, olen);
+    if (v.on && v.n_slew && s->k_done + n > v.k_s + v.n_slew) n = (size_t)(v.k_s + v.n_slew - s->k_done); // one quadratic per launch
+    *odone = n;
+    if (n == 0) return nullptr;
+    hipsoxr_job_t j;
+    std::memset(&j, 0, sizeof j);
+    j.in = s->in_fill ? s->d_in : d_out; j.out = d_out; j.elem = s->elem;
+    j.kernel = HIPSOXR_KERNEL_EXACT;
+    j.n_clips = 1; j.n_channels = s->ch;
+    j.in_frame_stride = s->ch; j.in_chan_stride = 1;
+    j.out_frame_stride = s->ch; j.out_chan_stride = 1;
+    j.in_abs0 = s->in_base; j.in_frames = (int64_t)s->in_fill;
+    j.out_k0 = (int64_t)s->k_done; j.out_frames = (int64_t)n;
+    j.clip_counter = s->d_clips;
+    j.dither = (s->elem == HIPSOXR_I16 && !(s->flags & HIPSOXR_NO_DITHER)) ? 1u : 0u;
+    j.dither_seed = s->dither_seed;
+    if (v.on) {
+        const i128 T0 = v.pos(s->k_done), S0 = v.step(s->k_done), D = s->k_done < v.k_s + v.n_slew ? v.delta : 0;
+        const VrPos vp = {(uint64_t)((u128)T0 >> 64), (uint64_t)(u128)T0, (uint64_t)((u128)S0 >> 64), (uint64_t)(u128)S0,
+                          (uint64_t)((u128)D >> 64), (uint64_t)(u128)D};
+        if (const char *e = launch_job(&s->plan->p, j, s->st, &vp, nullptr, nullptr)) return e;
+    } else {
+        if (const char *e = launch_job(&s->plan->p, j, s->st, nullptr, nullptr, nullptr)) return e;
+    }
+    s->k_done += n;
+    return nullptr;
+}
+
+static const char *device_process(hipsoxr_stream *s, const void *d_in, size_t ilen, void *d_out, size_t olen, size_t *odone)
+{
+    const size_t frame = (size_t)s->ch * esz(s);
+    if (d_in == nullptr) {
+        s->ended = true;
+    } else if (ilen > 0) {
+        if (s->ended) return "Input after last input";
+        if (s->ring_on_host) { if (const char *e = host_ring_to_device(s)) return e; } // (a ring inherited from a small-chunk stream)
+        if (s->in_fill + ilen > s->in_cap) {
+            const int64_t n0 = first_needed(s);
+            const int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base), s->in_base + (int64_t)s->in_fill);
+            const size_t keep = s->in_fill - (size_t)(keep_from - s->in_base);
+            size_t need = keep + 4 * ilen, cap = std::max<size_t>(s->in_cap, 1024);
+            if (need > ((size_t)1 << 24)) need = keep + ilen;
+            while (cap < need) cap <<= 1;
+            if (const char *e = stream_compact(s, cap)) return e;
+        }
+        if (const char *e = launch_copy((char *)s->d_in + s->in_fill * frame, d_in, ilen * frame, s->st)) return e;
+        s->in_fill += ilen;
+        s->n_in_total += ilen;
+    }
+    size_t total = 0;
+    while (d_out && total < olen) {
+        size_t got = 0;
+        if (const char *e = device_emit_once(s, (char *)d_out + total * frame, olen - total, &got)) return e;
+        total += got;
+        if (!got) break;
+        if (!(s->vr.on && s->vr.n_slew && s->k_done == s->vr.k_s + s->vr.n_slew)) break; // another pass only at the end of a slew
+    }
+    *odone = total;
+    return nullptr;
+}
+
+hipsoxr_error_t hipsoxr_stream_process_device(hipsoxr_stream_t *s, const void *in, size_t ilen, void *out, size_t olen,
+                                              size_t *odone, void *hip_stream)
+{
+    if (!s || !odone) return "null argument";
+    *odone = 0;
+    if (s->split || s->split_io || s->defer || (s->flags & (HIPSOXR_RESIDENT | HIPSOXR_AUTO_RESIDENT)))
+        return "device chunks: interleaved streams without the deferred / resident flags only";
+    DeviceGuard guard(s->device);
+    resident_stop(s);
+    hipStream_t own = s->st, user = (hipStream_t)hip_stream;
+    // Ordering against the stream's OWN HIP stream, where host-pointer calls and the pool put their work: what such calls
+    // left there comes first (one event, only when there was such a call since the last device call); the other way
+    // round — device calls still in flight when a host-pointer call, clear or delete arrives — `ext_sync` waits.
+    if (user != own && s->own_used && s->ev) {
+        HIP_TRY(hipEventRecord(s->ev, own));
+        HIP_TRY(hipStreamWaitEvent(user, s->ev, 0));
+    }
+    s->own_used = false;
+    if (s->ext_st && s->ext_st != user) HIP_TRY(hipStreamSynchronize(s->ext_st)); // (a different caller stream than last time)
+    s->ext_st = user; s->ext_pending = true;
+    s->st = user;
+    const char *err = device_process(s, in, ilen, out, olen, odone);
+    s->st = own;
+    return err;
+}
+
 hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size_t ilen, void *out,
                                        size_t olen, size_t *odone)
 {
     if (!s || !odone) return "null argument";
     DeviceGuard guard(s->device);
     *odone = 0;
+    ext_sync(s);
+    s->own_used = true;
     if (s->split_io && !s->adapt_decided && in && ilen) {
         // first chunk of a split-layout stream: a small one puts the stream on the interleaved small-chunk path for good
         // (its per-channel planes are woven / unwoven at this boundary: a few hundred frames per call); a large one keeps
@@ -1278,6 +1395,7 @@ hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *s)
 {
     if (!s) return "null argument";
     DeviceGuard guard(s->device);
+    ext_sync(s);
     resident_stop(s);
     s->res.mirror_of = nullptr; // (the ring starts over at frame 0: nothing in the device mirror is current)
     if (s->st) (void)hipStreamSynchronize(s->st);
@@ -1312,6 +1430,7 @@ size_t hipsoxr_stream_num_clips(hipsoxr_stream_t *s)
     if (!s) return 0;
     DeviceGuard guard(s->device);
     uint64_t v = 0;
+    ext_sync(s);
     resident_stop(s);
     if (hipMemcpyAsync(&v, s->d_clips, sizeof v, hipMemcpyDeviceToHost, s->st) != hipSuccess) return 0;
     (void)hipStreamSynchronize(s->st);

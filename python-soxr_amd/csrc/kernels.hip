@@ -2900,6 +2900,35 @@ void resident_leave(volatile uint64_t *w, uint32_t epoch)
     __builtin_ia32_sfence();
 }
 
+// a chunk appended to a stream's device ring (engine.cpp device_process): 16 bytes per thread where both ends allow it
+__global__ void __launch_bounds__(256) k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_copy2(uint16_t *__restrict__ dst, const uint16_t *__restrict__ src, size_t n2)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n2) dst[i] = src[i];
+}
+const char *launch_copy(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!bytes) return nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0) {
+        const size_t n = bytes / 16;
+        hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)src, n);
+    } else if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 1) == 0) { // (frames are at least two bytes)
+        const size_t n = bytes / 2;
+        hipLaunchKernelGGL(k_copy2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint16_t *)dst, (const uint16_t *)src, n);
+    } else {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return nullptr;
+    }
+    HIP_TRY(hipGetLastError());
+    return nullptr;
+}
+
 const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr, ResidentLaunch *res, ChainDone *cd)
 {
     if (cd) cd->n_wgs = 0;

@@ -101,6 +101,8 @@ SIGNATURES = {
     "hipsoxr_stream_create_with_plan": (_err, [C.c_void_p, C.c_uint, C.c_int, C.c_ulong, _P(C.c_void_p)]),
     "hipsoxr_stream_process": (_err, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                       _P(C.c_size_t)]),
+    "hipsoxr_stream_process_device": (_err, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             _P(C.c_size_t), C.c_void_p]),
     "hipsoxr_stream_delete": (None, [C.c_void_p]),
     "hipsoxr_stream_clear": (_err, [C.c_void_p]),
     "hipsoxr_stream_delay": (C.c_double, [C.c_void_p]),

@@ -163,65 +163,73 @@ def resample_tensor(plan, x, out=None, kernel=_n.KERNEL_AUTO, dither=False, clip
 class TensorStream:
     """Device-resident counterpart of `ResampleStream` (reference: src/soxr/__init__.py:56-131, CSoxr::process
     src/soxr_ext.cpp:129-187): chunks are torch tensors that already live in HBM, the pending input stays there, and a
-    call is ONE asynchronous launch on the current torch stream — no copy over PCIe, no host synchronisation.
+    call enqueues one device-to-device copy and one launch on the current torch stream — no copy over PCIe, no host
+    synchronisation (`hipsoxr_stream_process_device`: the stream handle's counters, ring and clock, device pointers).
 
         ts = TensorStream(44100, 16000, num_channels=2, dtype=torch.int16, quality="VHQ")
         y = ts.resample_chunk(x_dev)            # x_dev: [frames] (mono) or [frames, channels]
         tail = ts.resample_chunk(x_last, last=True)
 
-    The concatenated output is the one-shot result bit for bit (canonical-order engine: every output is a pure function of
-    absolute positions, so how the signal is cut into calls cannot matter) — the property the reference's
-    test_stream_length / test_divide_match pin for its own streams.  Constant rate; `kernel` may be set to KERNEL_AUTO
-    to let large float chunks take the frequency-domain engine (1e-6 class, then not chunk-invariant to the bit).
-    Like every torch op the call is ordered on the CURRENT stream: use one stream per TensorStream, or synchronise."""
+    The same frames come out of the same calls as from `ResampleStream` on the same input, and the concatenated output
+    is the one-shot result bit for bit (canonical-order engine: every output is a pure function of absolute positions)
+    — the property the reference's test_stream_length / test_divide_match pin for its own streams.  vr=True: a
+    variable-rate stream (`set_io_ratio`), in_rate / out_rate the LARGEST io ratio that will be used.  int16 output is
+    dithered as the host stream's is (dither=False: off).  Like every torch op a call is ordered on the CURRENT
+    stream: use one torch stream per TensorStream, or synchronise."""
 
-    def __init__(self, in_rate, out_rate, num_channels=1, dtype=None, quality="HQ", kernel=_n.KERNEL_EXACT, plan=None,
-                 dither=False):
+    def __init__(self, in_rate, out_rate, num_channels=1, dtype=None, quality="HQ", vr=False, dither=True, dither_seed=0):
         import torch
-        self.plan = plan if plan is not None else Plan(in_rate, out_rate, quality)
+        if in_rate <= 0 or out_rate <= 0:
+            raise ValueError("Sample rate should be over 0")
         if num_channels < 1 or num_channels > 65536:
             raise ValueError("Invalid number of channels")
         self.channels = int(num_channels)
         self.dtype = torch.float32 if dtype is None else dtype
         self._elem = _torch_elem(self.dtype)
-        self._kernel, self._dither = kernel, bool(dither)
-        self._H = self.plan.taps // 2
-        j = _n.Job()
-        j.elem, j.kernel, j.n_clips, j.n_channels = self._elem, kernel, 1, self.channels
-        j.in_clip_stride, j.in_frame_stride, j.in_chan_stride = 0, self.channels, 1
-        j.out_clip_stride, j.out_frame_stride, j.out_chan_stride = 0, self.channels, 1
-        j.dither, j.dither_seed = int(bool(dither)), 0
-        self._job, self._job_ref = j, _C.byref(j)
-        self._buf = None
-        self._clips = None
-        self.clear()
+        self._ratio = float(out_rate) / float(in_rate)
+        self._h = _C.c_void_p()
+        flags = (_n.VR if vr else 0) | (0 if dither else _n.NO_DITHER)
+        _n.check(_n.lib.hipsoxr_stream_create(float(in_rate), float(out_rate), self.channels, self._elem,
+                                              _quality_to_enum(quality), flags, _C.byref(self._h)))
+        if dither_seed:
+            _n.check(_n.lib.hipsoxr_stream_set_dither_seed(self._h, int(dither_seed) & 0xFFFFFFFF))
+        self._vr = bool(vr)
+        self._done = _C.c_size_t(0)
+        self._done_ref = _C.byref(self._done)
+        self._ended = False
+        info = _n.PlanInfo()
+        _n.check(_n.lib.hipsoxr_plan_info(_n.lib.hipsoxr_stream_plan(self._h), _C.byref(info)))
+        # frames a constant-rate call can return at most: what the chunk adds plus what was pending before it
+        self._slack = int((info.taps / 2 + 2) * self._ratio) + 4
+        self._min_io = 1.0 / self._ratio  # (variable rate: the smallest io ratio requested so far bounds a call's output)
+
+    def __del__(self, _delete=_n.lib.hipsoxr_stream_delete):  # bound early: module globals may be gone at exit
+        h = getattr(self, "_h", None)
+        if h:
+            _delete(h)
+            self._h = None
 
     def clear(self):
         """Fresh signal: pending input and counters are dropped (reference: ResampleStream.clear)."""
-        self._base = 0        # absolute index of _buf[0]
-        self._fill = 0        # frames held in _buf
-        self._n_in = 0        # frames fed so far
-        self._k_done = 0      # outputs produced so far
+        _n.check(_n.lib.hipsoxr_stream_clear(self._h))
         self._ended = False
-
-    def _k_avail(self):
-        """Outputs computable from the frames fed so far without zero-extension (engine.cpp k_avail): output k needs
-        inputs up to floor(k*M/L) + T/2."""
-        q = self._n_in - 1 - self._H
-        if q < 0:
-            return 0
-        return ((q + 1) * self.plan.L - 1) // self.plan.M + 1
-
-    def _first_needed(self, k):
-        return k * self.plan.M // self.plan.L - (self._H - 1)
 
     def delay(self):
         """Output frames still owed for the input fed so far (reference: ResampleStream.delay)."""
-        return max(0.0, self._n_in * self.plan.L / self.plan.M - self._k_done)
+        return float(_n.lib.hipsoxr_stream_delay(self._h))
 
     def num_clips(self):
-        """Integer outputs that saturated (device counter; synchronises)."""
-        return int(self._clips.item()) if self._clips is not None else 0
+        """Integer outputs that saturated (reads a device counter: synchronises)."""
+        return int(_n.lib.hipsoxr_stream_num_clips(self._h))
+
+    def set_io_ratio(self, in_rate, out_rate, slew_len=0):
+        """Variable-rate streams: move to in_rate / out_rate over slew_len output frames (reference:
+        ResampleStream.set_io_ratio, src/soxr/__init__.py:162-179)."""
+        if in_rate <= 0 or out_rate <= 0:
+            raise ValueError("Sample rate should be over 0")
+        io = float(in_rate) / float(out_rate)
+        _n.check(_n.lib.hipsoxr_stream_set_io_ratio(self._h, io, int(slew_len)))
+        self._min_io = min(self._min_io, io)
 
     def resample_chunk(self, x, last=False):
         import torch
@@ -231,44 +239,30 @@ class TensorStream:
             raise RuntimeError("TensorStream needs device tensors (ResampleStream is the host-array surface)")
         if x.dtype != self.dtype:
             raise TypeError(f"Data type mismatch: stream is {self.dtype}, chunk is {x.dtype}")
-        x2 = x[:, None] if x.ndim == 1 else x
-        if x2.ndim != 2 or x2.shape[1] != self.channels or (x.ndim == 1 and self.channels != 1):
+        if x.ndim not in (1, 2) or (x.ndim == 1 and self.channels != 1) or (x.ndim == 2 and x.shape[1] != self.channels):
             raise ValueError("Input must be [frames] for one channel or [frames, channels]")
-        ch, n = self.channels, int(x2.shape[0])
-        if self._buf is None or self._buf.device != x.device:
-            self._buf = torch.empty((max(4096, 4 * n + self.plan.taps), ch), dtype=self.dtype, device=x.device)
-            if self.dtype in (torch.int16, torch.int32):
-                self._clips = torch.zeros(1, dtype=torch.int64, device=x.device)
-        if self._fill + n > self._buf.shape[0]:
-            # retire what no future output needs; grow only if that is not enough (all on the current stream)
-            keep_from = min(max(self._first_needed(self._k_done), self._base), self._base + self._fill)
-            drop, keep = keep_from - self._base, self._base + self._fill - keep_from
-            cap = self._buf.shape[0]
-            while cap < keep + 4 * n:
-                cap *= 2
-            if cap != self._buf.shape[0]:
-                nb = torch.empty((cap, ch), dtype=self.dtype, device=x.device)
-                nb[:keep] = self._buf[drop:drop + keep]
-                self._buf = nb
-            elif keep:
-                self._buf[:keep] = self._buf[drop:drop + keep].clone()
-            self._base, self._fill = keep_from, keep
-        if n:
-            self._buf[self._fill:self._fill + n] = x2
-            self._fill += n
-            self._n_in += n
+        if not x.is_contiguous():
+            x = x.contiguous()
+        ch, n = self.channels, int(x.shape[0])
+        if self._vr:
+            cap = int(_n.lib.hipsoxr_stream_delay(self._h) + n / self._min_io) + 4
+        else:
+            cap = int(n * self._ratio) + self._slack
+        out = torch.empty((cap,) if x.ndim == 1 else (cap, ch), dtype=self.dtype, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        fn, done = _n.lib.hipsoxr_stream_process_device, self._done
+        err = fn(self._h, x.data_ptr() if n else out.data_ptr(), n, out.data_ptr(), cap, self._done_ref, stream)
+        if err:
+            _n.check(err)
+        pos = done.value
         if last:
             self._ended = True
-        k_end = self.plan.out_len(self._n_in) if last else self._k_avail()
-        m = max(0, k_end - self._k_done)
-        out = torch.empty((m, ch), dtype=self.dtype, device=x.device)
-        if m:
-            j = self._job  # (the descriptor is kept: a call changes five of its fields)
-            j.in_, j.out = self._buf.data_ptr(), out.data_ptr()
-            j.in_abs0, j.in_frames, j.out_k0, j.out_frames = self._base, self._fill, self._k_done, m
-            j.clip_counter = self._clips.data_ptr() if self._clips is not None else None
-            err = _n.lib.hipsoxr_run_device(self.plan.handle, self._job_ref, torch.cuda.current_stream(x.device).cuda_stream)
-            if err:
-                _n.check(err)
-            self._k_done = k_end
-        return out[:, 0] if x.ndim == 1 else out
+            row = ch * x.element_size()
+            while True:  # flush until the stream runs dry (src/soxr_ext.cpp:109-127)
+                if pos >= out.shape[0]:
+                    out = torch.cat([out, torch.empty_like(out)])
+                _n.check(fn(self._h, None, 0, out.data_ptr() + pos * row, out.shape[0] - pos, self._done_ref, stream))
+                if done.value == 0:
+                    break
+                pos += done.value
+        return out[:pos]

@@ -33,15 +33,9 @@ def test_tensor_stream_equals_oneshot_and_host_stream(soxr, dtype, rates, qualit
         assert y.is_cuda and y.dtype == xd.dtype and (y.ndim == xd.ndim)
         got.append(y.cpu().numpy())
         host.append(rs.resample_chunk(x[a:b], last=last))
-        if dtype != np.int16:  # (int16: the host stream dithers by default, the device job only on request)
-            assert np.array_equal(got[-1], host[-1]), (a, b)                     # same frames in the same calls
+        assert np.array_equal(got[-1], host[-1]), (a, b)                         # same frames in the same calls
     got = np.concatenate(got)
-    if dtype == np.int16:
-        xd_all = dev.resample_tensor(dev.Plan(rates[0], rates[1], quality), xd, kernel=dev.KERNEL_EXACT).cpu().numpy()
-        assert np.array_equal(got, xd_all)
-        assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 2    # dither: within an LSB or two
-    else:
-        assert got.shape == want.shape and np.array_equal(got, want)
+    assert got.shape == want.shape and np.array_equal(got, want)
     assert ts.delay() < 1.0
     with pytest.raises(RuntimeError):
         ts.resample_chunk(xd[:10])                                               # input after the last input
@@ -62,7 +56,6 @@ def test_tensor_stream_long_run_retires_input(soxr):
     parts = [ts.resample_chunk(xd[a:a + 441], last=(a + 441 >= len(x))) for a in range(0, len(x), 441)]
     got = torch.cat(parts).cpu().numpy()
     assert np.array_equal(got, soxr.resample(x, 44100, 16000, quality="VHQ"))
-    assert ts._buf.shape[0] <= 8192
 
 
 def test_tensor_stream_clip_counter_and_errors(soxr):
@@ -74,10 +67,59 @@ def test_tensor_stream_clip_counter_and_errors(soxr):
     ts.resample_chunk(x, last=True)
     rs = soxr.ResampleStream(48000, 44100, 1, dtype="int16", quality="VHQ")
     rs.resample_chunk(x.cpu().numpy(), last=True)
-    assert ts.num_clips() > 0 and abs(ts.num_clips() - rs.num_clips()) <= rs.num_clips() // 10 + 2   # (the host stream dithers)
+    assert ts.num_clips() > 0 and ts.num_clips() == rs.num_clips()
     with pytest.raises(TypeError):
         dev.TensorStream(48000, 44100, 1, dtype=torch.int16).resample_chunk(x.float())
     with pytest.raises(RuntimeError):
         dev.TensorStream(48000, 44100, 1, dtype=torch.float32).resample_chunk(torch.zeros(10))
     with pytest.raises(ValueError):
         dev.TensorStream(48000, 44100, 2, dtype=torch.float32).resample_chunk(torch.zeros(10, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int16, np.float64])
+def test_tensor_stream_variable_rate_equals_host_stream(soxr, dtype):
+    """vr=True: the stream handle's own Q64.64 clock serves device chunks too — the same frames in the same calls as the host
+    stream (which tests/test_gpu_vr.py pins to the oracle), across jumps, slews, a change during a slew, small and large
+    chunks (k_chain / k_interp_wave)."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(23)
+    x = _sig(rng, (160000, 2), dtype)
+    xd = torch.from_numpy(x).cuda()
+    ts = dev.TensorStream(44100, 16000, 2, dtype=xd.dtype, quality="VHQ", vr=True)
+    rs = soxr.ResampleStream(44100, 16000, 2, dtype=dtype, quality="VHQ", vr=True)
+    cuts = [0, 441, 882, 5000, 45000, 45000, 46000, 90000, 120000, 160000]
+    changes = {2: (44100, 22050, 300), 3: (5, 2, 0), 5: (44100, 30000, 4000), 6: (44100, 16000, 50), 7: (1, 1, 1000)}
+    total = 0
+    for c, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if c in changes:
+            ts.set_io_ratio(*changes[c])
+            rs.set_io_ratio(*changes[c])
+        last = b == cuts[-1]
+        y = ts.resample_chunk(xd[a:b], last=last).cpu().numpy()
+        w = rs.resample_chunk(x[a:b], last=last)
+        assert y.shape == w.shape and np.array_equal(y, w), (c, a, b)
+        total += len(y)
+    assert total > 60000 and ts.delay() < 2
+    with pytest.raises(RuntimeError):
+        dev.TensorStream(44100, 16000, 1, dtype=torch.float32).set_io_ratio(2, 1)   # needs vr=True
+
+
+def test_tensor_stream_on_a_side_stream_and_mixed_with_host_calls(soxr):
+    """A call is ordered on the CURRENT torch stream; host-pointer calls on the same handle (its own HIP stream) are
+    ordered against device calls by events."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(24)
+    x = _sig(rng, (60000,), np.float32)
+    want = soxr.resample(x, 48000, 44100, quality="VHQ")
+    side = torch.cuda.Stream()
+    ts = dev.TensorStream(48000, 44100, 1, dtype=torch.float32, quality="VHQ")
+    parts = []
+    with torch.cuda.stream(side):
+        xd = torch.from_numpy(x).cuda()
+        for a in range(0, 60000, 7000):
+            parts.append(ts.resample_chunk(xd[a:a + 7000], last=(a + 7000 >= 60000)))
+        y = torch.cat(parts)
+    side.synchronize()
+    assert np.array_equal(y.cpu().numpy(), want)
