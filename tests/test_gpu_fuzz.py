@@ -50,3 +50,11 @@ def test_device_api_exact_engine_random_cases_bit_identical():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_device_exact.py"), "200", "41"],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_device_chunk_streams_equal_host_streams():
+    """tests/fuzz/fuzz_device_stream.py: TensorStream (hipsoxr_stream_process_device) against ResampleStream on random rate
+    pairs, recipes, dtypes, channel counts, constant and variable rate, chunk sizes 0 .. 30 000 — bit for bit per call."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_device_stream.py"), "120", "51"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
