@@ -459,6 +459,24 @@ def configs4_stream(seconds=20):
             dt = time.perf_counter() - t0
             out[f"device_chunk{chunk}"] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls, "Msamples_per_s": len(x) / dt / 1e6,
                                            "note": "chunks and results are device tensors; one sync after the last call"}
+        # many live streams in lock step are the CHANNELS of one handle (channels are independent columns): 128 of them,
+        # 10 ms chunks each, one copy kernel and one launch per call for all
+        nch = 128
+        xm = (torch.randn((441 * 400, nch), device="cuda") * 5000).to(torch.int16)
+        ts = dev.TensorStream(44100, 16000, nch, dtype=torch.int16, quality="VHQ")
+        ts.resample_chunk(xm[:441])
+        ts.clear()
+        torch.cuda.synchronize()
+        n_calls = 0
+        t0 = time.perf_counter()
+        for a in range(0, xm.shape[0], 441):
+            ts.resample_chunk(xm[a:a + 441], last=(a + 441 >= xm.shape[0]))
+            n_calls += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["device_chunk441_x128_streams"] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls, "streams": nch,
+                                               "Msamples_per_s": xm.numel() / dt / 1e6,
+                                               "note": "128 lock-step mono streams as the channels of one handle, 441-frame chunks"}
     except Exception as e:  # noqa: BLE001
         out["device_stream"] = {"error": str(e)}
     return out
