@@ -96,6 +96,8 @@ struct Switches {
     bool no_tile_split = false;   // HIPSOXR_NO_TILE_SPLIT    k_tile / k_tile_mfma: never spread a slab's row tiles over several workgroups
     bool no_interp_tile = false;  // HIPSOXR_NO_INTERP_TILE   large interpolated launches on k_interp
     bool no_interp_wave = false;  // HIPSOXR_NO_INTERP_WAVE   mid-size interpolated / variable-rate launches on lane-per-output k_interp
+    bool no_gather_wave = false;  // HIPSOXR_NO_GATHER_WAVE   exact-bank jobs below the tile kernels' size on k_chain / k_gather / the tile kernels as before
+    int dbg_gw_taps = 0;          // HIPSOXR_DEBUG_GW_TAPS    k_gather_wave takes AUTO jobs of up to this many million output x tap products (default 16)
     bool no_two_stage = false;    // HIPSOXR_NO_TWO_STAGE     float device jobs of interpolated-phase plans stay on the exact engine
     // timing experiments on the tile kernels (results may be wrong with dbg_flags != 0)
     int dbg_flags = 0;            // HIPSOXR_DEBUG_FLAGS      1 no staging, 2 no LDS reads, 4 no coefficient loads, 8 no stores

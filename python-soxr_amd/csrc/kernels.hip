@@ -30,6 +30,9 @@
 //   k_interp(_tile) interpolated-phase plans (arbitrary ratios) and variable rate: per tap a cubic in
 //                   the fractional position (Horner FMAs); lane per output (fallback) / outputs sorted by phase
 //                   interval, large launches.
+//   k_gather_wave   exact-bank launches of 4096 outputs and more that the period tiles do not take (too few periods for a
+//                   slab; stream chunks written straight into host memory): a half-chain per QUAD of lanes on the
+//                   phase-major bank, the chain by DPP — in place of lane-per-output k_gather.
 //   k_interp_wave   the same for launches between 512 outputs and what fills the chip (a stream's 96 000-frame
 //                   chunk, 1 s clips), and every large variable-rate launch: a half-chain per QUAD of lanes —
 //                   lane k fetches and evaluates tap 4s + k, the chain takes the four coefficients by DPP.
@@ -73,7 +76,7 @@ const Switches &switches()
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX");
         w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT");
         w.no_interp_tile = on("HIPSOXR_NO_INTERP_TILE"); w.no_two_stage = on("HIPSOXR_NO_TWO_STAGE");
-        w.no_interp_wave = on("HIPSOXR_NO_INTERP_WAVE");
+        w.no_interp_wave = on("HIPSOXR_NO_INTERP_WAVE"); w.no_gather_wave = on("HIPSOXR_NO_GATHER_WAVE"); w.dbg_gw_taps = num("HIPSOXR_DEBUG_GW_TAPS");
         w.dbg_flags = num("HIPSOXR_DEBUG_FLAGS"); w.dbg_nrt = num("HIPSOXR_DEBUG_NRT"); w.dbg_nw = num("HIPSOXR_DEBUG_NW");
         w.dbg_split = num("HIPSOXR_DEBUG_SPLIT"); w.dbg_chain_no = num("HIPSOXR_DEBUG_CHAIN_NO"); w.dbg_lds = (size_t)num("HIPSOXR_DEBUG_LDS");
         w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD");
@@ -357,6 +360,155 @@ __global__ void __launch_bounds__(256) k_interp(InterpArgs ia)
     store_out<Real>(yo, accL + accR, a.oc, ch, a.out_k0 + idx);
 }
 
+// the value lane K of the quad holds, in all four of its lanes (DPP quad_perm)
+template <int K> __device__ __forceinline__ float quad_bcast_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+template <int K> __device__ __forceinline__ double quad_bcast_f(double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)u, K * 0x55, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), K * 0x55, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gather_wave — exact-bank jobs too small to fill the chip with period tiles (a stream's 96 000-frame chunk, 1 s clips)
+// ---------------------------------------------------------------------------------------------
+// The tile kernels share a phase's coefficients among the periods of a slab: 96 000 frames at 44.1k -> 16k are 218 periods
+// = 14 sixteen-period slabs, 14 workgroups on 256 CUs (15.7 us).  k_interp_wave's shape needs no sharing to fill the
+// chip: a half-chain per QUAD of lanes, here with the phase's own row of the phase-major bank [L][T] — lane k holds taps
+// 16 s + 4 k .. + 3 of step s as one 16-byte (float) / 32-byte (double) load, a quad reads 64 / 128 contiguous bytes
+// per step, requested 8 steps ahead; the chain takes the sixteen coefficients in canonical order by DPP.  Same
+// arithmetic per output as k_gather and the tile kernels: bit-identical.
+struct GatherWaveArgs {
+    GatherArgs g;            // .bank unused
+    const void *phase_major; // [L][T] Real
+    int32_t span_cap;        // staged samples per workgroup (>= 31 window shifts + T)
+    uint32_t *done_words;    // (optional) completion words, as ChainArgs::done_words
+    uint32_t done_seq;
+};
+
+template <typename IO, typename Real>
+__global__ void __launch_bounds__(256) k_gather_wave(GatherWaveArgs wa)
+{
+    typedef typename Vec4<Real>::type V4;
+    constexpr int U = 8; // steps (of sixteen taps) requested ahead
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ int64_t s_loc[4];
+    const GatherArgs &a = wa.g;
+    const int lane = threadIdx.x & 63, k = lane & 3, quad = lane >> 2;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), half = wave & 1, grp = wave >> 1;
+    Real *xs = reinterpret_cast<Real *>(smem_raw);
+    Real *accx = xs + wa.span_cap; // [32]
+    const int32_t T = a.T, H = T / 2, NS = (H + 15) / 16; // T is a multiple of 8: H of 4
+    const uint32_t col = blockIdx.y;
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
+    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+
+    const int64_t o = (int64_t)blockIdx.x * 32 + grp * 16 + quad;
+    const int64_t oc = o < a.out_frames ? o : a.out_frames - 1;
+    const int64_t t = a.p0 + oc * a.M, q = t / a.L, ph = t - q * a.L; // (out_k0 + o) * M = L * (d0 + q) + ph
+    const int64_t loc0 = a.d0 + q - (H - 1) - a.in_abs0;
+    if (half == 0 && (lane == 0 || lane == 63)) s_loc[grp * 2 + (lane ? 1 : 0)] = loc0;
+    __syncthreads();
+    const int64_t base = s_loc[0];
+    int32_t span = (int32_t)(s_loc[3] - base) + T;
+    if (span > wa.span_cap) span = wa.span_cap; // (never: the host sized span_cap from M / L)
+    const int32_t rel = (int32_t)(loc0 - base);
+    for (int m = (int)threadIdx.x; m < span; m += 256) {
+        const int64_t l = base + m;
+        xs[m] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+    }
+    __syncthreads();
+
+    const Real *row = (const Real *)wa.phase_major + ph * T;
+    Real acc = 0;
+    auto run = [&](auto half_c) {
+        constexpr bool HALF = decltype(half_c)::value;
+        // step s: taps 16 s .. 16 s + 15 of the first half-chain (upwards), T-1-16 s .. T-16-16 s of the second
+        // (downwards); lane k holds four of them, ascending in memory either way.  Loads are unconditional and clamped
+        // to the last step (a load under a condition is waited for at once: k_interp_wave).  A last step of fewer than
+        // sixteen taps reads past the half-chain, inside the row (T >= 32).
+        auto at = [&](int s_) {
+            const Real *p4 = row + (HALF ? T - 16 * (s_ + 1) : 16 * s_) + 4 * k;
+            return *reinterpret_cast<const V4 *>(p4);
+        };
+        const Real *xp = xs + rel + (HALF ? T - 1 : 0);
+        V4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = at(u < NS ? u : NS - 1);
+        auto four = [&](const V4 c, const Real *xq, auto lane_c) { // the four taps lane M holds, in chain order
+            constexpr int M = decltype(lane_c)::value;
+            if (!HALF) {
+                acc = fma_r(quad_bcast_f<M>(c.x), xq[4 * M + 0], acc);
+                acc = fma_r(quad_bcast_f<M>(c.y), xq[4 * M + 1], acc);
+                acc = fma_r(quad_bcast_f<M>(c.z), xq[4 * M + 2], acc);
+                acc = fma_r(quad_bcast_f<M>(c.w), xq[4 * M + 3], acc);
+            } else { // xq points at the step's HIGHEST tap; lane M's taps sit 15 - 4 M - e below it
+                acc = fma_r(quad_bcast_f<M>(c.w), xq[-(12 - 4 * M) - 0], acc);
+                acc = fma_r(quad_bcast_f<M>(c.z), xq[-(12 - 4 * M) - 1], acc);
+                acc = fma_r(quad_bcast_f<M>(c.y), xq[-(12 - 4 * M) - 2], acc);
+                acc = fma_r(quad_bcast_f<M>(c.x), xq[-(12 - 4 * M) - 3], acc);
+            }
+        };
+        auto chain = [&](const V4 c, int s_, int taps) { // taps: 16, or what is left of the half-chain in its last step
+            const Real *xq = HALF ? xp - 16 * s_ : xp + 16 * s_;
+            if (!HALF) {
+                four(c, xq, std::integral_constant<int, 0>());
+                if (taps > 4) four(c, xq, std::integral_constant<int, 1>());
+                if (taps > 8) four(c, xq, std::integral_constant<int, 2>());
+                if (taps > 12) four(c, xq, std::integral_constant<int, 3>());
+            } else {
+                four(c, xq, std::integral_constant<int, 3>());
+                if (taps > 4) four(c, xq, std::integral_constant<int, 2>());
+                if (taps > 8) four(c, xq, std::integral_constant<int, 1>());
+                if (taps > 12) four(c, xq, std::integral_constant<int, 0>());
+            }
+        };
+        const int full = H / 16; // steps of sixteen taps; a shorter last one follows when H is not a multiple of 16
+        int s0 = 0;
+        for (; s0 + 2 * U <= full; s0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const V4 v = r[u];
+                r[u] = at(s0 + u + U);
+                chain(v, s0 + u, 16);
+            }
+        }
+        for (; s0 + U <= full; s0 += U) { // (the look-ahead reaches the end: clamped)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const V4 v = r[u];
+                const int sn = s0 + u + U;
+                r[u] = at(sn < NS ? sn : NS - 1);
+                chain(v, s0 + u, 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { // fewer than U steps left, already requested; the last may be short
+            const int s_ = s0 + u;
+            if (s_ < full) chain(r[u], s_, 16);
+            else if (s_ < NS) chain(r[u], s_, H - 16 * full);
+        }
+    };
+    if (half) run(std::integral_constant<bool, true>());
+    else run(std::integral_constant<bool, false>());
+    if (half && k == 0) accx[grp * 16 + quad] = acc;
+    __syncthreads();
+    if (!half && k == 0 && o < a.out_frames) {
+        IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + o * a.ofs + (int64_t)ch * a.ochs;
+        store_out<Real>(yo, acc + accx[grp * 16 + quad], a.oc, ch, a.out_k0 + o);
+    }
+    if (wa.done_words) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&wa.done_words[blockIdx.y * gridDim.x + blockIdx.x], wa.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_interp_tile — throughput kernel for interpolated-phase plans and variable-rate launches
 // ---------------------------------------------------------------------------------------------
@@ -465,18 +617,6 @@ struct InterpWaveArgs {
     uint32_t *done_words; // (optional, pinned host memory) completion words, as ChainArgs::done_words
     uint32_t done_seq;
 };
-
-template <int K> __device__ __forceinline__ float quad_bcast_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
-}
-template <int K> __device__ __forceinline__ double quad_bcast_f(double v)
-{
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)u, K * 0x55, 0xf, 0xf, true);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), K * 0x55, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
 
 template <typename IO, typename Real, bool VR>
 __global__ void __launch_bounds__(256) k_interp_wave(InterpWaveArgs wa)
@@ -2347,6 +2487,38 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 wave_ok = wave_lds <= 64 * 1024;
             }
         }
+        // exact-bank launches of 4096 outputs and more that come here (launch_typed: periods too few for a slab, or a
+        // stream chunk whose result goes straight to host memory): k_gather_wave instead of lane-per-output k_gather
+        if (!p->phases && !res && !vr && !switches().no_gather_wave && nf >= 4096 && p->T >= 32 && (uint64_t)j.n_clips * j.n_channels <= 65535) {
+            const int64_t gspan = ((int64_t)(31 * ((p->M + p->L - 1) / p->L + 1)) + p->T + 4 + 3) & ~(int64_t)3; // 31 window shifts of at most ceil(M/L) + T
+            const size_t glds = (size_t)(gspan + 32) * sizeof(Real);
+            if (glds <= 64 * 1024) {
+                DeviceBank &dm = p->dev[sizeof(Real) == 4 ? 0 : 1];
+                const char *err = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(p->mu);
+                    if (!dm.phase_major) {
+                        std::vector<Real> pm(p->bank.size());
+                        for (size_t i = 0; i < pm.size(); ++i) pm[i] = (Real)p->bank[i];
+                        if (hipMalloc(&dm.phase_major, pm.size() * sizeof(Real)) != hipSuccess) err = "hipMalloc failed";
+                        else if (hipMemcpy(dm.phase_major, pm.data(), pm.size() * sizeof(Real), hipMemcpyHostToDevice) != hipSuccess)
+                            err = "hipMemcpy failed";
+                    }
+                }
+                if (err) return err;
+                GatherWaveArgs ga;
+                ga.g = a; ga.phase_major = dm.phase_major; ga.span_cap = (int32_t)gspan; ga.done_words = nullptr; ga.done_seq = 0;
+                const uint64_t wgs = (uint64_t)((nf + 31) / 32) * ((uint64_t)j.n_clips * j.n_channels);
+                if (cd && done == 0 && nf == j.out_frames && wgs <= cd->cap) { // the whole job is this launch
+                    ga.done_words = cd->words; ga.done_seq = cd->seq;
+                    cd->n_wgs = (uint32_t)wgs;
+                }
+                hipLaunchKernelGGL((k_gather_wave<IO, Real>), dim3((unsigned)((nf + 31) / 32), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1),
+                                   dim3(256), glds, st, ga);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
+        }
         // small launches (streaming chunks): the low-latency chain kernel (interpolated plans above 512 outputs: k_interp_wave —
         // 4410-frame variable-rate calls 29.0 -> 27.0 us; 441-frame calls are 2.5 us faster here: 20 short workgroups against 5)
         const bool no_chain = switches().no_chain;
@@ -2827,6 +2999,7 @@ static const char *launch_wave_dot(Plan *p, const hipsoxr_job_t &j, hipStream_t 
     return nullptr;
 }
 
+static constexpr double kGatherWaveTaps = 16e6;
 template <typename IO, typename Real>
 static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st, const VrPos *vr, ResidentLaunch *res = nullptr,
                                 ChainDone *cd = nullptr)
@@ -2857,7 +3030,16 @@ static const char *launch_typed(Plan *p, const hipsoxr_job_t &j, hipStream_t st,
     if (kernel == HIPSOXR_KERNEL_AUTO) {
         // a tile kernel pays off once a job spans a few thousand outputs per column
         const TileGeom &g = gm.ok ? gm : gv;
-        const bool big = g.ok && j.out_frames >= 16 * g.Lc && j.out_frames >= 4096;
+        bool big = g.ok && j.out_frames >= 16 * g.Lc && j.out_frames >= 4096;
+        // ... except for a stream chunk whose result the kernel writes straight into pinned host memory (`cd`: engine.cpp's
+        // direct path) while it is far too small to fill the chip with slabs.  As a kernel k_gather_wave is the slower one
+        // even there (96 000 frames at 44.1k -> 16k: 17.5 against 15.6 us; back to back on device buffers 15.0 against 9.6),
+        // but the CALL is shorter with it — its outputs leave as runs of 16 neighbouring samples, the tiles' as one sample
+        // per lane of a row tile: 20 000-frame int16 calls 35 against 41 us, 48 000-frame 43.5 against 45.6, 96 000-frame
+        // the same (interleaved A/B on one box, tools/gw_time.sh).  Up to kGatherWaveTaps output x tap products.
+        if (big && cd && !switches().no_gather_wave && p->T >= 32 &&
+            (double)j.out_frames * j.n_clips * j.n_channels * p->T < (switches().dbg_gw_taps ? switches().dbg_gw_taps * 1e6 : kGatherWaveTaps))
+            big = false;
         kernel = !big ? HIPSOXR_KERNEL_GATHER : gm.ok ? HIPSOXR_KERNEL_TILE_MFMA : HIPSOXR_KERNEL_TILE_VALU;
     }
     if (kernel == HIPSOXR_KERNEL_TILE_MFMA) return launch_tile<IO, Real>(p, j, st, gm);

@@ -38,6 +38,11 @@ vs = soxr.ResampleStream(44100, 16000, 1, dtype="float32", quality="VHQ", vr=Tru
 v0 = vs.resample_chunk(x1[:20000])
 vs.set_io_ratio(44100, 22050, 700)
 out["stream_vr"] = sha(np.concatenate([v0, vs.resample_chunk(x1[20000:], last=True)]))
+rs = soxr.ResampleStream(44100, 16000, 2, dtype="int16", quality="VHQ")                    # 20 000-frame chunks: k_gather_wave
+xl = (rng.standard_normal((50000, 2)) * 5000).astype(np.int16)
+out["stream_20000"] = sha(np.concatenate([rs.resample_chunk(xl[a:a + 20000], last=(a + 20000 >= len(xl))) for a in range(0, len(xl), 20000)]))
+xg = torch.from_numpy((rng.standard_normal((9000, 3)) * 0.25).astype(np.float32)).cuda()  # forced gather path, >= 4096 outputs
+out["dev_gather"] = sha(dev.resample_tensor(dev.Plan(48000, 44100, "HQ"), xg, kernel=dev.KERNEL_GATHER).cpu().numpy())
 for name, kw in (("stream", {}), ("stream_resident", {"resident": True}), ("stream_deferred", {"deferred": True})):
     rs = soxr.ResampleStream(44100, 16000, 1, dtype="int16", quality="VHQ", **kw)
     parts = [rs.resample_chunk(xi[a:a + 441, 0].copy(), last=(a + 441 >= len(xi))) for a in range(0, len(xi), 441)]
