@@ -65,6 +65,10 @@ void resident_leave(volatile uint64_t *words, uint32_t epoch);
 
 int device_count();
 
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize raised on the function: a driver call, made
+// ONCE per (function, device) — for the largest size a kernel can ask for, 160 KB — never inside the launch path again.
+const char *ensure_dyn_lds(const void *fn, size_t bytes);
+
 // Environment switches, read ONCE per process.  The product library reads four names:
 //   HIPSOXR_NO_FFT, HIPSOXR_RESIDENT, HIPSOXR_AUTO_RESIDENT, HIPSOXR_RESIDENT_IDLE_US.
 // Everything else is an A/B or timing-experiment switch behind the numbers in DESIGN.md / profiles/ and is compiled in

@@ -98,7 +98,7 @@ struct hipsoxr_stream {
     // device chunks (hipsoxr_stream_process_device) run on the CALLER's HIP stream: the last one used, whether work of such
     // calls may still be in flight there, and whether host-pointer calls have used the stream's own since
     hipStream_t ext_st = nullptr;
-    bool ext_pending = false, own_used = false;
+    bool ext_pending = false, own_used = true; // (true: creation enqueues a memset on the stream's own HIP stream)
     // pinned bounce buffers for small chunks: a pageable hipMemcpyAsync is staged by the runtime
     // with a blocking hand-shake per call (~30 us each way); a memcpy into pinned memory + a true
     // async copy costs a few us
@@ -389,10 +389,15 @@ hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *h, const double *src, size
     if (!h || !src) return "null argument";
     if (n != h->p.bank.size()) return "bank size mismatch";
     if (h->cached) return "this plan is shared through the plan cache (it belongs to a stream); create one with hipsoxr_plan_create";
+    // The bank every rank designs for itself is deterministic: installing the root's copy of it (the broadcast's usual
+    // case) changes nothing and keeps every derived table.  A bank that differs becomes the plan's filter for every
+    // engine that reads `bank`; the two-stage form, which samples the analytic prototype, declines the plan from then on.
+    if (std::memcmp(h->p.bank.data(), src, n * sizeof(double)) == 0) return nullptr;
     device_bank_release(&h->p);
     fft_release(&h->p);
     twostage_release(&h->p);
     std::memcpy(h->p.bank.data(), src, n * sizeof(double));
+    h->p.custom_bank = true;
     return nullptr;
 }
 
@@ -431,9 +436,13 @@ hipsoxr_error_t hipsoxr_plan_broadcast(hipsoxr_plan_t *h, void *nccl_comm, int r
             std::vector<double> got(n);
             if (hipMemcpyAsync(got.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) { err = "hipMemcpy failed"; break; }
-            device_bank_release(&h->p);
-            fft_release(&h->p);
-            h->p.bank.swap(got);
+            if (std::memcmp(h->p.bank.data(), got.data(), n * sizeof(double)) != 0) { // (see hipsoxr_plan_set_bank)
+                device_bank_release(&h->p);
+                fft_release(&h->p);
+                twostage_release(&h->p);
+                h->p.bank.swap(got);
+                h->p.custom_bank = true;
+            }
         } else if (hipStreamSynchronize(st) != hipSuccess) {
             err = "hip sync failed";
         }

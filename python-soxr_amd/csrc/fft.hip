@@ -23,14 +23,13 @@
 //                   FFT -> *H -> truncate -> inverse FFT (the chain is linear and real-to-real; H is real); compile-time
 //                   three-pass schedules for the standard audio ratios; unit-stride columns (mono, planar, batches):
 //                   raw buffer loads with the hardware range check, output runs staged through LDS and stored as
-//                   16-byte granules.  P = pairs per workgroup: P = 2 runs two pairs in one instruction stream — one
-//                   set of twiddle powers and filter values serves both, and the LDS traffic of one pair flies behind
-//                   the butterflies of the other.  float32, float64 and float32-on-float64 instances.
+//                   16-byte granules.  float32, float64 and float32-on-float64 instances.
 //   k_fft_strided2  the same chain for columns with a frame stride: interleaved data paired by channel (CP = true:
 //                   one (Real, Real) word per frame) or strided columns paired by block (CP = false).
 // Build switches: -DFFT2_TRACE (per-wave s_memtime stamps of k_fft_pair2, tools/trace_pair2.py).  The experiments of
-// rounds 1-3 (first-generation kernel, resident workgroups + queue, LDS-DMA staging, wave-local DIF schedule, early
-// table loads, interleaved stores, ablation bits) are in git history (tag r3-fft-experiments) and profiles/r03_*.
+// rounds 1-4 (first-generation kernel, resident workgroups + queue, LDS-DMA staging, wave-local DIF schedule, early
+// table loads, interleaved stores, ablation bits; two block pairs per workgroup, hand-packed complex arithmetic, the
+// thread-count sweep) are in git history (tags r3-fft-experiments, r4-fft-experiments) and profiles/r03_* / r04_*.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -61,41 +60,18 @@ template <typename C> using real_of = decltype(C().x);
 template <typename C> __device__ __forceinline__ C cadd(C a, C b) { return C(a.x + b.x, a.y + b.y); }
 template <typename C> __device__ __forceinline__ C csub(C a, C b) { return C(a.x - b.x, a.y - b.y); }
 template <typename C> __device__ __forceinline__ C cmul(C a, C b) { return C(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-template <typename C> __device__ __forceinline__ C cmulk(C a, C k) { return C(a.x * k.x - a.y * k.y, a.x * k.y + a.y * k.x); } // k: a compile-time constant (literal operands)
+// k: a compile-time constant.  Explicit fused forms with the NEGATED constant as the multiplier, so that every product is
+// a VOP2 instruction with a literal (v_mul / v_fmac): left to itself the compiler turns `x * kx - y * ky` into
+// v_fma(x, kx, -t), whose negated addend forces the VOP3 encoding with the constant in an SGPR — half issue rate on
+// gfx950 (tools/ubench/valu_ops.hip).
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename C> __device__ __forceinline__ C cmulk(C a, C k) { const real_of<C> nky = -k.y; return C(fma_(a.y, nky, a.x * k.x), fma_(a.y, k.x, a.x * k.y)); }
+// k = (h, +-h) (an odd eighth of a turn): two sums and two products
+template <typename C> __device__ __forceinline__ C cmul_h(C a, real_of<C> h, bool pos) { return pos ? C(h * (a.x - a.y), h * (a.x + a.y)) : C(h * (a.x + a.y), h * (a.y - a.x)); }
 // a + SIGN i b,  a - SIGN i b
 template <int SIGN, typename C> __device__ __forceinline__ C cadd_i(C a, C b) { return SIGN > 0 ? C(a.x - b.y, a.y + b.x) : C(a.x + b.y, a.y - b.x); }
 template <int SIGN, typename C> __device__ __forceinline__ C csub_i(C a, C b) { return cadd_i<-SIGN>(a, b); }
-#ifdef FFT_PK // experiment: float32 complex arithmetic on the packed instructions, one (re, im) register pair per operand
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-#define FFT_V2(x) __builtin_bit_cast(v2f_t, x)
-__device__ __forceinline__ float2 cadd(float2 a, float2 b)
-{
-    v2f_t d;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b)));
-    return __builtin_bit_cast(float2, d);
-}
-__device__ __forceinline__ float2 csub(float2 a, float2 b)
-{
-    v2f_t d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b)));
-    return __builtin_bit_cast(float2, d);
-}
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
-{
-    v2f_t t, d;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(FFT_V2(a)), "v"(FFT_V2(b)));                                     // (a.x b.x, a.y b.x)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b)), "v"(t)); // (-a.y b.y + t.x, a.x b.y + t.y)
-    return __builtin_bit_cast(float2, d);
-}
-template <int SIGN> __device__ __forceinline__ float2 cadd_i(float2 a, float2 b)
-{
-    v2f_t d;
-    if (SIGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b))); // (a.x - b.y, a.y + b.x)
-    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(FFT_V2(a)), "v"(FFT_V2(b)));          // (a.x + b.y, a.y - b.x)
-    return __builtin_bit_cast(float2, d);
-}
-template <int SIGN> __device__ __forceinline__ float2 csub_i(float2 a, float2 b) { return cadd_i<-SIGN>(a, b); }
-#endif
 template <typename C> __device__ __forceinline__ C cconj(C a) { return C(a.x, -a.y); }
 // multiply by SIGN * i
 template <int SIGN, typename C> __device__ __forceinline__ C cmuli(C a)
@@ -141,11 +117,11 @@ template <int SIGN, typename C> __device__ __forceinline__ void dft16(C *u)
         x[a][0] = v0; x[a][1] = v1; x[a][2] = v2; x[a][3] = v3;
     }
     // twiddle x[a][b] *= w16^(a*b), w16 = exp(SIGN * 2 pi i / 16)
-    const C w1 = C(c1, sg * s1), w2 = C(h, sg * h), w3 = C(s1, sg * c1);
-    const C w4 = C((T)0, sg), w6 = C(-h, sg * h), w9 = C(-c1, -sg * s1);
-    x[1][1] = cmulk(x[1][1], w1); x[1][2] = cmulk(x[1][2], w2); x[1][3] = cmulk(x[1][3], w3);
-    x[2][1] = cmulk(x[2][1], w2); x[2][2] = cmulk(x[2][2], w4); x[2][3] = cmulk(x[2][3], w6);
-    x[3][1] = cmulk(x[3][1], w3); x[3][2] = cmulk(x[3][2], w6); x[3][3] = cmulk(x[3][3], w9);
+    // (w2 = (h, sg h), w4 = sg i, w6 = (-h, sg h) = sg i w2: the forms without a general complex product)
+    const C w1 = C(c1, sg * s1), w3 = C(s1, sg * c1), w9 = C(-c1, -sg * s1);
+    x[1][1] = cmulk(x[1][1], w1); x[1][2] = cmul_h(x[1][2], h, SIGN > 0); x[1][3] = cmulk(x[1][3], w3);
+    x[2][1] = cmul_h(x[2][1], h, SIGN > 0); x[2][2] = cmuli<SIGN>(x[2][2]); x[2][3] = cmuli<SIGN>(cmul_h(x[2][3], h, SIGN > 0));
+    x[3][1] = cmulk(x[3][1], w3); x[3][2] = cmuli<SIGN>(cmul_h(x[3][2], h, SIGN > 0)); x[3][3] = cmulk(x[3][3], w9);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         C v0 = x[0][b], v1 = x[1][b], v2 = x[2][b], v3 = x[3][b];
@@ -170,13 +146,17 @@ template <int R, int SIGN, typename C> __device__ __forceinline__ void dft_odd(C
     out[0] = sum;
 #pragma unroll
     for (int m = 1; m <= Hh; ++m) {
-        C A = x0, B = C((T)0, (T)0);
+        // (B starts from its first PRODUCT, not from 0 + product: `fma(sn, d, 0)` cannot be folded — signed zeros — and
+        //  becomes a v_fma_f32 with the constant in an SGPR, which issues at half rate on gfx950; a plain product takes
+        //  the constant as a literal)
+        C A = x0, B;
 #pragma unroll
         for (int t = 1; t <= Hh; ++t) {
             const T c = (T)__builtin_cos(PI2 * (double)((m * t) % R) / R);
             const T sn = (T)__builtin_sin(PI2 * (double)((m * t) % R) / R);
-            A.x += c * s[t - 1].x; A.y += c * s[t - 1].y;
-            B.x += sn * d[t - 1].x; B.y += sn * d[t - 1].y;
+            A.x = fma_(c, s[t - 1].x, A.x); A.y = fma_(c, s[t - 1].y, A.y); // (explicit: `x + y * -k` would be rewritten as x - y * k, a VOP3 form again)
+            if (t == 1) { B.x = sn * d[0].x; B.y = sn * d[0].y; }
+            else { B.x = fma_(sn, d[t - 1].x, B.x); B.y = fma_(sn, d[t - 1].y, B.y); }
         }
         out[m] = cadd_i<SIGN>(A, B);     // A + SIGN i B
         out[R - m] = csub_i<SIGN>(A, B);
@@ -274,23 +254,24 @@ __device__ __forceinline__ void fft_pass(cf *buf, int N, int Ns, const cf *W)
     __syncthreads();
 }
 
-// Compile-time specialised pass (N, Ns, R constants): no divisions, fully unrolled, over P transforms that share the
-// schedule — butterfly j of every transform sits in the same thread, so one set of twiddle powers serves all P.
-// `load(p, n, t)` supplies element n of transform p's pass input (t: which of the butterfly's inputs; LDS, or global
-// memory for the first pass) and `store(p, n, v)` consumes element n of its pass output (LDS, or the staging layout for
-// the last pass), so the first pass streams straight from HBM without an extra LDS round trip.
+// Compile-time specialised pass (N, Ns, R constants): no divisions, fully unrolled.
+// `load(j, t)` supplies input t of butterfly j — element j + t * N/R of the pass input (LDS, or global memory for the
+// first pass) — and `store(o, t, v)` consumes element o + t * Ns of its output (LDS, or the staging layout for the last
+// pass), so the first pass streams straight from HBM without an extra LDS round trip.  Loaders and storers get the
+// butterfly's own index and the COMPILE-TIME input number apart: everything that depends on t alone (offsets, which side
+// of the spectrum a bin is on) folds into immediates, and a thread's addresses are a base register plus a constant.
 // The in-place barrier stands straight behind the pass's LDS reads, not behind its butterflies: what it must guarantee
 // is that every thread HOLDS its inputs, not that it has finished computing.
 // Twiddles: any power formed from ONE rounded table entry inherits t times its phase error ((w(1+e))^t ~ w^t (1+te)),
 // so for the large radices a second entry, w^4, is read and w^(4a+b) = (w^4)^a w^b: the error factor drops from R-1 to
 // <= a+b for the same number of complex products (engine error 3.5e-7 -> 2.2e-7 relative RMS).
-template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, int P, typename C, typename Load, typename Store>
+template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, typename C, typename Load, typename Store>
 __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store)
 {
     constexpr int nb = N / R, wstep = N / (Ns * R), NB = (nb + NT - 1) / NT;
     typedef real_of<C> T;
     const int tid = (int)threadIdx.x;
-    C u[P][NB][R];
+    C u[NB][R];
     C w1s[NB], w4s[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -301,9 +282,7 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store)
             if (Ns > 1) w1s[i] = W[k * wstep];
             if (Ns > 1 && R >= 10) w4s[i] = W[4 * k * wstep]; // 4*k*wstep < 4N/R <= N
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int t = 0; t < R; ++t) u[p][i][t] = load(p, j + t * nb, t);
+            for (int t = 0; t < R; ++t) u[i][t] = load(j, t);
         }
     }
     if (SYNC_BEFORE_STORE) __syncthreads(); // in place: every input of the pass is in registers
@@ -312,8 +291,8 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store)
         const int j = tid + i * NT;
         if (NB * NT == nb || j < nb) {
             const int k = j % Ns, o = (j - k) * R + k;
-            C pw[R];
             if (Ns > 1) {
+                C pw[R];
                 const C w1 = w1s[i];
                 pw[1] = w1;
                 if constexpr (R >= 10) {
@@ -329,17 +308,12 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store)
 #pragma unroll
                     for (int t = 2; t < R; ++t) pw[t] = (t & 1) ? cmul(pw[t - 1], w1) : cmul(pw[t / 2], pw[t / 2]);
                 }
+#pragma unroll
+                for (int t = 1; t < R; ++t) u[i][t] = cmul(u[i][t], pw[t]);
             }
+            dft_r<R, SIGN>(u[i]);
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                if (Ns > 1) {
-#pragma unroll
-                    for (int t = 1; t < R; ++t) u[p][i][t] = cmul(u[p][i][t], pw[t]);
-                }
-                dft_r<R, SIGN>(u[p][i]);
-#pragma unroll
-                for (int t = 0; t < R; ++t) store(p, o + t * Ns, u[p][i][t]);
-            }
+            for (int t = 0; t < R; ++t) store(o, t, u[i][t]);
         }
     }
 }
@@ -348,7 +322,11 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store)
 // LDS bank conflicts: pass loads are contiguous across lanes (conflict-free); pass stores run in groups of Ns consecutive
 // elements, so only the FIRST pass (Ns = 1: lane stride = R0 elements) can conflict.  An odd-ish R0 (5, 21: stride 40 /
 // 168 bytes) is conflict-free as it is; for R0 = 16 (stride 128 bytes = every lane on the same two banks) the buffer
-// between pass 1 and pass 2 is kept in a swizzled layout  n -> n ^ ((n >> 4) & 15)  (SWZ).
+// between pass 1 and pass 2 is kept in a swizzled layout  n -> n ^ ((n >> 4) & 15)  (SWZ).  What the swizzle costs in
+// address arithmetic (round 5): pass 1 stores element t of butterfly j at 16 j + (t ^ (j & 15)) — one XOR per element;
+// pass 2 reads element j + t * N/R1, whose mask ((j >> 4) + t * N/(16 R1)) & 15 takes only 16 / gcd(16, N/(16 R1))
+// different values over t (four for 5120 = 16 * 16 * 20): that many base addresses per thread, every read an immediate
+// offset from one of them (it was an add, a shift-and-mask and an XOR per element: 65 -> 16 vector instructions).
 #ifdef FFT2_TRACE
 #define FFT_STAMP() do { if (g_tr && (threadIdx.x & 63) == 0 && g_tri < 16) g_tr[g_tri] = __builtin_amdgcn_s_memtime(); ++g_tri; } while (0)
 #define FFT_STAMP_DECL unsigned long long *g_tr, int &g_tri,
@@ -358,26 +336,38 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store)
 #define FFT_STAMP_DECL
 #define FFT_STAMP_ARGS
 #endif
-// buf(p) = transform p's LDS buffer
-template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, bool LASTSYNC, int P, typename C, typename Buf, typename Load, typename Store>
-__device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL Buf buf, const C *W, Load first_load, Store last_store, bool first_in_lds)
+// (last_store_alt / use_alt: a second form of the last pass's consumer behind ONE wave-uniform branch around the whole pass)
+template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, bool LASTSYNC, typename C, typename Load, typename Store, typename StoreAlt>
+__device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL C *buf, const C *W, Load first_load, Store last_store, bool first_in_lds, StoreAlt last_store_alt,
+                                        bool use_alt)
 {
     static_assert(R0 * R1 * R2 == N, "radix schedule");
-    auto lds_load = [&](int p, int n, int) -> C { return buf(p)[n]; };
-    auto lds_store = [&](int p, int n, C v) { buf(p)[n] = v; };
-    auto swz_load = [&](int p, int n, int) -> C { return buf(p)[SWZ ? n ^ ((n >> 4) & 15) : n]; };
-    auto swz_store = [&](int p, int n, C v) { buf(p)[SWZ ? n ^ ((n >> 4) & 15) : n] = v; };
+    static_assert(!SWZ || R0 == 16, "the swizzled layout is the radix-16 first pass's");
+    constexpr int nb1 = N / R1, nb2 = N / R2;
+    auto lds_load2 = [&](int j, int t) -> C { return buf[j + t * nb2]; };
+    auto lds_store1 = [&](int o, int t, C v) { buf[o + t * R0] = v; };
+    auto swz_load = [&](int j, int t) -> C {
+        if constexpr (!SWZ) return buf[j + t * nb1];
+        else if constexpr (nb1 % 16 == 0) // the element's row (n >> 4) = (j >> 4) + t * nb1 / 16: its low four bits repeat over t
+            return buf[(j & ~15) + t * nb1 + ((j & 15) ^ (((j >> 4) + ((t * (nb1 / 16)) & 15)) & 15))];
+        else { const int n = j + t * nb1; return buf[n ^ ((n >> 4) & 15)]; }
+    };
+    auto swz_store = [&](int o, int t, C v) { // pass 0: Ns = 1, o = R0 j
+        if constexpr (SWZ) buf[o + (t ^ ((o >> 4) & 15))] = v;
+        else buf[o + t] = v;
+    };
     // pass 0 (Ns = 1): when its input is not in LDS nothing has to be protected before storing
-    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true, P>(W, first_load, swz_store);
-    else fft_pass_ct<N, 1, R0, SIGN, NT, false, P>(W, first_load, swz_store);
+    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, swz_store);
+    else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, swz_store);
     FFT_STAMP();
     __syncthreads();
     FFT_STAMP();
-    fft_pass_ct<N, R0, R1, SIGN, NT, true, P>(W, swz_load, lds_store);
+    fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, swz_load, lds_store1);
     FFT_STAMP();
     __syncthreads();
     FFT_STAMP();
-    fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC, P>(W, lds_load, last_store);
+    if (use_alt) fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load2, last_store_alt);
+    else fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load2, last_store);
     FFT_STAMP();
 }
 
@@ -526,14 +516,14 @@ __global__ void __launch_bounds__(256, 2) k_fft_block(FftArgs a)
 template <int NA_, int NB_, int NT_, int A0, int A1, int A2, bool ASWZ, int B0, int B1, int B2, bool BSWZ>
 struct PairSpec {
     static constexpr int NA = NA_, NB = NB_, NT = NT_;
-    static constexpr int RA0 = A0, RB0 = B0;
-    template <int P, typename C, typename Buf, typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL Buf b, const C *W, Ld ld, St st)
-    { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ, false, P>(FFT_STAMP_ARGS b, W, ld, st, false); }
-    template <int P, typename C, typename Buf, typename Ld, typename St> static __device__ __forceinline__ void inv(FFT_STAMP_DECL Buf b, const C *W, Ld ld, St st)
-    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, false, P>(FFT_STAMP_ARGS b, W, ld, st, true); }
+    static constexpr int RA0 = A0, RA2 = A2, RB0 = B0, RB2 = B2;
+    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st)
+    { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ, false>(FFT_STAMP_ARGS b, W, ld, st, false, st, false); }
+    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void inv(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st)
+    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, false>(FFT_STAMP_ARGS b, W, ld, st, true, st, false); }
     // last pass stores into LDS in another layout (output staging): all its inputs must be in registers first
-    template <int P, typename C, typename Buf, typename Ld, typename St> static __device__ __forceinline__ void inv_staged(FFT_STAMP_DECL Buf b, const C *W, Ld ld, St st)
-    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, true, P>(FFT_STAMP_ARGS b, W, ld, st, true); }
+    template <typename C, typename Ld, typename St, typename StAlt> static __device__ __forceinline__ void inv_staged(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st, StAlt st_alt, bool use_alt)
+    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, true>(FFT_STAMP_ARGS b, W, ld, st, true, st_alt, use_alt); }
 };
 // Three-pass schedule of each transform length in use (first radix 21: conflict-free as it is; first radix 16:
 // swizzled layout between pass 1 and 2).  4410 = 21*14*15 is the order the product runs (configs[2] 47 us, against
@@ -615,28 +605,33 @@ template <> struct PairTabs<double> {
 //     last items), and the per-butterfly offsets t*N/R0 (+ block * hop) ride in the instruction's scalar offset instead
 //     of 64-bit vector address arithmetic;
 //   * output: the last inverse pass writes its kept outputs into LDS as the contiguous run they are in memory (block a
-//     then block b of every pair of the item: 2 P hop_out consecutive elements of the column), index-shifted so that
-//     LDS and memory agree on 16-byte phase, and the workgroup then stores the run with 16-byte buffer stores — every
-//     wave writes 1 KB of whole 16-byte granules (write traffic = algorithmic bytes).
+//     then block b of the pair: 2 hop_out consecutive elements of the column), index-shifted so that LDS and memory
+//     agree on 16-byte phase, and the workgroup then stores the run with 16-byte buffer stores — every wave writes 1 KB
+//     of whole 16-byte granules (write traffic = algorithmic bytes).
 // Real = float: float32 device jobs.  Real = double: float64 device jobs — libsoxr's own VHQ engine is a float64 one
 // (SURVEY.md §0.3); the same chain in double2 (LDS 16 bytes per point), results within the method's own floor of the
 // float64 direct form (the neglected stop-band aliasing, ~3e-10 for VHQ).  IO = the signal's element type when it
 // differs from the arithmetic: <double, float> is float32 I/O on float64 arithmetic — what libsoxr's VHQ recipe itself
 // does for float32 clients (reference src/soxr_ext.cpp:74,228) — selected by HIPSOXR_KERNEL_FFT_F64.
-// One work item = P consecutive pairs of blocks of one column: item (col, bx) = blocks 2 P bx .. 2 P bx + 2 P - 1.
-// An item beyond its clip's last pair (ragged batches) leaves at once.
+// One work item = a pair of blocks of one column: item (col, bx) = blocks 2 bx, 2 bx + 1.  An item beyond its clip's
+// last pair (ragged batches) leaves at once.
+// Round 5, instruction diet (tools/isa_stats.py; the launch runs at the board's power cap, so instructions are energy):
+// the filter values come through a buffer descriptor too (offsets in the scalar operand; which side of the spectrum a
+// bin lies on is decided at compile time for all but the one butterfly input that straddles the middle: 97 -> ~50
+// vector instructions in front of the first inverse butterfly), and the staging stores test their range per butterfly
+// OUTPUT in the scalar unit — only the two outputs that can straddle an end of the kept run compare per lane.
 // ---------------------------------------------------------------------------------------------
-template <typename Spec, typename Real, typename IO, int P>
+template <typename Spec, typename Real, typename IO>
 __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem_raw, uint32_t col, int64_t bx)
 {
     typedef typename PairTabs<Real>::C C;
     typedef typename PairTabs<IO>::V16 V16;
     constexpr int ES = (int)sizeof(IO), EPS = 16 / ES; // element size, elements per 16-byte store
-    constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0;
-    constexpr int LB = NA > NB ? NA : NB; // complex points per transform buffer
-    C *cur = reinterpret_cast<C *>(smem_raw);
+    constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0, nbB = NB / Spec::RB0;
+    constexpr int NsL = NB / Spec::RB2;   // the last inverse pass writes element o + t * NsL, o < NsL
+    constexpr int LB = NA > NB ? NA : NB; // complex points of the transform buffer
+    C *buf = reinterpret_cast<C *>(smem_raw);
     IO *stage = reinterpret_cast<IO *>(smem_raw);
-    auto buf = [&](int p) -> C * { return cur + p * LB; };
 #ifdef FFT2_TRACE
     unsigned long long *g_tr = a.trace ? a.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + threadIdx.x / 64) * 16 : nullptr;
     int g_tri = 0;
@@ -645,7 +640,7 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
 
     const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels);
     const uint32_t clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    const int64_t pa = 2 * P * bx * a.hop_periods - a.lead_periods; // first period of the item's first block; block i starts i * hop_periods later
+    const int64_t pa = 2 * bx * a.hop_periods - a.lead_periods; // first period of the pair's first block; the second starts hop_periods later
     const int64_t ina = pa * a.M, outa = pa * a.L;
     const int32_t hop_in = (int32_t)(a.hop_periods * a.M);
     // ragged batch: this clip's own place and length (four scalar loads; the grid spans the longest clip, so a
@@ -657,61 +652,84 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
     }
     if (outa + a.v0 >= out_frames) return;
     const IO *xin = (const IO *)a.in + clip_in + (int64_t)ch * a.ichs;
-    auto lds_store = [&](int p, int n, C v) { buf(p)[n] = v; };
+    auto last_fwd_store = [&](int o, int t, C v) { buf[o + t * (NA / Spec::RA2)] = v; };
 
-    // ---- forward: z_p[n] = x_{2p}[n] + i x_{2p+1}[n], first pass straight from HBM ------------------
+    // ---- forward: z[n] = x_a[n] + i x_b[n], first pass straight from HBM --------------------------
     if (ina >= a.in_lo) {
         const int64_t left = (in_frames - ina) * ES; // bytes from the first block's first sample to the end of the column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             uniform_ptr((void *)(xin + ina)), 0, __builtin_amdgcn_readfirstlane((int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left)), 0x00020000);
-        Spec::template fwd<P>(FFT_STAMP_ARGS buf, PairTabs<Real>::wa(a), [&](int p, int n, int t) -> C {
-            const int j4 = (n - t * nbA) * ES; // the butterfly's own offset (one VGPR for all t and p)
-            return C((Real)buf_load_real<IO>(rs, j4, (t * nbA + 2 * p * hop_in) * ES), (Real)buf_load_real<IO>(rs, j4, (t * nbA + (2 * p + 1) * hop_in) * ES));
-        }, lds_store);
+        Spec::fwd(FFT_STAMP_ARGS buf, PairTabs<Real>::wa(a), [&](int j, int t) -> C { // (the butterfly's own offset: one VGPR for all t)
+            return C((Real)buf_load_real<IO>(rs, j * ES, t * nbA * ES), (Real)buf_load_real<IO>(rs, j * ES, (t * nbA + hop_in) * ES));
+        }, last_fwd_store);
     } else { // the first item of a column reaches before its start: explicit zero-extension
-        Spec::template fwd<P>(FFT_STAMP_ARGS buf, PairTabs<Real>::wa(a), [&](int p, int n, int) -> C {
-            const int64_t la = ina + 2 * p * hop_in + n, lb = la + hop_in;
+        Spec::fwd(FFT_STAMP_ARGS buf, PairTabs<Real>::wa(a), [&](int j, int t) -> C {
+            const int64_t la = ina + j + t * nbA, lb = la + hop_in;
             return C((la >= a.in_lo && la < in_frames) ? (Real)xin[la] : (Real)0, (lb >= a.in_lo && lb < in_frames) ? (Real)xin[lb] : (Real)0);
-        }, lds_store);
+        }, last_fwd_store);
     }
-    const Real *Hr = PairTabs<Real>::hr(a);
+    // the filter, |frequency| in bins -> real gain, through a descriptor of its own: Hr[0 .. NB/2]
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((void *)PairTabs<Real>::hr(a)), 0,
+                                                                         (NB / 2 + 1) * (int)sizeof(Real), 0x00020000);
     __syncthreads();
     FFT_STAMP();
 
     // ---- inverse: bin n of the output grid <- bin n or n + NA - NB of the input grid, times (real) H; the last pass
-    //      writes into the staging layout ------------------------------------------------------------
+    //      writes into the staging layout.  Input t of butterfly j is bin n = j + t * nbB: bins up to NB/2 are the
+    //      non-negative frequencies, the rest the negative ones — for all but one t that is known at compile time.
     const int32_t v0 = a.v0, v1 = a.v0 + a.hop_out, hop_out = a.hop_out;
     IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
     // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
     const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
-    Real hq[P > 1 ? Spec::RB0 : 1]; // P > 1: the butterfly's filter values, read once for all its transforms
-    auto h_load = [&](int p, int n, int t) -> C {
-        const bool neg = n > NB / 2;
-        const int q = neg ? NB - n : n; // |frequency| in bins
-        Real h;
-        if constexpr (P > 1) { if (p == 0) hq[t] = Hr[q]; h = hq[t]; }
-        else h = Hr[q];
+    auto h_load = [&](int j, int t) -> C {
+        constexpr int RS = (int)sizeof(Real);
+        const int lo = t * nbB, hi = lo + nbB - 1; // the bins this input can be, over all butterflies (j < nbB)
+        const int n = j + lo;
         if constexpr (NA >= NB) {
-            const C x = buf(p)[neg ? n + (NA - NB) : n];
-            return C(x.x * h, x.y * h); // (the Nyquist bin's alias term is dropped with Im H: stop band, < -170 dB)
+            if (hi <= NB / 2) {        // non-negative frequencies
+                const Real h = buf_load_real<Real>(rh, j * RS, lo * RS);
+                const C x = buf[n];
+                return C(x.x * h, x.y * h);
+            } else if (lo > NB / 2) {  // negative frequencies: |q| = NB - n = (NB - lo - nbB) + (nbB - j)
+                const Real h = buf_load_real<Real>(rh, (nbB - j) * RS, (NB - lo - nbB) * RS);
+                const C x = buf[n + (NA - NB)];
+                return C(x.x * h, x.y * h);
+            } else {                   // the butterfly input that straddles the middle
+                const bool neg = n > NB / 2;
+                const Real h = buf_load_real<Real>(rh, (neg ? NB - n : n) * RS, 0);
+                const C x = buf[neg ? n + (NA - NB) : n];
+                return C(x.x * h, x.y * h); // (the Nyquist bin's alias term is dropped with Im H: stop band, < -170 dB)
+            }
         } else {
+            const bool neg = n > NB / 2;
+            const int q = neg ? NB - n : n; // |frequency| in bins
             const bool in_band = q < NA / 2;
-            const C x = buf(p)[in_band ? (neg ? NA - q : q) : 0];
+            const Real h = buf_load_real<Real>(rh, q * RS, 0);
+            const C x = buf[in_band ? (neg ? NA - q : q) : 0];
             return in_band ? C(x.x * h, x.y * h) : C((Real)0, (Real)0);
         }
     };
-    Spec::template inv_staged<P>(FFT_STAMP_ARGS buf, PairTabs<Real>::wb(a), h_load, [&](int p, int n, C w) {
-        if (n >= v0 && n < v1) {
-            stage[n - v0 + sh + 2 * p * hop_out] = (IO)w.x;
-            stage[n - v0 + sh + (2 * p + 1) * hop_out] = (IO)w.y;
-        }
-    });
+    // Staging stores: output n = o + t * NsL (o < NsL) of both blocks is kept iff v0 <= n < v1.  In every geometry in use
+    // the kept run begins inside the first stride of outputs and ends inside the last one (`typical`, wave-uniform):
+    // then only outputs t = 0 and t = RB2 - 1 compare per lane, the others are stored as they are.
+    const bool typical = v0 >= 0 && v0 <= NsL && v1 >= NB - NsL && v1 <= NB;
+    Spec::inv_staged(FFT_STAMP_ARGS buf, PairTabs<Real>::wb(a), h_load,
+        [&](int o, int t, C w) { // typical geometry
+            IO *const sa = stage + (o - v0 + sh) + t * NsL, *const sb = sa + hop_out;
+            if (t == 0) { if (o >= v0) { *sa = (IO)w.x; *sb = (IO)w.y; } }
+            else if (t == Spec::RB2 - 1) { if (o < v1 - t * NsL) { *sa = (IO)w.x; *sb = (IO)w.y; } }
+            else { *sa = (IO)w.x; *sb = (IO)w.y; }
+        },
+        [&](int o, int t, C w) { // any geometry
+            IO *const sa = stage + (o - v0 + sh) + t * NsL, *const sb = sa + hop_out;
+            if ((unsigned)(o + t * NsL - v0) < (unsigned)hop_out) { *sa = (IO)w.x; *sb = (IO)w.y; }
+        }, !typical);
     __syncthreads();
     FFT_STAMP();
 
     // ---- store the run: elements [0, valid) of it exist in the column ----------------------------------
     const int64_t remain = out_frames - (outa + v0);
-    const int32_t valid = (int32_t)(remain < 0 ? 0 : remain > 2 * P * (int64_t)hop_out ? 2 * P * (int64_t)hop_out : remain);
+    const int32_t valid = (int32_t)(remain < 0 ? 0 : remain > 2 * (int64_t)hop_out ? 2 * (int64_t)hop_out : remain);
     // 16-byte buffer stores: the descriptor starts at the 16-byte granule that holds run[0] (sh elements before it)
     // and ends with the run, so the hardware range check drops what lies beyond the column (and the trips past the
     // run: no trip count, no branches — every LDS read and every store of the thread is in flight at once).  The
@@ -719,8 +737,8 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
     {
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((void *)(ybase - sh)), 0,
                                                                              __builtin_amdgcn_readfirstlane((valid + sh) * ES), 0x00020000);
-        constexpr int QMAX = (2 * P * (NB - 1) + EPS - 1 + EPS) / EPS; // 2 P hop_out < 2 P NB elements, + sh
-        constexpr int LQ = (int)((size_t)P * LB * sizeof(C) / 16);     // 16-byte granules of the LDS buffers
+        constexpr int QMAX = (2 * (NB - 1) + EPS - 1 + EPS) / EPS; // 2 hop_out < 2 NB elements, + sh
+        constexpr int LQ = (int)((size_t)LB * sizeof(C) / 16);     // 16-byte granules of the LDS buffer
         const int tid_out = (int)threadIdx.x;
 #pragma unroll
         for (int it = 0; it < (QMAX + NT - 1) / NT; ++it) {
@@ -746,11 +764,11 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
 #endif
 }
 
-template <typename Spec, typename Real, typename IO = Real, int P = 1>
+template <typename Spec, typename Real, typename IO = Real>
 __global__ void __launch_bounds__(Spec::NT) k_fft_pair2(FftArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    pair2_item<Spec, Real, IO, P>(a, smem_raw, blockIdx.y, blockIdx.x);
+    pair2_item<Spec, Real, IO>(a, smem_raw, blockIdx.y, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -804,7 +822,6 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
     unsigned long long *g_tr = nullptr;
     int g_tri = 0;
 #endif
-    auto buf = [&](int) -> C * { return cur; };
     // XCD-aware ids: x = 8 * slot + xcd, slot = chunk * units + unit;
     // or (a.xcd_map == 0: one column per grid row) items along x, columns along y
     const uint32_t units = CP ? a.n_channels / 2 : a.n_channels;
@@ -824,7 +841,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
     const int32_t hop_in = (int32_t)(a.hop_periods * a.M), hop_out = a.hop_out;
     const Real *xin = (const Real *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
     const int32_t ifb = (int32_t)a.ifs * ES, ofb = (int32_t)a.ofs * ES; // bytes per frame (launcher: 2 N * frame < 2^30)
-    auto lds_store = [&](int, int n, C v) { cur[n] = v; };
+    auto last_fwd_store = [&](int o, int t, C v) { cur[o + t * (NA / Spec::RA2)] = v; };
     const Real *Hr = PairTabs<Real>::hr(a);
     const int32_t v0 = a.v0, v1 = a.v0 + hop_out;
     const int64_t pa = (CP ? 1 : 2) * bx * a.hop_periods - a.lead_periods; // first period of the (first) block
@@ -836,13 +853,13 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             uniform_ptr((void *)(xin + ina * a.ifs)), 0, __builtin_amdgcn_readfirstlane((int)(left < 0 ? 0 : left > 0x40000000 ? 0x40000000 : left)), 0x00020000);
         const int32_t stepb = nbA * ifb; // one butterfly input further: N/R0 frames
-        Spec::template fwd<1>(FFT_STAMP_ARGS buf, PairTabs<Real>::wa(a), [&](int, int n, int t) -> C {
-            if constexpr (CP) return CpIo<Real>::load(rs, (n - t * nbA) * ifb, t * stepb);
-            else return C(buf_load_real<Real>(rs, (n - t * nbA) * ifb, t * stepb), buf_load_real<Real>(rs, (n - t * nbA) * ifb, t * stepb + hop_in * ifb));
-        }, lds_store);
+        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int j, int t) -> C {
+            if constexpr (CP) return CpIo<Real>::load(rs, j * ifb, t * stepb);
+            else return C(buf_load_real<Real>(rs, j * ifb, t * stepb), buf_load_real<Real>(rs, j * ifb, t * stepb + hop_in * ifb));
+        }, last_fwd_store);
     } else { // the first block of a column reaches before its start: explicit zero-extension
-        Spec::template fwd<1>(FFT_STAMP_ARGS buf, PairTabs<Real>::wa(a), [&](int, int n, int) -> C {
-            const int64_t l = ina + n, lb = l + hop_in;
+        Spec::fwd(FFT_STAMP_ARGS cur, PairTabs<Real>::wa(a), [&](int j, int t) -> C {
+            const int64_t l = ina + j + t * nbA, lb = l + hop_in;
             if constexpr (CP) {
                 C v = C((Real)0, (Real)0);
                 if (l >= a.in_lo && l < a.in_frames) v = C(xin[l * a.ifs], xin[l * a.ifs + 1]);
@@ -850,7 +867,7 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
             } else {
                 return C((l >= a.in_lo && l < a.in_frames) ? xin[l * a.ifs] : (Real)0, (lb >= a.in_lo && lb < a.in_frames) ? xin[lb * a.ifs] : (Real)0);
             }
-        }, lds_store);
+        }, last_fwd_store);
     }
     __syncthreads();
 
@@ -859,7 +876,8 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
     const int64_t oleft = (a.out_frames - (outa + v0)) * (int64_t)ofb;
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr((void *)ybase), 0, __builtin_amdgcn_readfirstlane((int)(oleft < 0 ? 0 : oleft > 0x40000000 ? 0x40000000 : oleft)), 0x00020000);
-    auto h_load = [&](int, int n, int) -> C {
+    auto h_load = [&](int j, int t) -> C {
+        const int n = j + t * (NB / Spec::RB0);
         const bool neg = n > NB / 2;
         const int q = neg ? NB - n : n; // |frequency| in bins
         const Real h = Hr[q];
@@ -872,7 +890,8 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
             return in_band ? C(x.x * h, x.y * h) : C((Real)0, (Real)0);
         }
     };
-    Spec::template inv<1>(FFT_STAMP_ARGS buf, PairTabs<Real>::wb(a), h_load, [&](int, int n, C wv) {
+    Spec::inv(FFT_STAMP_ARGS cur, PairTabs<Real>::wb(a), h_load, [&](int o, int t, C wv) {
+        const int n = o + t * (NB / Spec::RB2);
         if (n >= v0 && n < v1) {
             if constexpr (CP) {
                 CpIo<Real>::store(wv, ro, (n - v0) * ofb); // frame outa + n holds (y_c, y_{c+1})
@@ -1079,27 +1098,16 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
         void (*kern2fd)(FftArgs);                        // float32 I/O on float64 arithmetic (HIPSOXR_KERNEL_FFT_F64)
         void (*kcp)(FftArgs); void (*kcpd)(FftArgs);     // channel-pair mode (interleaved data), float32 / float64
         void (*kst)(FftArgs); void (*kstd)(FftArgs);     // strided columns, two blocks per transform
-        void (*kern2x2)(FftArgs); unsigned nt2;          // float32, two pairs per workgroup (throughput jobs); its thread count
     };
-#define HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, X2, NT2) \
+#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) \
     {L, M, k, small, NT, k_fft_pair2<PairOf<NA, NB, NT>, float>, k_fft_pair2<PairOf<NA, NB, NT>, double>, \
      k_fft_pair2<PairOf<NA, NB, NT>, double, float>, \
      k_fft_strided2<PairOf<NA, NB, NT>, float, true>, k_fft_strided2<PairOf<NA, NB, NT>, double, true>, \
-     k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>, X2, NT2}
-#define HIPSOXR_PAIR(L, M, k, small, NA, NB, NT) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, nullptr, 0)
-// Two pairs per workgroup (P = 2: one set of twiddle powers and filter values for both, 6 % fewer vector-ALU instructions):
-// measured in round 4 and NOT faster — 5120-point blocks 158 vs 133 us (80 KB of LDS: two workgroups per CU), 2560-point
-// blocks 137 vs 138 (P = 1, four waves) — because the batch launch is bound by the board's power cap, not by instruction
-// issue (profiles/NOTES_r04.md).  Instantiated only in experiment builds (-DFFT_EXPERIMENT_X2; tools/x2_check.py, tools/nt_sweep.sh).
-#ifdef FFT_EXPERIMENT_X2
-#define HIPSOXR_PAIR_X2(L, M, k, small, NA, NB, NT, NT2) HIPSOXR_PAIR_(L, M, k, small, NA, NB, NT, (k_fft_pair2<PairOf<NA, NB, NT2>, float, float, 2>), NT2)
-#else
-#define HIPSOXR_PAIR_X2(L, M, k, small, NA, NB, NT, NT2) HIPSOXR_PAIR(L, M, k, small, NA, NB, NT)
-#endif
+     k_fft_strided2<PairOf<NA, NB, NT>, float, false>, k_fft_strided2<PairOf<NA, NB, NT>, double, false>}
     static const PairEntry pairs[] = {
         // L, M (out/in = L/M), periods per block, small-job variant, N_in, N_out, threads
-        HIPSOXR_PAIR_X2(147, 160, 32, false, 5120, 4704, 384, 384), HIPSOXR_PAIR_X2(147, 160, 16, true, 2560, 2352, 384, 256),   // 48k -> 44.1k
-        HIPSOXR_PAIR_X2(160, 147, 32, false, 4704, 5120, 384, 384), HIPSOXR_PAIR_X2(160, 147, 16, true, 2352, 2560, 384, 256),   // 44.1k -> 48k
+        HIPSOXR_PAIR(147, 160, 32, false, 5120, 4704, 384), HIPSOXR_PAIR(147, 160, 16, true, 2560, 2352, 384),   // 48k -> 44.1k
+        HIPSOXR_PAIR(160, 147, 32, false, 4704, 5120, 384), HIPSOXR_PAIR(160, 147, 16, true, 2352, 2560, 384),   // 44.1k -> 48k
         HIPSOXR_PAIR(147, 160, 8, 2, 1280, 1176, 256), HIPSOXR_PAIR(160, 147, 8, 2, 1176, 1280, 256),           // ... quarter-size blocks: jobs of a few hundred pairs
         HIPSOXR_PAIR(160, 441, 16, false, 7056, 2560, 448), HIPSOXR_PAIR(441, 160, 16, false, 2560, 7056, 448),  // 44.1k <-> 16k
         HIPSOXR_PAIR(160, 441, 10, true, 4410, 1600, 320), HIPSOXR_PAIR(441, 160, 10, true, 1600, 4410, 320),    // ... 35 KB blocks: 4 workgroups per CU
@@ -1225,30 +1233,10 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 size_t lds = lds1;
                 if (v2ok) {
                     kern = io64 ? use->kern2d : wide32 ? use->kern2fd : use->kern2;
-                    // experiment builds: HIPSOXR_FFT_X2=1 runs two pairs per workgroup in one instruction stream (see HIPSOXR_PAIR_X2)
-                    if (!f64 && use->kern2x2 && switches().fft_x2 > 0 && 4 * (int64_t)g.hop_periods * p->M * (int64_t)esz < (1LL << 30)) {
-                        kern = use->kern2x2; nt = use->nt2; lds = 2 * lds1;
-                        grid.x = (grid.x + 1) / 2;
-                    }
-#if defined(FFT_NT_SWEEP) && defined(FFT_EXPERIMENT_X2) // experiment build: thread-count sweep of the 48k -> 44.1k kernels (HIPSOXR_DEBUG_NW = waves per workgroup)
-                    if (!f64 && p->L == 147 && p->M == 160 && switches().dbg_nw) {
-                        const int nw = switches().dbg_nw;
-                        const bool two = kern == use->kern2x2;
-                        void (*k)(FftArgs) = nullptr;
-                        if (g.N_in == 2560) {
-                            if (!two) k = nw == 3 ? k_fft_pair2<PairOf<2560, 2352, 192>, float> : nw == 4 ? k_fft_pair2<PairOf<2560, 2352, 256>, float> : nw == 5 ? k_fft_pair2<PairOf<2560, 2352, 320>, float> : nullptr;
-                            else k = nw == 3 ? k_fft_pair2<PairOf<2560, 2352, 192>, float, float, 2> : nw == 6 ? k_fft_pair2<PairOf<2560, 2352, 384>, float, float, 2> : nullptr;
-                        } else if (g.N_in == 5120) {
-                            if (!two) k = nw == 5 ? k_fft_pair2<PairOf<5120, 4704, 320>, float> : nw == 4 ? k_fft_pair2<PairOf<5120, 4704, 256>, float> : nullptr;
-                        }
-                        if (k) { kern = k; nt = 64 * nw; }
-                    }
-#endif
                 } else {
                     kern = cp2ok ? (f64 ? use->kcpd : use->kcp) : (f64 ? use->kstd : use->kst);
                 }
-                if (lds > 64 * 1024)
-                    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (const char *e = ensure_dyn_lds((const void *)kern, lds)) return e;
 #ifdef FFT2_TRACE
                 size_t trace_n = 0;
                 if (switches().dbg_trace && v2ok) {
@@ -1305,8 +1293,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
     const uint64_t cols = (uint64_t)j.n_clips * j.n_channels;
     if (cols > 65535) return "too many (clip, channel) columns for one launch (max 65535)";
     if (n_blocks > 2147483647LL) return "job too long for one launch";
-    if (g.lds_bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)k_fft_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+    if (const char *e = ensure_dyn_lds((const void *)k_fft_block, std::max(g.lds_bytes, switches().dbg_fft_lds))) return e;
     const size_t dbg_lds = switches().dbg_fft_lds;
     hipLaunchKernelGGL(k_fft_block, dim3((unsigned)n_blocks, (unsigned)cols, 1), dim3(256), std::max(g.lds_bytes, dbg_lds),
                        (hipStream_t)stream, a);

@@ -2107,6 +2107,22 @@ int device_count()
     return n;
 }
 
+const char *ensure_dyn_lds(const void *fn, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return nullptr;
+    if (bytes > 160 * 1024) return "a launch asks for more LDS than a CU has (160 KB)";
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done; // (function, device) pairs already raised to 160 KB
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &e : done)
+        if (e.first == fn && e.second == dev) return nullptr;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.push_back({fn, dev});
+    return nullptr;
+}
+
 static inline int32_t floor4(int32_t v) { return v >= 0 ? (v / 4) * 4 : -(((-v) + 3) / 4) * 4; }
 
 struct TileGeom {
@@ -2585,8 +2601,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     const unsigned gx = (unsigned)((nf + NO - 1) / NO), gy = (unsigned)((uint64_t)j.n_clips * j.n_channels);
                     // every workgroup must be on the chip at once (they wait for each other): a quarter of the slots at most
                     int occ = 0, dev = 0, cus = 0;
-                    if (lds > 64 * 1024)
-                        HIP_TRY(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    if (const char *e = ensure_dyn_lds((const void *)rk, lds)) return e;
                     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)rk, 256, lds));
                     HIP_TRY(hipGetDevice(&dev));
                     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -2604,8 +2619,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     HIP_TRY(hipGetLastError());
                     return nullptr;
                 }
-                if (lds > 64 * 1024)
-                    HIP_TRY(hipFuncSetAttribute((const void *)ck, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (const char *e = ensure_dyn_lds((const void *)ck, lds)) return e;
                 {
                     const uint64_t wgs = (uint64_t)((nf + NO - 1) / NO) * ((uint64_t)j.n_clips * j.n_channels);
                     if (cd && done == 0 && nf == j.out_frames && wgs <= cd->cap) { // the whole job is this launch
@@ -2711,7 +2725,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 const size_t lds = (size_t)ta.span_cap * sizeof(Real) + (size_t)KO * 2 + (size_t)(2 * p->phases + 2) * 4 + 64;
                 const dim3 tgrid((unsigned)((nf + KO - 1) / KO), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1);
                 void (*tk)(InterpTileArgs) = vr ? k_interp_tile<IO, Real, true> : k_interp_tile<IO, Real, false>;
-                HIP_TRY(hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (const char *e = ensure_dyn_lds((const void *)tk, lds)) return e;
                 hipLaunchKernelGGL(tk, tgrid, dim3(1024), lds, st, ta);
                 HIP_TRY(hipGetLastError());
                 continue;
@@ -2941,9 +2955,7 @@ static const char *launch_tile(Plan *p, const hipsoxr_job_t &j, hipStream_t st, 
     }
     size_t lds_bytes = g.lds_bytes;
     lds_bytes = std::max<size_t>(lds_bytes, switches().dbg_lds); // occupancy experiments
-    if (lds_bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes));
+    if (const char *e = ensure_dyn_lds((const void *)kern, lds_bytes)) return e;
     a.trace = nullptr;
     const char *trace_path = switches().dbg_trace;
     size_t trace_n = 0;

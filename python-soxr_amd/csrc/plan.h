@@ -44,6 +44,9 @@ struct Plan {
     int32_t phases = 0;
     std::vector<double> bank; // float64
     double proto_scale = 0; // interpolated-phase plans: DC normalisation of the continuous-time prototype (plan_proto)
+    // A bank installed from outside (hipsoxr_plan_set_bank / hipsoxr_plan_broadcast) that DIFFERS from the designed one:
+    // engines that derive their tables from the analytic prototype instead of `bank` (the two-stage form) decline the plan.
+    bool custom_bank = false;
     // device side (lazily built on first use, per precision: 0 = f32, 1 = f64)
     DeviceBank dev[2];
     std::mutex mu;

@@ -80,7 +80,7 @@ static const char *twostage_build(Plan *p)
 {
     TwoStage *ts = new TwoStage;
     p->two = ts;
-    if (!p->phases || p->q.bits < 20. || p->proto_scale == 0.) return nullptr; // HQ / VHQ windowed-sinc interpolated plans only
+    if (!p->phases || p->q.bits < 20. || p->proto_scale == 0. || p->custom_bank) return nullptr; // HQ / VHQ windowed-sinc interpolated plans only
     const double fi = p->in_rate, fo = p->out_rate;
     ts->up = fo > fi;
     const double rho = ts->up ? 1. : fi / (2. * fo); // polyphase stage: input samples per output sample is rho (down) / Ms/Ls (up)
@@ -505,7 +505,7 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
 #undef HIPSOXR_POLY_T
     }
     if (!kern) return "two-stage: no polyphase instance for this tap count";
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (const char *e = ensure_dyn_lds((const void *)kern, lds)) return e;
     // workgroups walk tiles (the table is loaded once per workgroup): exactly as many as the chip holds at once — a
     // partly filled second round of workgroups would double the launch
     int per_cu = 0, dev = 0, n_cu = 256;

@@ -18,6 +18,7 @@ bench.py and the multi-process tests import these from here; nothing below touch
 """
 import ctypes as _C
 import hashlib
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -179,6 +180,7 @@ class RaggedJob:
 # service that meets many rate pairs must not keep all of them for ever.
 _PLANS = {}
 _PLANS_MAX = 32
+_CACHE_LOCK = threading.Lock()   # guards _PLANS and _PIPES: `resample_batch` is called from many threads (the module's model)
 
 
 def _plan_on(device_index, in_rate, out_rate, quality, bank=None):
@@ -186,20 +188,57 @@ def _plan_on(device_index, in_rate, out_rate, quality, bank=None):
     broadcast: one design, identical coefficients everywhere).  At most `_PLANS_MAX` plans are kept (LRU);
     `clear_plans()` drops them all."""
     key = (device_index, float(in_rate), float(out_rate), str(quality))
-    p = _PLANS.pop(key, None)
-    if p is None:
-        p = _dev.Plan(in_rate, out_rate, quality)
-        if bank is not None:
-            p.set_bank(bank)
-    _PLANS[key] = p                      # (re-inserted: most recently used last)
-    while len(_PLANS) > _PLANS_MAX:
-        _PLANS.pop(next(iter(_PLANS)))
+    with _CACHE_LOCK:
+        p = _PLANS.pop(key, None)
+        if p is None:
+            p = _dev.Plan(in_rate, out_rate, quality)
+            if bank is not None:
+                p.set_bank(bank)
+        _PLANS[key] = p                      # (re-inserted: most recently used last)
+        while len(_PLANS) > _PLANS_MAX:
+            _PLANS.pop(next(iter(_PLANS)))
     return p
 
 
 def clear_plans():
-    """Drop the cached plans (and with them their device tables)."""
-    _PLANS.clear()
+    """Drop the cached plans (and with them their device tables) and the idle staging pipes."""
+    with _CACHE_LOCK:
+        _PLANS.clear()
+        _PIPES.clear()
+
+
+class _PipeRun:
+    """Bookkeeping of ONE `_HostPipe.run`: the block list, the events between its three host threads and the first
+    error.  `fail()` wakes everything that can wait, so that an error anywhere — a HIP call in the issuing loop, an
+    allocation in a copy thread — ends the run as an exception in the caller instead of a hang."""
+
+    def __init__(self, n_in, n_out, ch, es, block_bytes, slots):
+        self.n_in, self.n_out, self.ch, self.slots = n_in, n_out, ch, slots
+        self.blocks, cur, cur_b = [], [], 0          # blocks hold whole clips, about block_bytes of input each
+        for i, n in enumerate(n_in):
+            if cur and cur_b + n * ch * es > block_bytes:
+                self.blocks.append(cur); cur, cur_b = [], 0
+            cur.append(i); cur_b += n * ch * es
+        if cur:
+            self.blocks.append(cur)
+        nb = len(self.blocks)
+        self.tot_in = [sum(n_in[i] for i in b) * ch for b in self.blocks]
+        self.tot_out = [sum(n_out[i] for i in b) * ch for b in self.blocks]
+        self.ev_free_in = [None] * slots    # h2d of the block that used the slot before has read the pinned input
+        self.ev_out = [None] * nb           # d2h(k) done
+        self.ev_run = [None] * nb           # run(k) done
+        self.free_out = [threading.Semaphore(1) for _ in range(slots)]   # the output slot has been unstaged
+        self.own_out = [None] * nb          # pinned_results: the block's own pinned result buffer
+        self.staged = [threading.Event() for _ in range(nb)]
+        self.issued = [threading.Event() for _ in range(nb)]
+        self.err = []
+
+    def fail(self, e):
+        self.err.append(e)
+        for ev in self.staged + self.issued:
+            ev.set()
+        for sem in self.free_out:
+            sem.release()
 
 
 class _HostPipe:
@@ -212,23 +251,25 @@ class _HostPipe:
     so that the H2D copy of block k+1, the launch of block k and the D2H copy of block k-1 are in flight together and
     the two CPU copies run beside them.  Blocks hold whole clips, about `block_bytes` of input each.
     With `pinned_results` d2h(k) lands in a pinned buffer of the block's own (from torch's caching host allocator) and the
-    result arrays ARE views of it: no unstage copy — half of the CPU work of the path, which is what bounds it."""
+    result arrays ARE views of it: no unstage copy — half of the CPU work of the path, which is what bounds it.
+    One run at a time per pipe (`resample_batch` checks pipes out of a pool: concurrent callers get pipes of their own)."""
     SLOTS = 3
 
     def __init__(self, plan, device, dtype, ch, kernel, block_bytes, pinned_results=False):
+        import os
         import torch
         self.torch, self.plan, self.device, self.kernel, self.ch = torch, plan, device, kernel, ch
         self.pinned_results = pinned_results
         self.tdtype = dtype
         self.sin, self.sc, self.sout = (torch.cuda.Stream(device=device) for _ in range(3))
         self.block_bytes = block_bytes
-        import os
         self.copy_threads = int(os.environ.get("SOXR_AMD_COPY_THREADS", 0)) or max(2, min(8, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4) // 2))
         self.cap_in = self.cap_out = 0
         self.pin_in = self.pin_out = self.dev_in = self.dev_out = None
 
     def _ensure(self, n_in_el, n_out_el):
         torch = self.torch
+        n_in_el, n_out_el = max(1, n_in_el), max(1, n_out_el)   # (a share of zero-length clips still has slots to name)
         if n_in_el > self.cap_in:
             self.cap_in = n_in_el
             self.pin_in = [torch.empty(n_in_el, dtype=self.tdtype, pin_memory=True) for _ in range(self.SLOTS)]
@@ -240,150 +281,165 @@ class _HostPipe:
         if not self.pinned_results and (self.pin_out is None or self.pin_out[0].numel() < self.cap_out):
             self.pin_out = [torch.empty(self.cap_out, dtype=self.tdtype, pin_memory=True) for _ in range(self.SLOTS)]
 
-    def run(self, clips, results, idx):
-        """clips: numpy arrays of this device (all the same dtype / channel count); results[idx[i]] = resampled clips[i]."""
-        import threading
-        torch, ch, plan = self.torch, self.ch, self.plan
-        es = clips[0].dtype.itemsize
-        n_in = [int(c.shape[0]) for c in clips]
-        n_out = [plan.out_len(n) for n in n_in]
-        blocks, cur, cur_b = [], [], 0
-        for i, n in enumerate(n_in):
-            if cur and cur_b + n * ch * es > self.block_bytes:
-                blocks.append(cur); cur, cur_b = [], 0
-            cur.append(i); cur_b += n * ch * es
-        if cur:
-            blocks.append(cur)
-        self._ensure(max(sum(n_in[i] for i in b) for b in blocks) * ch, max(sum(n_out[i] for i in b) for b in blocks) * ch)
-        ev_free_in = [None] * self.SLOTS    # h2d of the block that used the slot before has read the pinned input
-        ev_out = [None] * len(blocks)       # d2h(k) done
-        ev_run = [None] * len(blocks)       # run(k) done
-        free_out = [threading.Semaphore(1) for _ in range(self.SLOTS)]   # the output slot has been unstaged
-        own_out = [None] * len(blocks)      # pinned_results: the block's own pinned result buffer
-        staged = [threading.Event() for _ in blocks]
-        issued = [threading.Event() for _ in blocks]
-        err = []
-
-        def stager():
-            try:
-                for k, b in enumerate(blocks):
-                    s = k % self.SLOTS
-                    if k >= self.SLOTS:               # the pinned slot's previous block has been copied to the device
-                        issued[k - self.SLOTS].wait()
-                        if err:
-                            return
-                        ev_free_in[s].synchronize()
-                    view, pos, runs = self.pin_in[s].numpy(), 0, [[] for _ in range(self.copy_threads)]
-                    share, t = sum(n_in[i] for i in b) * ch / self.copy_threads, 0
-                    for i in b:                       # one task per copy thread: a run of clips of about equal bytes
-                        n = n_in[i] * ch
-                        if pos >= (t + 1) * share and t + 1 < self.copy_threads:
-                            t += 1
-                        runs[t].append((pos, n, i))
-                        pos += n
-
-                    def put(run):
-                        for pos, n, i in run:
-                            np.copyto(view[pos:pos + n], clips[i].reshape(-1), casting="no")
-
-                    for f in [pool.submit(put, r) for r in runs if r]:
-                        f.result()
-                    staged[k].set()
-            except Exception as e:  # pragma: no cover
-                err.append(e)
-                for ev in staged:
-                    ev.set()
-
-        def unstager():
-            try:
-                for k, b in enumerate(blocks):
-                    issued[k].wait()
-                    if err:
+    def _stager(self, st, clips, pool):
+        """Host thread A: block k's clips into pinned input slot k mod SLOTS, spread over the copy threads."""
+        try:
+            for k, b in enumerate(st.blocks):
+                s = k % self.SLOTS
+                if k >= self.SLOTS:               # the pinned slot's previous block has been copied to the device
+                    st.issued[k - self.SLOTS].wait()
+                    if st.err:
                         return
-                    ev_out[k].synchronize()
-                    s = k % self.SLOTS
-                    if own_out[k] is not None:        # the results are views of the block's pinned buffer (which they keep alive)
-                        view, pos = own_out[k].numpy(), 0
-                        for i in b:
-                            n = n_out[i] * ch
-                            results[idx[i]] = view[pos:pos + n].reshape((n_out[i],) if clips[i].ndim == 1 else (n_out[i], ch))
-                            pos += n
-                        own_out[k] = None
-                        continue
-                    view, pos, jobs = self.pin_out[s].numpy(), 0, []
+                    st.ev_free_in[s].synchronize()
+                view, pos, runs = self.pin_in[s].numpy(), 0, [[] for _ in range(self.copy_threads)]
+                share, t = st.tot_in[k] / self.copy_threads, 0
+                for i in b:                       # one task per copy thread: a run of clips of about equal bytes
+                    n = st.n_in[i] * st.ch
+                    if pos >= (t + 1) * share and t + 1 < self.copy_threads:
+                        t += 1
+                    runs[t].append((pos, n, i))
+                    pos += n
 
-                    def take(i, pos, n):   # (allocation included: the first touch of a fresh result array is most of its cost)
-                        out = np.empty((n_out[i],) if clips[i].ndim == 1 else (n_out[i], ch), dtype=clips[i].dtype)
-                        np.copyto(out.reshape(-1), view[pos:pos + n], casting="no")
-                        results[idx[i]] = out
+                def put(run):
+                    for pos, n, i in run:
+                        np.copyto(view[pos:pos + n], clips[i].reshape(-1), casting="no")
 
+                for f in [pool.submit(put, r) for r in runs if r]:
+                    f.result()
+                st.staged[k].set()
+        except Exception as e:
+            st.fail(e)
+
+    def _unstager(self, st, clips, results, idx, pool):
+        """Host thread B: block k's results out of its pinned buffer (views of it with `pinned_results`)."""
+        ch = st.ch
+        try:
+            for k, b in enumerate(st.blocks):
+                st.issued[k].wait()
+                if st.err:
+                    return
+                st.ev_out[k].synchronize()
+                s = k % self.SLOTS
+                shape = lambda i: (st.n_out[i],) if clips[i].ndim == 1 else (st.n_out[i], ch)   # noqa: E731
+                if st.own_out[k] is not None:     # the results are views of the block's pinned buffer (which they keep alive)
+                    view, pos = st.own_out[k].numpy(), 0
                     for i in b:
-                        n = n_out[i] * ch
-                        jobs.append(pool.submit(take, i, pos, n))
+                        n = st.n_out[i] * ch
+                        results[idx[i]] = view[pos:pos + n].reshape(shape(i))
                         pos += n
-                    for f in jobs:
-                        f.result()
-                    free_out[s].release()
-            except Exception as e:  # pragma: no cover
-                err.append(e)
+                    st.own_out[k] = None
+                    continue
+                view, pos, jobs = self.pin_out[s].numpy(), 0, []
 
+                def take(i, pos, n):   # (allocation included: the first touch of a fresh result array is most of its cost)
+                    out = np.empty(shape(i), dtype=clips[i].dtype)
+                    np.copyto(out.reshape(-1), view[pos:pos + n], casting="no")
+                    results[idx[i]] = out
+
+                for i in b:
+                    n = st.n_out[i] * ch
+                    jobs.append(pool.submit(take, i, pos, n))
+                    pos += n
+                for f in jobs:
+                    f.result()
+                st.free_out[s].release()
+        except Exception as e:
+            st.fail(e)
+
+    def _issue(self, st, k):
+        """Block k onto the three streams: h2d on `sin`, the ragged launch on `sc`, d2h on `sout`."""
+        torch, ch, s, b = self.torch, st.ch, k % self.SLOTS, st.blocks[k]
+        tot_in, tot_out = st.tot_in[k], st.tot_out[k]
+        with torch.cuda.stream(self.sin):
+            if k >= self.SLOTS:
+                self.sin.wait_event(st.ev_run[k - self.SLOTS])   # dev_in[s] was read by run(k - SLOTS)
+            self.dev_in[s][:tot_in].copy_(self.pin_in[s][:tot_in], non_blocking=True)
+            e_in = torch.cuda.Event(); e_in.record(self.sin)
+        st.ev_free_in[s] = e_in
+        # the block's table: clips end to end in the packed device buffers (device copy uploaded by the library)
+        ni = np.array([st.n_in[i] for i in b], np.int64); no = np.array([st.n_out[i] for i in b], np.int64)
+        table = np.ascontiguousarray(np.stack([np.concatenate([[0], np.cumsum(ni)[:-1]]) * ch, ni,
+                                               np.concatenate([[0], np.cumsum(no)[:-1]]) * ch, no], axis=1), dtype=np.int64)
+        j = _n.Job()
+        j.in_, j.out = self.dev_in[s].data_ptr(), self.dev_out[s].data_ptr()
+        j.elem, j.kernel = _dev._torch_elem(self.tdtype), self.kernel
+        j.n_clips, j.n_channels = len(b), ch
+        j.in_frame_stride, j.in_chan_stride, j.out_frame_stride, j.out_chan_stride = ch, 1, ch, 1
+        j.in_frames, j.out_frames = int(ni.max()), int(no.max())
+        j.clip_table, j.clip_table_dev = table.ctypes.data, None
+        j.dither = int(self.tdtype == torch.int16)
+        if self.pinned_results:
+            st.own_out[k] = torch.empty(max(tot_out, 1), dtype=self.tdtype, pin_memory=True)
+        else:
+            st.free_out[s].acquire()              # the result slot of block k - SLOTS has been copied out
+            if st.err:
+                return
+        self.sc.wait_event(e_in)
+        if k >= self.SLOTS:
+            self.sc.wait_event(st.ev_out[k - self.SLOTS])   # ... and its device buffer read by d2h(k - SLOTS)
+        if j.out_frames > 0:
+            _n.check(_n.lib.hipsoxr_run_device(self.plan.handle, _C.byref(j), self.sc.cuda_stream))
+        e_c = torch.cuda.Event(); e_c.record(self.sc)
+        st.ev_run[k] = e_c
+        with torch.cuda.stream(self.sout):
+            self.sout.wait_event(e_c)
+            (st.own_out[k] if self.pinned_results else self.pin_out[s])[:tot_out].copy_(self.dev_out[s][:tot_out], non_blocking=True)
+            e_o = torch.cuda.Event(); e_o.record(self.sout)
+        st.ev_out[k] = e_o
+
+    def run(self, clips, results, idx):
+        """clips: numpy arrays of this device (all the same dtype / channel count); results[idx[i]] = resampled clips[i].
+        Any error — in the issuing loop or in either copy thread — is raised here after all three have stopped."""
+        n_in = [int(c.shape[0]) for c in clips]
+        st = _PipeRun(n_in, [self.plan.out_len(n) for n in n_in], self.ch, clips[0].dtype.itemsize, self.block_bytes, self.SLOTS)
+        self._ensure(max(st.tot_in), max(st.tot_out))
         # the two CPU copies of a block are spread over a few threads (numpy releases the GIL inside a large copy; one
         # thread moves ~10-25 GB/s, the link 63 GB/s each way)
         pool = ThreadPoolExecutor(self.copy_threads)
-        ta, tb = threading.Thread(target=stager), threading.Thread(target=unstager)
+        ta = threading.Thread(target=self._stager, args=(st, clips, pool))
+        tb = threading.Thread(target=self._unstager, args=(st, clips, results, idx, pool))
         ta.start(); tb.start()
         try:
-            for k, b in enumerate(blocks):
-                s = k % self.SLOTS
-                staged[k].wait()
-                if err:
+            for k in range(len(st.blocks)):
+                st.staged[k].wait()
+                if st.err:
                     break
-                tot_in, tot_out = sum(n_in[i] for i in b) * ch, sum(n_out[i] for i in b) * ch
-                with torch.cuda.stream(self.sin):
-                    if k >= self.SLOTS:
-                        self.sin.wait_event(ev_run[k - self.SLOTS])   # dev_in[s] was read by run(k - SLOTS)
-                    self.dev_in[s][:tot_in].copy_(self.pin_in[s][:tot_in], non_blocking=True)
-                    e_in = torch.cuda.Event(); e_in.record(self.sin)
-                ev_free_in[s] = e_in
-                # the block's table: clips end to end in the packed device buffers (device copy uploaded by the library)
-                ni = np.array([n_in[i] for i in b], np.int64); no = np.array([n_out[i] for i in b], np.int64)
-                table = np.ascontiguousarray(np.stack([np.concatenate([[0], np.cumsum(ni)[:-1]]) * ch, ni,
-                                                       np.concatenate([[0], np.cumsum(no)[:-1]]) * ch, no], axis=1), dtype=np.int64)
-                j = _n.Job()
-                j.in_, j.out = self.dev_in[s].data_ptr(), self.dev_out[s].data_ptr()
-                j.elem, j.kernel = _dev._torch_elem(self.tdtype), self.kernel
-                j.n_clips, j.n_channels = len(b), ch
-                j.in_frame_stride, j.in_chan_stride, j.out_frame_stride, j.out_chan_stride = ch, 1, ch, 1
-                j.in_frames, j.out_frames = int(ni.max()), int(no.max())
-                j.clip_table, j.clip_table_dev = table.ctypes.data, None
-                j.dither = int(self.tdtype == torch.int16)
-                if self.pinned_results:
-                    own_out[k] = torch.empty(max(tot_out, 1), dtype=self.tdtype, pin_memory=True)
-                else:
-                    free_out[s].acquire()             # the result slot of block k - SLOTS has been copied out
-                self.sc.wait_event(e_in)
-                if k >= self.SLOTS:
-                    self.sc.wait_event(ev_out[k - self.SLOTS])   # ... and its device buffer read by d2h(k - SLOTS)
-                if j.out_frames > 0:
-                    _n.check(_n.lib.hipsoxr_run_device(plan.handle, _C.byref(j), self.sc.cuda_stream))
-                e_c = torch.cuda.Event(); e_c.record(self.sc)
-                ev_run[k] = e_c
-                with torch.cuda.stream(self.sout):
-                    self.sout.wait_event(e_c)
-                    (own_out[k] if self.pinned_results else self.pin_out[s])[:tot_out].copy_(self.dev_out[s][:tot_out], non_blocking=True)
-                    e_o = torch.cuda.Event(); e_o.record(self.sout)
-                ev_out[k] = e_o
-                issued[k].set()
+                self._issue(st, k)
+                if st.err:
+                    break
+                st.issued[k].set()
+        except Exception as e:
+            st.fail(e)
         finally:
-            for ev in issued:
+            for ev in st.issued:
                 ev.set()
             ta.join(); tb.join()
             pool.shutdown()
-        if err:
-            raise err[0]
+        if st.err:
+            for s_ in (self.sin, self.sc, self.sout):   # nothing of the failed run may still be in flight when the slots are reused
+                try:
+                    s_.synchronize()
+                except Exception:  # noqa: BLE001 — (the error being raised is the first one)
+                    pass
+            raise st.err[0]
 
 
-_PIPES = {}
+_PIPES = {}     # key -> idle pipes (a run checks one out for its duration: concurrent callers never share slots)
+
+
+def _checkout_pipe(key, make):
+    with _CACHE_LOCK:
+        idle = _PIPES.get(key)
+        if idle:
+            return idle.pop()
+    return make()
+
+
+def _return_pipe(key, pipe, keep=2):
+    with _CACHE_LOCK:
+        idle = _PIPES.setdefault(key, [])
+        if len(idle) < keep:           # (more than that were made for a burst of concurrent callers: let them go)
+            idle.append(pipe)
 
 
 PINNED_RESULTS_MAX = 8 << 30     # host results up to this many bytes per call are returned in pinned memory by default
@@ -429,6 +485,11 @@ def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel
         pinned_results = sum(c.nbytes for c in clips if isinstance(c, np.ndarray)) * r <= PINNED_RESULTS_MAX
     parts = shard_by_frames([int(c.shape[0]) for c in clips], len(devices))
 
+    # torch's current stream is THREAD-local: the workers below would see their own default streams, not the caller's.
+    # The streams the caller's tensors were produced on (and on which the results must be ordered) are looked up HERE.
+    involved = set(devices) | {c.device.index for c in clips if not isinstance(c, np.ndarray) and c.is_cuda}
+    caller = {d: torch.cuda.current_stream(torch.device("cuda", d)) for d in involved}
+
     def work(i):
         mine = parts[i]
         if not mine:
@@ -439,24 +500,29 @@ def resample_batch(clips, in_rate, out_rate, quality="VHQ", devices=None, kernel
             plan = _plan_on(d, in_rate, out_rate, quality, bank0 if i else None)
             host = [k for k in mine if isinstance(clips[k], np.ndarray)]
             dev = [k for k in mine if not isinstance(clips[k], np.ndarray)]
+            if host and sum(int(clips[k].shape[0]) for k in host) == 0:   # nothing to move: empty results of the right shape
+                for k in host:
+                    results[k] = np.empty((0,) + clips[k].shape[1:], clips[k].dtype)
+                host = []
             if host:
                 c0 = clips[host[0]]
                 ch = 1 if c0.ndim == 1 else c0.shape[1]
                 tdt = torch.from_numpy(np.empty(0, c0.dtype)).dtype
-                key = (d, i, tdt, ch, int(kernel), int(block_bytes), bool(pinned_results))   # (one pipe per device SLOT: the same device listed twice runs two)
-                pipe = _PIPES.get(key)
-                if pipe is None:
-                    pipe = _PIPES[key] = _HostPipe(plan, dev_t, tdt, ch, kernel, block_bytes, bool(pinned_results))
+                key = (d, tdt, ch, int(kernel), int(block_bytes), bool(pinned_results))
+                pipe = _checkout_pipe(key, lambda: _HostPipe(plan, dev_t, tdt, ch, kernel, block_bytes, bool(pinned_results)))
                 pipe.plan = plan
-                pipe.run([np.ascontiguousarray(clips[k]) for k in host], results, host)
+                try:
+                    pipe.run([np.ascontiguousarray(clips[k]) for k in host], results, host)
+                finally:
+                    _return_pipe(key, pipe)
             if dev:
-                cur = torch.cuda.current_stream(dev_t)
+                cur = caller[d]
                 side = torch.cuda.Stream(device=dev_t)
                 tens = []
                 for k in dev:
                     c = clips[k]
-                    if c.is_cuda:   # whatever produced the clip on its own device's current stream comes first
-                        side.wait_stream(torch.cuda.current_stream(c.device))
+                    if c.is_cuda:   # whatever produced the clip on its own device's (caller's) current stream comes first
+                        side.wait_stream(caller[c.device.index])
                     with torch.cuda.stream(side):
                         tens.append(c if c.device == dev_t else c.to(dev_t, non_blocking=True))
                 side.wait_stream(cur)

@@ -96,6 +96,52 @@ extern "C" __attribute__((visibility("default"))) const char *stream_probe_name(
 // bytes moved through HBM per byte of `bytes`: 2 for copies, 1 for sweeps
 extern "C" __attribute__((visibility("default"))) int stream_probe_moves(int mode) { return mode <= 5 ? 2 : 1; }
 
+// ---- the MEMORY side of a block-transform launch on its own (bench.py `roofline.floor_us`): workgroup (bx, col) reads
+// `wg_in` floats starting at col * in_col + bx * hop_in (4-byte loads, lane-contiguous: the paired FFT kernels' own load shape)
+// and writes `wg_out` floats at col * out_col + bx * hop_out as 16-byte stores; `lds` bytes of dynamic LDS are declared so
+// that as many workgroups fit a CU as in the real kernel.  No arithmetic.  (tools/ubench/pattern_probe.hip is the
+// batch-only ancestor of this.)
+struct PatternArgs { float *out; const float *in; long long in_col, out_col, in_len, out_len; int hop_in, hop_out, wg_in, wg_out; };
+template <int NT>
+__global__ void __launch_bounds__(NT) k_pattern(PatternArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const float *x = a.in + (long long)blockIdx.y * a.in_col + (long long)blockIdx.x * a.hop_in;
+    const long long left_in = a.in_len - (long long)blockIdx.x * a.hop_in;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < a.wg_in; i += 8 * NT) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int n = i + u * NT; v[u] = (n < a.wg_in && n < left_in) ? x[n] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    if (acc == 1.2345678f) reinterpret_cast<float *>(smem)[threadIdx.x] = acc; // (never: keeps LDS and the loads alive)
+    float *y = a.out + (long long)blockIdx.y * a.out_col + (long long)blockIdx.x * a.hop_out;
+    const long long left_out = a.out_len - (long long)blockIdx.x * a.hop_out;
+    const int head = (int)((4 - ((reinterpret_cast<uintptr_t>(y) >> 2) & 3)) & 3); // elements in front of the first whole granule
+    for (int q = threadIdx.x; q * 4 + head + 3 < a.wg_out && q * 4 + head + 3 < left_out; q += NT)
+        __builtin_nontemporal_store(v4f{acc, acc, acc, acc}, reinterpret_cast<v4f *>(y + head) + q);
+}
+extern "C" __attribute__((visibility("default"))) int stream_probe_pattern(void *dst, const void *src, unsigned grid_x, unsigned grid_y,
+    int hop_in, int hop_out, int wg_in, int wg_out, long long in_col, long long out_col, long long in_len, long long out_len,
+    unsigned lds, unsigned threads, void *stream)
+{
+    PatternArgs a{(float *)dst, (const float *)src, in_col, out_col, in_len, out_len, hop_in, hop_out, wg_in, wg_out};
+    hipStream_t st = (hipStream_t)stream;
+    if (threads == 384) hipLaunchKernelGGL((k_pattern<384>), dim3(grid_x, grid_y), dim3(384), lds, st, a);
+    else if (threads == 320) hipLaunchKernelGGL((k_pattern<320>), dim3(grid_x, grid_y), dim3(320), lds, st, a);
+    else hipLaunchKernelGGL((k_pattern<256>), dim3(grid_x, grid_y), dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+}
+// an empty launch: the floor under any one-kernel step (bench.py `launch_floor_us`)
+__global__ void k_empty() {}
+extern "C" __attribute__((visibility("default"))) int stream_probe_empty(void *stream)
+{
+    hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    return (int)hipGetLastError();
+}
+
 #ifndef PROBE_LIB
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main(int argc, char **argv)
