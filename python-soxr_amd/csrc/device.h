@@ -66,7 +66,7 @@ void resident_leave(volatile uint64_t *words, uint32_t epoch);
 int device_count();
 
 // Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize raised on the function: a driver call, made
-// ONCE per (function, device) — for the largest size a kernel can ask for, 160 KB — never inside the launch path again.
+// once per (function, device) and high-water mark of the sizes asked for — not inside every launch.
 const char *ensure_dyn_lds(const void *fn, size_t bytes);
 
 // Environment switches, read ONCE per process.  The product library reads four names:

@@ -2110,16 +2110,20 @@ int device_count()
 const char *ensure_dyn_lds(const void *fn, size_t bytes)
 {
     if (bytes <= 64 * 1024) return nullptr;
-    if (bytes > 160 * 1024) return "a launch asks for more LDS than a CU has (160 KB)";
     static std::mutex mu;
-    static std::vector<std::pair<const void *, int>> done; // (function, device) pairs already raised to 160 KB
+    struct Raised { const void *fn; int dev; size_t bytes; };
+    static std::vector<Raised> done; // the limit each (function, device) has been raised to
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    for (const auto &e : done)
-        if (e.first == fn && e.second == dev) return nullptr;
-    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done.push_back({fn, dev});
+    Raised *r = nullptr;
+    for (auto &e : done)
+        if (e.fn == fn && e.dev == dev) { r = &e; break; }
+    if (r && r->bytes >= bytes) return nullptr;
+    // (the limit counts against 160 KB together with the kernel's STATIC LDS: raise to what is asked for, not to the maximum)
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (r) r->bytes = bytes;
+    else done.push_back({fn, dev, bytes});
     return nullptr;
 }
 

@@ -176,3 +176,95 @@ def test_config3_whole_batch_on_one_gpu(oracle):
             assert _rms(yc[k0:k0 + 2000] - want) <= 1e-6 * max(_rms(want), 0.05)
     del x, y
     torch.cuda.empty_cache()
+
+
+def test_host_pipeline_surfaces_errors_instead_of_hanging(monkeypatch):
+    """Fault injection into `_HostPipe` (three host threads, three streams): an error in the issuing loop mid-corpus — the
+    library refusing the third block — and an error inside a copy thread must both come back as exceptions from
+    `resample_batch`, with every helper thread stopped, and the pipe must serve the next call normally."""
+    import threading
+    from soxr_amd import dist as sdist, _native as nat
+    rng = np.random.default_rng(4)
+    clips = [(rng.standard_normal(48000) * 0.25).astype(np.float32) for _ in range(24)]
+    kw = dict(devices=[0], block_bytes=4 * 48000 * 3, kernel=6)          # 8 blocks of 3 clips
+    good = sdist.resample_batch(clips, 48000, 44100, "VHQ", **kw)
+    before = threading.active_count()
+
+    # (a) the C entry fails on its third call
+    real = nat.lib.hipsoxr_run_device
+    calls = {"n": 0}
+
+    class Failing:
+        def __call__(self, *a):
+            calls["n"] += 1
+            return b"injected failure" if calls["n"] == 3 else real(*a)
+    monkeypatch.setattr(nat.lib, "hipsoxr_run_device", Failing())
+    done = {}
+
+    def run():
+        try:
+            sdist.resample_batch(clips, 48000, 44100, "VHQ", **kw)
+            done["r"] = "no error"
+        except Exception as e:  # noqa: BLE001
+            done["r"] = e
+    t = threading.Thread(target=run); t.start(); t.join(60)
+    assert not t.is_alive(), "resample_batch hangs after a failed launch"
+    assert isinstance(done["r"], RuntimeError) and "injected failure" in str(done["r"]), done
+    monkeypatch.setattr(nat.lib, "hipsoxr_run_device", real)
+
+    # (b) a copy thread fails (pageable results: the unstager allocates)
+    real_empty = np.empty
+    hits = {"n": 0}
+
+    def bad_empty(*a, **k):
+        if threading.current_thread() is not threading.main_thread() and a and a[0] == (44100,):
+            hits["n"] += 1
+            if hits["n"] == 5:
+                raise MemoryError("injected allocation failure")
+        return real_empty(*a, **k)
+    monkeypatch.setattr(np, "empty", bad_empty)
+    t = threading.Thread(target=lambda: done.__setitem__("r2", _try(lambda: sdist.resample_batch(clips, 48000, 44100, "VHQ", pinned_results=False, **kw))))
+    t.start(); t.join(60)
+    assert not t.is_alive(), "resample_batch hangs after a failed copy thread"
+    assert isinstance(done["r2"], MemoryError), done
+    monkeypatch.setattr(np, "empty", real_empty)
+
+    # the pipes still work, and no helper thread is left behind
+    again = sdist.resample_batch(clips, 48000, 44100, "VHQ", **kw)
+    assert all(np.array_equal(a, b) for a, b in zip(good, again))
+    assert threading.active_count() <= before
+
+
+def _try(f):
+    try:
+        return f()
+    except Exception as e:  # noqa: BLE001
+        return e
+
+
+def test_host_pipeline_concurrent_callers_do_not_share_slots():
+    """Two Python threads in `resample_batch` on host arrays at once (the module's concurrency model): each run checks a
+    pipe out for itself — results equal the single-threaded ones bit for bit."""
+    import threading
+    from soxr_amd import dist as sdist
+    rng = np.random.default_rng(6)
+    sets = [[(rng.standard_normal(int(n)) * 0.25).astype(np.float32) for n in rng.integers(20000, 90000, size=40)] for _ in range(3)]
+    want = [sdist.resample_batch(c, 48000, 44100, "VHQ", devices=[0], kernel=6, block_bytes=1 << 20) for c in sets]
+    got = [None] * 3
+
+    def run(i):
+        for _ in range(3):
+            got[i] = sdist.resample_batch(sets[i], 48000, 44100, "VHQ", devices=[0], kernel=6, block_bytes=1 << 20)
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]; [t.join(300) for t in ts]
+    for w, g in zip(want, got):
+        assert all(np.array_equal(a, b) for a, b in zip(w, g))
+
+
+def test_zero_length_host_share_is_served():
+    """A device's share made of zero-length host clips (round-4 advisor finding): empty results, no dead stager."""
+    from soxr_amd import dist as sdist
+    outs = sdist.resample_batch([np.zeros(0, np.float32), np.zeros((0, 2), np.float32)[:, 0].copy()], 48000, 44100, "VHQ", devices=[0])
+    assert [o.shape for o in outs] == [(0,), (0,)]
+    outs = sdist.resample_batch([np.zeros(0, np.float32), np.ones(4800, np.float32)], 48000, 44100, "VHQ", devices=[0])
+    assert outs[0].shape == (0,) and outs[1].shape == (4410,)

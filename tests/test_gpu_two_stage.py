@@ -126,3 +126,31 @@ def test_two_stage_over_many_ratios(quality):
         assert rel <= 1e-6 and ends <= 8e-6, (a, b, quality, plan.phases, rel, ends)
         worst = max(worst, rel)
     assert worst > 0        # (at least one pair took the two-stage form)
+
+
+def test_an_installed_bank_is_honoured_by_every_engine():
+    """Round-4 advisor finding: the two-stage form samples the plan's ANALYTIC prototype, so a bank installed from outside
+    (`hipsoxr_plan_set_bank`, the bank broadcast) must take the plan off that form — else AUTO float device jobs of
+    >= 8192 frames would silently ignore it while every other path follows it.  A scaled bank scales the output of
+    every engine; the plan's own bank re-installed (the broadcast's usual case) changes nothing and keeps the fast form."""
+    import torch
+    from soxr_amd import device as dev
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    x = torch.randn(200000, device="cuda", generator=g) * 0.25
+    plan = dev.Plan(48000, 44101.5, "VHQ")
+    assert plan.phases > 0
+    y_auto = dev.resample_tensor(plan, x).double()
+    y_exact = dev.resample_tensor(plan, x, kernel=dev.KERNEL_EXACT).double()
+    assert not torch.equal(y_auto.float(), y_exact.float())            # AUTO really is the two-stage form here ...
+    assert float((y_auto - y_exact).norm() / y_exact.norm()) <= 1e-6   # ... and agrees with the exact engine
+    same = dev.Plan(48000, 44101.5, "VHQ")
+    same.set_bank(plan.bank())                                          # identical bank: a no-op, the fast form stays
+    assert torch.equal(dev.resample_tensor(same, x), dev.resample_tensor(plan, x))
+    half = dev.Plan(48000, 44101.5, "VHQ")
+    half.set_bank(0.5 * plan.bank())
+    for kernel in (dev.KERNEL_AUTO, dev.KERNEL_EXACT):
+        got = dev.resample_tensor(half, x, kernel=kernel).double()
+        assert float((got - 0.5 * y_exact).norm() / y_exact.norm()) <= 1e-6, kernel
+    zero = dev.Plan(48000, 44101.5, "VHQ")
+    zero.set_bank(np.zeros_like(plan.bank()))
+    assert not dev.resample_tensor(zero, x).any()
