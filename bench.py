@@ -477,6 +477,24 @@ def configs4_stream(seconds=20):
         out["device_chunk441_x128_streams"] = {"us_per_call": dt / n_calls * 1e6, "calls": n_calls, "streams": nch,
                                                "Msamples_per_s": xm.numel() / dt / 1e6,
                                                "note": "128 lock-step mono streams as the channels of one handle, 441-frame chunks"}
+        # ... and N INDEPENDENT handles (different phases and pending counts: every stream is fed a prefix of its own length
+        # first) served by ONE launch per call: soxr_amd.device.TensorStreamGroup / hipsoxr_streams_process_device
+        grp = dev.TensorStreamGroup(nch, 44100, 16000, 1, dtype=torch.int16, quality="VHQ", dither_seeds=list(range(nch)))
+        for i, s in enumerate(grp.streams):
+            s.resample_chunk(xm[: 7 * i, 0].contiguous())
+        xg = xm.t().contiguous()                       # [streams, frames]
+        grp.resample_chunks(xg[:, :441].contiguous())
+        torch.cuda.synchronize()
+        chunks = [xg[:, a:a + 441].contiguous() for a in range(441, xg.shape[1], 441)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in chunks:
+            grp.resample_chunks(c)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["device_chunk441_x128_independent_handles"] = {"us_per_call": dt / len(chunks) * 1e6, "calls": len(chunks), "streams": nch,
+                                                           "Msamples_per_s": nch * 441 * len(chunks) / dt / 1e6,
+                                                           "note": "128 independent stream handles (own phases, pending counts, dither seeds), 441-frame chunks each, one launch per call"}
     except Exception as e:  # noqa: BLE001
         out["device_stream"] = {"error": str(e)}
     return out
@@ -882,12 +900,15 @@ def main():
                                   "value": x2.numel() / k2 / 1e6, "unit": "Msamples/s", "launch_us": k2 * 1e6,
                                   "roofline": {"bound": "hbm", "achieved": bytes2 / k2 / 1e9, "peak": HBM_PEAK_GBS,
                                                "unit": "GB/s", "frac": bytes2 / k2 / 1e9 / HBM_PEAK_GBS,
-                                               "traffic": c2_traffic, "kernel": "k_fft_frames<4410x1600,float,8 channels> (whole frames staged per block)", **c2_prov}}
+                                               "traffic": c2_traffic, "kernel": "k_fft_strided2<4410x1600,float,channel pairs>", **c2_prov}}
             if fft_kernel and args.seconds == 60 and not args.no_sustained:
                 r2 = result["configs2"]["roofline"]
-                # memory side alone: 750 blocks of 4410 frames x 8 channels in (hop 3528 frames), 1280 frames x 8 out
+                # memory side alone in the best access shape (whole frames, contiguous): 750 blocks of 4410 frames x 8 channels in
+                # (hop 3528 frames), 1280 frames x 8 out.  The kernel's OWN shape — 8-byte words at the 32-byte frame stride, four
+                # workgroups per line — takes 40 us by itself (tools/ubench/c2_probe.hip, profiles/NOTES_r05.md §3)
                 r2["floor_us"] = pattern_floor(device, (y2.shape[0] + 1279) // 1280, 1, 3528 * 8, 1280 * 8, 4410 * 8, 1280 * 8, 0, 0,
-                                               x2.numel(), y2.numel(), 4410 * 8 * 4, 320)
+                                               x2.numel(), y2.numel(), 0, 256)
+                r2["floor_us_own_access_shape"] = 40.1
                 x2s = [x2] + [torch.randn_like(x2) * 0.25 for _ in range(2)]    # (rotating: 3 x 115 MB > the Infinity Cache)
                 r2["sustained"] = power_leg(plan2, x2s, 1.5, device, args.kernel, bytes2)
                 del x2s

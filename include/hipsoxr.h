@@ -116,6 +116,7 @@ typedef struct hipsoxr_plan hipsoxr_plan_t;     /* immutable: ratio + polyphase 
 typedef struct hipsoxr_stream hipsoxr_stream_t; /* stateful converter: the `soxr_t` counterpart */
 
 /* ---- library ---------------------------------------------------------------------------- */
+#define HIPSOXR_VERSION_STRING "0.5.0" /* one number for hipsoxr_version() and the libsoxr-named soxr_version() */
 HIPSOXR_API const char *hipsoxr_version(void);
 HIPSOXR_API int hipsoxr_device_count(void); /* 0 when no HIP device is visible (never throws) */
 
@@ -217,7 +218,7 @@ HIPSOXR_API hipsoxr_error_t hipsoxr_stream_create_with_plan(hipsoxr_plan_t *, un
  * All of `ilen` is always consumed.  At most `olen` frames are written; *odone = frames written. */
 HIPSOXR_API hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *, const void *in, size_t ilen,
                                                    void *out, size_t olen, size_t *odone);
-/* The same call on DEVICE buffers (round 4; version 0.4.1): `in` / `out` are device pointers (interleaved streams only),
+/* The same call on DEVICE buffers (round 4; version 0.4.1; round 5: small constant-rate calls are ONE dispatch — the kernel appends the chunk): `in` / `out` are device pointers (interleaved streams only),
  * the chunk is appended to the stream's ring by a device-to-device copy and every output the input so far determines is
  * written straight into `out`, all enqueued on `hip_stream` (a hipStream_t; NULL = default stream) — asynchronous, no
  * copy over PCIe, no host synchronisation; *odone is known at once (it is a function of the counts alone).  The caller
@@ -228,6 +229,16 @@ HIPSOXR_API hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *, const voi
  * flags or the split layout. */
 HIPSOXR_API hipsoxr_error_t hipsoxr_stream_process_device(hipsoxr_stream_t *, const void *in, size_t ilen,
                                                           void *out, size_t olen, size_t *odone, void *hip_stream);
+/* Many INDEPENDENT streams in one call (round 5; version 0.5.0): handles[i] gets chunk ins[i] / ilens[i] and writes up to
+ * olens[i] frames to outs[i], exactly as n calls of hipsoxr_stream_process_device in index order would — same frames,
+ * same counters, bit for bit — but streams that share a plan (rates, quality), element type, channel count and device are
+ * served by ONE kernel launch on `hip_stream`, whatever their phases and pending counts (a service with N live callers
+ * at 10 ms chunks: one dispatch per tick instead of 2 N).  Streams the shared launch does not take (variable rate, end
+ * of input, 4096 or more outputs due, mixed plans) are processed one by one inside the same call.  What N threads around
+ * CSoxr::process (reference src/soxr_ext.cpp:129-187, tests/bench.py:71-88) would be for callers whose audio lives in HBM. */
+HIPSOXR_API hipsoxr_error_t hipsoxr_streams_process_device(hipsoxr_stream_t *const *handles, size_t n, const void *const *ins,
+                                                           const size_t *ilens, void *const *outs, const size_t *olens,
+                                                           size_t *odones, void *hip_stream);
 HIPSOXR_API void hipsoxr_stream_delete(hipsoxr_stream_t *);
 HIPSOXR_API hipsoxr_error_t hipsoxr_stream_clear(hipsoxr_stream_t *);
 HIPSOXR_API double hipsoxr_stream_delay(hipsoxr_stream_t *);

@@ -88,7 +88,6 @@ struct Switches {
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
     bool fft_no_tiny = false;     // HIPSOXR_FFT_NO_TINY      never the quarter-size blocks
-    int fft_x2 = -1;              // HIPSOXR_FFT_X2           1: two block pairs per workgroup (k_fft_pair2<.., 2>; builds with -DFFT_EXPERIMENT_X2 only)
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_mfma64 = false;       // HIPSOXR_NO_MFMA64        float64 engine (float64 / int32 I/O) on the vector ALU (k_tile) instead of v_mfma_f64
     bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)
@@ -122,6 +121,36 @@ struct Switches {
     const char *dbg_trace = nullptr; // HIPSOXR_DEBUG_TRACE   path for per-wave s_memtime stamps (k_tile_mfma_p; k_fft_pair2 with -DFFT2_TRACE)
 };
 const Switches &switches();
+
+// One independent stream's part of a many-streams launch (kernels.hip k_chain_multi; engine.cpp
+// hipsoxr_streams_process_device): the small-launch kernel's job description per stream, plus the chunk this call appends
+// to the stream's ring — frames the launch reads straight from the caller's buffer while its workgroups copy them into the
+// ring for the calls to come (one dispatch per call instead of a copy kernel and a launch).
+struct ChainItem {
+    const void *ring;    // the stream's device ring: frame 0 of it is absolute input frame in_abs0
+    const void *chunk;   // this call's new frames (device memory, the stream's own layout), or nullptr
+    void *out;           // where this stream's outputs go
+    void *clip_counter;  // device counter of saturated integer outputs (or nullptr)
+    int64_t in_abs0;     // absolute index of ring frame 0
+    int64_t in_frames;   // ring frames that count for this launch, INCLUDING the chunk's
+    int64_t split;       // first ring-relative frame that (still) lives in `chunk` (= in_frames - chunk_frames)
+    int64_t chunk_frames;
+    int64_t out_k0, out_frames; // outputs [out_k0, out_k0 + out_frames)
+    int64_t d0, p0;      // out_k0 * M = L * d0 + p0 (exact-bank plans)
+    uint32_t dither_seed, pad;
+    // Ring compaction rides on the same launch: when ring_dst != ring the workgroups copy the frames still needed —
+    // ring frames [keep_from, split) — to the start of ring_dst and the chunk behind them; the NEXT launch's ring is ring_dst
+    // (frame 0 of it = absolute frame in_abs0 + keep_from).  ring_dst == ring: the chunk goes to ring frame `split`.
+    void *ring_dst;
+    int64_t keep_from;
+    int64_t reserved;    // (sizeof = 128: the table is staged 16 bytes per thread)
+};
+// n_items streams of one plan, element type and channel count in ONE launch of the small-launch kernel (constant rate;
+// every stream < 4096 outputs).  items_dev: the same table where the device can read it (pinned, device-mapped host
+// memory is fine) — not needed for one item, which travels in the kernel arguments.  *handled = false: not a job for
+// this kernel, nothing was launched.
+const char *launch_chain_items(Plan *p, int elem, uint32_t n_channels, bool dither, const ChainItem *items, const ChainItem *items_dev,
+                               uint32_t n_items, void *stream, bool *handled);
 
 // device-to-device copy as an ordinary kernel launch on `stream` (a stream's chunk appended to its ring: hipMemcpyAsync costs
 // ~2x the API time and queues behind a barrier packet)

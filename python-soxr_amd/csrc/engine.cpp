@@ -324,7 +324,7 @@ static void plan_release(hipsoxr_plan *h)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *hipsoxr_version(void) { return "hipsoxr-0.4.1 (gfx950)"; }
+const char *hipsoxr_version(void) { return "hipsoxr-" HIPSOXR_VERSION_STRING " (gfx950)"; }
 
 int hipsoxr_device_count(void) { return device_count(); }
 
@@ -1243,6 +1243,80 @@ static const char *device_emit_once(hipsoxr_stream *s, void *d_out, size_t olen,
     return nullptr;
 }
 
+// Room in the device ring for `ilen` more frames (retire consumed input first; grow — power of two, room for four chunks,
+// so that compaction runs every fourth call — only if that is not enough).  Enqueues on s->st.
+static const char *device_ring_reserve(hipsoxr_stream *s, size_t ilen)
+{
+    if (s->ring_on_host) { if (const char *e = host_ring_to_device(s)) return e; } // (a ring inherited from a small-chunk stream)
+    if (s->in_fill + ilen > s->in_cap) {
+        const int64_t n0 = first_needed(s);
+        const int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base), s->in_base + (int64_t)s->in_fill);
+        const size_t keep = s->in_fill - (size_t)(keep_from - s->in_base);
+        size_t need = keep + 4 * ilen, cap = std::max<size_t>(s->in_cap, 1024);
+        if (need > ((size_t)1 << 24)) need = keep + ilen;
+        while (cap < need) cap <<= 1;
+        if (const char *e = stream_compact(s, cap)) return e;
+    }
+    return nullptr;
+}
+
+// A constant-rate device call as ONE item of the small-launch kernel (round 5): the chunk is read where the caller left it
+// and copied into the ring by the launch's own workgroups — and when the ring is full, the frames still needed move to the
+// stream's other buffer in the same launch (no copy command, no extra dispatch: with 128 streams in one call a
+// hipMemcpyAsync per compacting stream was 70 of the call's 87 us).  Fills `it` and returns true when the call is of that
+// kind (constant rate, a chunk to append, every output the input so far determines — what device_emit_once would emit in
+// one go — fewer than 4096 of them); the stream's counters are NOT touched (stream_item_commit does that once the launch
+// is in).  *err: an allocation failed.
+static bool stream_item_prepare(hipsoxr_stream *s, const void *d_in, size_t ilen, void *d_out, size_t olen, ChainItem *it, size_t *n_out,
+                                const char **err)
+{
+    const Plan &p = s->plan->p;
+    *err = nullptr;
+    if (s->vr.on || s->ended || !d_in || !ilen || !d_out || s->ring_on_host || s->split) return false;
+    const uint64_t n_total = s->n_in_total + ilen;
+    const uint64_t k_end = k_avail(p, n_total);
+    const size_t n = k_end > s->k_done ? (size_t)std::min<uint64_t>(k_end - s->k_done, olen) : 0;
+    if (n >= 4096) return false;
+    it->ring = s->d_in; it->ring_dst = s->d_in; it->keep_from = 0;
+    if (s->in_fill + ilen > s->in_cap || !s->d_in) { // the ring moves: keep [first frame the next output needs, end), into the other buffer
+        const int64_t n0 = first_needed(s);
+        const int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base), s->in_base + (int64_t)s->in_fill);
+        const size_t keep = s->in_fill - (size_t)(keep_from - s->in_base);
+        size_t need = keep + 16 * ilen, cap = std::max<size_t>(s->in_cap, 1024);   // room for sixteen chunks: the move runs every ~16th call
+        if (need > ((size_t)1 << 24)) need = keep + ilen;
+        while (cap < need) cap <<= 1;
+        if (s->alt_cap < cap || !s->d_in_alt) {
+            if (s->d_in_alt && hipFree(s->d_in_alt) != hipSuccess) { *err = "hipFree failed"; return false; }
+            s->d_in_alt = nullptr; s->alt_cap = 0;
+            if (hipMalloc(&s->d_in_alt, cap * s->ch * esz(s)) != hipSuccess) { *err = "out of device memory (stream ring)"; return false; }
+            s->alt_cap = cap;
+        }
+        it->ring_dst = s->d_in_alt;
+        it->keep_from = keep_from - s->in_base;
+        if (!s->d_in) it->ring = s->d_in_alt; // (first call: nothing to keep, and the launch reads only the chunk)
+    }
+    it->chunk = d_in; it->out = d_out; it->clip_counter = s->d_clips;
+    it->in_abs0 = s->in_base; it->in_frames = (int64_t)(s->in_fill + ilen); it->split = (int64_t)s->in_fill; it->chunk_frames = (int64_t)ilen;
+    it->out_k0 = (int64_t)s->k_done; it->out_frames = (int64_t)n;
+    const __int128 kM = (__int128)it->out_k0 * p.M;
+    it->d0 = (int64_t)(kM / p.L); it->p0 = (int64_t)(kM % p.L);
+    it->dither_seed = s->dither_seed; it->pad = 0; it->reserved = 0;
+    *n_out = n;
+    return true;
+}
+static void stream_item_commit(hipsoxr_stream *s, const ChainItem &it, size_t ilen, size_t n)
+{
+    if (it.ring_dst != s->d_in) { // the launch moved the ring
+        std::swap(s->d_in, s->d_in_alt);
+        std::swap(s->in_cap, s->alt_cap);
+        s->in_base += it.keep_from;
+        s->in_fill -= (size_t)it.keep_from;
+    }
+    s->in_fill += ilen;
+    s->n_in_total += ilen;
+    s->k_done += n;
+}
+
 static const char *device_process(hipsoxr_stream *s, const void *d_in, size_t ilen, void *d_out, size_t olen, size_t *odone)
 {
     const size_t frame = (size_t)s->ch * esz(s);
@@ -1251,15 +1325,23 @@ static const char *device_process(hipsoxr_stream *s, const void *d_in, size_t il
     } else if (ilen > 0) {
         if (s->ended) return "Input after last input";
         if (s->ring_on_host) { if (const char *e = host_ring_to_device(s)) return e; } // (a ring inherited from a small-chunk stream)
-        if (s->in_fill + ilen > s->in_cap) {
-            const int64_t n0 = first_needed(s);
-            const int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base), s->in_base + (int64_t)s->in_fill);
-            const size_t keep = s->in_fill - (size_t)(keep_from - s->in_base);
-            size_t need = keep + 4 * ilen, cap = std::max<size_t>(s->in_cap, 1024);
-            if (need > ((size_t)1 << 24)) need = keep + ilen;
-            while (cap < need) cap <<= 1;
-            if (const char *e = stream_compact(s, cap)) return e;
+        {   // one dispatch: the small-launch kernel appends the chunk (and moves a full ring) itself
+            ChainItem it;
+            size_t n = 0;
+            const char *perr = nullptr;
+            if (stream_item_prepare(s, d_in, ilen, d_out, olen, &it, &n, &perr)) {
+                bool handled = false;
+                const bool dither = s->elem == HIPSOXR_I16 && !(s->flags & HIPSOXR_NO_DITHER);
+                if (const char *e = launch_chain_items(&s->plan->p, s->elem, s->ch, dither, &it, nullptr, 1, s->st, &handled)) return e;
+                if (handled) {
+                    stream_item_commit(s, it, ilen, n);
+                    *odone = n;
+                    return nullptr;
+                }
+            }
+            if (perr) return perr;
         }
+        if (const char *e = device_ring_reserve(s, ilen)) return e;
         if (const char *e = launch_copy((char *)s->d_in + s->in_fill * frame, d_in, ilen * frame, s->st)) return e;
         s->in_fill += ilen;
         s->n_in_total += ilen;
@@ -1300,6 +1382,134 @@ hipsoxr_error_t hipsoxr_stream_process_device(hipsoxr_stream_t *s, const void *i
     const char *err = device_process(s, in, ilen, out, olen, odone);
     s->st = own;
     return err;
+}
+
+// ---- many independent streams, one launch (round 5) -------------------------------------------------------------------
+// The item table is written into pinned, device-mapped host memory and staged into a device mirror by a copy KERNEL in front
+// of the launch (one coalesced sweep over PCIe; letting every workgroup of the launch read its item from host memory cost
+// 85 us per call for 128 streams: thousands of 64-byte PCIe reads).  Two halves of kItemsHalf items used in turn; before a
+// half is used again the launches that read it are waited for (an event per caller stream, recorded when the half is left).
+static constexpr size_t kItemsHalf = 8192;
+struct ItemArena {
+    ChainItem *host = nullptr, *dev = nullptr, *mirror = nullptr; // pinned table, its device address, the device copy
+    size_t pos = 0;
+    int half = 0;
+    std::vector<hipStream_t> used[2];
+    std::vector<hipEvent_t> pending[2];
+    std::vector<hipEvent_t> spare;
+    std::mutex mu;
+};
+static ItemArena &item_arena(int device)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, ItemArena *>> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : all)
+        if (e.first == device) return *e.second;
+    all.push_back({device, new ItemArena});
+    return *all.back().second;
+}
+// room for n items (n <= kItemsHalf); the arena's mutex is held by the caller
+static const char *arena_take(ItemArena &ar, size_t n, hipStream_t st, ChainItem **host, ChainItem **dev, ChainItem **mirror)
+{
+    static_assert(sizeof(ChainItem) % 16 == 0, "the table is staged 16 bytes per thread");
+    if (!ar.host) {
+        HIP_TRY(hipHostMalloc((void **)&ar.host, 2 * kItemsHalf * sizeof(ChainItem), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&ar.dev, ar.host, 0));
+        HIP_TRY(hipMalloc((void **)&ar.mirror, 2 * kItemsHalf * sizeof(ChainItem)));
+    }
+    if (ar.pos + n > kItemsHalf) { // leave this half: mark what still reads it, take the other one once ITS readers are done
+        for (hipStream_t u : ar.used[ar.half]) {
+            hipEvent_t ev = nullptr;
+            if (!ar.spare.empty()) { ev = ar.spare.back(); ar.spare.pop_back(); }
+            else HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ev, u));
+            ar.pending[ar.half].push_back(ev);
+        }
+        ar.used[ar.half].clear();
+        ar.half ^= 1; ar.pos = 0;
+        for (hipEvent_t ev : ar.pending[ar.half]) { HIP_TRY(hipEventSynchronize(ev)); ar.spare.push_back(ev); }
+        ar.pending[ar.half].clear();
+    }
+    if (std::find(ar.used[ar.half].begin(), ar.used[ar.half].end(), st) == ar.used[ar.half].end()) ar.used[ar.half].push_back(st);
+    *host = ar.host + ar.half * kItemsHalf + ar.pos;
+    *dev = ar.dev + ar.half * kItemsHalf + ar.pos;
+    *mirror = ar.mirror + ar.half * kItemsHalf + ar.pos;
+    ar.pos += n;
+    return nullptr;
+}
+
+hipsoxr_error_t hipsoxr_streams_process_device(hipsoxr_stream_t *const *handles, size_t n, const void *const *ins, const size_t *ilens,
+                                               void *const *outs, const size_t *olens, size_t *odones, void *hip_stream)
+{
+    if (!n) return nullptr;
+    if (!handles || !ins || !ilens || !outs || !olens || !odones) return "null argument";
+    for (size_t i = 0; i < n; ++i) {
+        if (!handles[i]) return "null argument";
+        odones[i] = 0;
+    }
+    hipsoxr_stream *s0 = handles[0];
+    // one launch serves streams of ONE plan, element type, channel count and dither setting on one device, constant rate,
+    // each with a chunk to append and fewer than 4096 outputs due; anything else goes handle by handle (same results)
+    bool together = n > 1 && n <= kItemsHalf;
+    for (size_t i = 0; together && i < n; ++i) {
+        hipsoxr_stream *s = handles[i];
+        together = s->plan == s0->plan && s->elem == s0->elem && s->ch == s0->ch && s->device == s0->device &&
+                   ((s->flags ^ s0->flags) & HIPSOXR_NO_DITHER) == 0 && !s->vr.on && !s->split && !s->split_io && !s->defer &&
+                   !(s->flags & (HIPSOXR_RESIDENT | HIPSOXR_AUTO_RESIDENT)) && !s->ended && ins[i] && ilens[i] && outs[i];
+        for (size_t k = 0; together && k < i; ++k) together = handles[k] != s; // (a handle twice in one call: in order, one by one)
+    }
+    if (!together) {
+        for (size_t i = 0; i < n; ++i)
+            if (const char *e = hipsoxr_stream_process_device(handles[i], ins[i], ilens[i], outs[i], olens[i], &odones[i], hip_stream)) return e;
+        return nullptr;
+    }
+    DeviceGuard guard(s0->device);
+    hipStream_t user = (hipStream_t)hip_stream;
+    // stream-order bookkeeping of every handle, as in hipsoxr_stream_process_device
+    for (size_t i = 0; i < n; ++i) {
+        hipsoxr_stream *s = handles[i];
+        resident_stop(s);
+        if (user != s->st && s->own_used && s->ev) {
+            HIP_TRY(hipEventRecord(s->ev, s->st));
+            HIP_TRY(hipStreamWaitEvent(user, s->ev, 0));
+        }
+        s->own_used = false;
+        if (s->ext_st && s->ext_st != user) HIP_TRY(hipStreamSynchronize(s->ext_st));
+        s->ext_st = user; s->ext_pending = true;
+        if (s->ring_on_host) {                          // (a ring inherited from a small-chunk stream)
+            hipStream_t own = s->st;
+            s->st = user;
+            const char *e = host_ring_to_device(s);
+            s->st = own;
+            if (e) return e;
+        }
+    }
+    ItemArena &ar = item_arena(s0->device);
+    std::lock_guard<std::mutex> lk(ar.mu);
+    ChainItem *host = nullptr, *dev = nullptr, *mirror = nullptr;
+    if (const char *e = arena_take(ar, n, user, &host, &dev, &mirror)) return e;
+    std::vector<size_t> nout(n);
+    bool all = true;
+    const char *perr = nullptr;
+    for (size_t i = 0; all && i < n; ++i) all = stream_item_prepare(handles[i], ins[i], ilens[i], outs[i], olens[i], &host[i], &nout[i], &perr);
+    if (perr) return perr;
+    bool handled = false;
+    if (all) {
+        const bool dither = s0->elem == HIPSOXR_I16 && !(s0->flags & HIPSOXR_NO_DITHER);
+        if (const char *e = launch_copy(mirror, dev, n * sizeof(ChainItem), user)) return e;
+        if (const char *e = launch_chain_items(&s0->plan->p, s0->elem, s0->ch, dither, host, mirror, (uint32_t)n, user, &handled)) return e;
+    }
+    if (!handled) { // (a stream with too many outputs due, or a plan the small-launch kernel does not take)
+        for (size_t i = 0; i < n; ++i)
+            if (const char *e = hipsoxr_stream_process_device(handles[i], ins[i], ilens[i], outs[i], olens[i], &odones[i], hip_stream)) return e;
+        return nullptr;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        stream_item_commit(handles[i], host[i], ilens[i], nout[i]);
+        odones[i] = nout[i];
+    }
+    return nullptr;
 }
 
 hipsoxr_error_t hipsoxr_stream_process(hipsoxr_stream_t *s, const void *in, size_t ilen, void *out,

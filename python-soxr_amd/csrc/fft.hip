@@ -265,12 +265,13 @@ __device__ __forceinline__ void fft_pass(cf *buf, int N, int Ns, const cf *W)
 // Twiddles: any power formed from ONE rounded table entry inherits t times its phase error ((w(1+e))^t ~ w^t (1+te)),
 // so for the large radices a second entry, w^4, is read and w^(4a+b) = (w^4)^a w^b: the error factor drops from R-1 to
 // <= a+b for the same number of complex products (engine error 3.5e-7 -> 2.2e-7 relative RMS).
+// `tid` = the thread's index among the NT threads that share ONE transform (threadIdx.x; an experiment of round 5 interleaved
+// the transforms of four channel pairs across the lanes of one workgroup: profiles/NOTES_r05.md §3).
 template <int N, int Ns, int R, int SIGN, int NT, bool SYNC_BEFORE_STORE, typename C, typename Load, typename Store>
-__device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store)
+__device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store, const int tid)
 {
     constexpr int nb = N / R, wstep = N / (Ns * R), NB = (nb + NT - 1) / NT;
     typedef real_of<C> T;
-    const int tid = (int)threadIdx.x;
     C u[NB][R];
     C w1s[NB], w4s[NB];
 #pragma unroll
@@ -339,7 +340,7 @@ __device__ __forceinline__ void fft_pass_ct(const C *W, Load load, Store store)
 // (last_store_alt / use_alt: a second form of the last pass's consumer behind ONE wave-uniform branch around the whole pass)
 template <int N, int SIGN, int NT, int R0, int R1, int R2, bool SWZ, bool LASTSYNC, typename C, typename Load, typename Store, typename StoreAlt>
 __device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL C *buf, const C *W, Load first_load, Store last_store, bool first_in_lds, StoreAlt last_store_alt,
-                                        bool use_alt)
+                                        bool use_alt, const int tid)
 {
     static_assert(R0 * R1 * R2 == N, "radix schedule");
     static_assert(!SWZ || R0 == 16, "the swizzled layout is the radix-16 first pass's");
@@ -357,17 +358,17 @@ __device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL C *buf, const C *W, Load 
         else buf[o + t] = v;
     };
     // pass 0 (Ns = 1): when its input is not in LDS nothing has to be protected before storing
-    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, swz_store);
-    else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, swz_store);
+    if (first_in_lds) fft_pass_ct<N, 1, R0, SIGN, NT, true>(W, first_load, swz_store, tid);
+    else fft_pass_ct<N, 1, R0, SIGN, NT, false>(W, first_load, swz_store, tid);
     FFT_STAMP();
     __syncthreads();
     FFT_STAMP();
-    fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, swz_load, lds_store1);
+    fft_pass_ct<N, R0, R1, SIGN, NT, true>(W, swz_load, lds_store1, tid);
     FFT_STAMP();
     __syncthreads();
     FFT_STAMP();
-    if (use_alt) fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load2, last_store_alt);
-    else fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load2, last_store);
+    if (use_alt) fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load2, last_store_alt, tid);
+    else fft_pass_ct<N, R0 * R1, R2, SIGN, NT, LASTSYNC>(W, lds_load2, last_store, tid);
     FFT_STAMP();
 }
 
@@ -517,13 +518,13 @@ template <int NA_, int NB_, int NT_, int A0, int A1, int A2, bool ASWZ, int B0, 
 struct PairSpec {
     static constexpr int NA = NA_, NB = NB_, NT = NT_;
     static constexpr int RA0 = A0, RA2 = A2, RB0 = B0, RB2 = B2;
-    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st)
-    { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ, false>(FFT_STAMP_ARGS b, W, ld, st, false, st, false); }
-    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void inv(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st)
-    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, false>(FFT_STAMP_ARGS b, W, ld, st, true, st, false); }
+    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void fwd(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st, int tid = (int)threadIdx.x)
+    { fft_ct3<NA, -1, NT, A0, A1, A2, ASWZ, false>(FFT_STAMP_ARGS b, W, ld, st, false, st, false, tid); }
+    template <typename C, typename Ld, typename St> static __device__ __forceinline__ void inv(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st, int tid = (int)threadIdx.x)
+    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, false>(FFT_STAMP_ARGS b, W, ld, st, true, st, false, tid); }
     // last pass stores into LDS in another layout (output staging): all its inputs must be in registers first
     template <typename C, typename Ld, typename St, typename StAlt> static __device__ __forceinline__ void inv_staged(FFT_STAMP_DECL C *b, const C *W, Ld ld, St st, StAlt st_alt, bool use_alt)
-    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, true>(FFT_STAMP_ARGS b, W, ld, st, true, st_alt, use_alt); }
+    { fft_ct3<NB, +1, NT, B0, B1, B2, BSWZ, true>(FFT_STAMP_ARGS b, W, ld, st, true, st_alt, use_alt, (int)threadIdx.x); }
 };
 // Three-pass schedule of each transform length in use (first radix 21: conflict-free as it is; first radix 16:
 // swizzled layout between pass 1 and 2).  4410 = 21*14*15 is the order the product runs (configs[2] 47 us, against
@@ -564,6 +565,7 @@ __device__ __forceinline__ void *uniform_ptr(void *p) // the same address, prova
 #ifndef FFT_STORE_AUX
 #define FFT_STORE_AUX 2
 #endif
+
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 template <typename Real> __device__ __forceinline__ Real buf_load_real(__amdgpu_buffer_rsrc_t r, int voff, int soff);
@@ -598,6 +600,41 @@ template <> struct PairTabs<double> {
     static __device__ __forceinline__ const double *hr(const FftArgs &a) { return a.Hrd; }
 };
 
+// Input t of butterfly j of the FIRST INVERSE pass: bin n = j + t * NB/RB0 of the output grid <- bin n (non-negative
+// frequencies, n <= NB/2) or n + NA - NB (negative ones) of the input grid in `buf`, times the real filter gain of
+// |frequency| — read through the descriptor `rh` over Hr[0 .. NB/2] with the t-dependent part of the offset in the scalar
+// operand.  Which side of the spectrum a bin lies on is known at compile time for all but the one t that straddles NB/2.
+template <typename Spec, typename Real, typename C>
+__device__ __forceinline__ C spectrum_load(const C *buf, __amdgpu_buffer_rsrc_t rh, int j, int t)
+{
+    constexpr int NA = Spec::NA, NB = Spec::NB, nbB = NB / Spec::RB0, RS = (int)sizeof(Real);
+    const int lo = t * nbB, hi = lo + nbB - 1; // the bins this input can be, over all butterflies (j < nbB)
+    const int n = j + lo;
+    if constexpr (NA >= NB) {
+        if (hi <= NB / 2) {        // non-negative frequencies
+            const Real h = buf_load_real<Real>(rh, j * RS, lo * RS);
+            const C x = buf[n];
+            return C(x.x * h, x.y * h);
+        } else if (lo > NB / 2) {  // negative frequencies: |q| = NB - n = (NB - lo - nbB) + (nbB - j)
+            const Real h = buf_load_real<Real>(rh, (nbB - j) * RS, (NB - lo - nbB) * RS);
+            const C x = buf[n + (NA - NB)];
+            return C(x.x * h, x.y * h);
+        } else {                   // the butterfly input that straddles the middle
+            const bool neg = n > NB / 2;
+            const Real h = buf_load_real<Real>(rh, (neg ? NB - n : n) * RS, 0);
+            const C x = buf[neg ? n + (NA - NB) : n];
+            return C(x.x * h, x.y * h); // (the Nyquist bin's alias term is dropped with Im H: stop band, < -170 dB)
+        }
+    } else {
+        const bool neg = n > NB / 2;
+        const int q = neg ? NB - n : n; // |frequency| in bins
+        const bool in_band = q < NA / 2;
+        const Real h = buf_load_real<Real>(rh, q * RS, 0);
+        const C x = buf[in_band ? (neg ? NA - q : q) : 0];
+        return in_band ? C(x.x * h, x.y * h) : C((Real)0, (Real)0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_fft_pair2: unit-stride columns (mono / planar data; batches).  How it touches HBM:
 //   * input: raw buffer loads whose descriptor covers [first sample of the item's first block, end of the column): the
@@ -627,7 +664,7 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
     typedef typename PairTabs<Real>::C C;
     typedef typename PairTabs<IO>::V16 V16;
     constexpr int ES = (int)sizeof(IO), EPS = 16 / ES; // element size, elements per 16-byte store
-    constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0, nbB = NB / Spec::RB0;
+    constexpr int NA = Spec::NA, NB = Spec::NB, NT = Spec::NT, nbA = NA / Spec::RA0;
     constexpr int NsL = NB / Spec::RB2;   // the last inverse pass writes element o + t * NsL, o < NsL
     constexpr int LB = NA > NB ? NA : NB; // complex points of the transform buffer
     C *buf = reinterpret_cast<C *>(smem_raw);
@@ -681,34 +718,7 @@ __device__ __forceinline__ void pair2_item(const FftArgs &a, unsigned char *smem
     IO *ybase = (IO *)a.out + clip_out + (int64_t)ch * a.ochs + (outa + v0); // run[0]; outa + v0 >= 0
     // LDS element index == run index + sh: the 16-byte phases of staging and memory agree
     const int32_t sh = (int32_t)((reinterpret_cast<uintptr_t>(ybase) / ES) & (EPS - 1));
-    auto h_load = [&](int j, int t) -> C {
-        constexpr int RS = (int)sizeof(Real);
-        const int lo = t * nbB, hi = lo + nbB - 1; // the bins this input can be, over all butterflies (j < nbB)
-        const int n = j + lo;
-        if constexpr (NA >= NB) {
-            if (hi <= NB / 2) {        // non-negative frequencies
-                const Real h = buf_load_real<Real>(rh, j * RS, lo * RS);
-                const C x = buf[n];
-                return C(x.x * h, x.y * h);
-            } else if (lo > NB / 2) {  // negative frequencies: |q| = NB - n = (NB - lo - nbB) + (nbB - j)
-                const Real h = buf_load_real<Real>(rh, (nbB - j) * RS, (NB - lo - nbB) * RS);
-                const C x = buf[n + (NA - NB)];
-                return C(x.x * h, x.y * h);
-            } else {                   // the butterfly input that straddles the middle
-                const bool neg = n > NB / 2;
-                const Real h = buf_load_real<Real>(rh, (neg ? NB - n : n) * RS, 0);
-                const C x = buf[neg ? n + (NA - NB) : n];
-                return C(x.x * h, x.y * h); // (the Nyquist bin's alias term is dropped with Im H: stop band, < -170 dB)
-            }
-        } else {
-            const bool neg = n > NB / 2;
-            const int q = neg ? NB - n : n; // |frequency| in bins
-            const bool in_band = q < NA / 2;
-            const Real h = buf_load_real<Real>(rh, q * RS, 0);
-            const C x = buf[in_band ? (neg ? NA - q : q) : 0];
-            return in_band ? C(x.x * h, x.y * h) : C((Real)0, (Real)0);
-        }
-    };
+    auto h_load = [&](int j, int t) -> C { return spectrum_load<Spec, Real>(buf, rh, j, t); };
     // Staging stores: output n = o + t * NsL (o < NsL) of both blocks is kept iff v0 <= n < v1.  In every geometry in use
     // the kept run begins inside the first stride of outputs and ends inside the last one (`typical`, wave-uniform):
     // then only outputs t = 0 and t = RB2 - 1 compare per lane, the others are stored as they are.
@@ -819,8 +829,9 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
     C *cur = reinterpret_cast<C *>(smem_raw);
     constexpr int NA = Spec::NA, NB = Spec::NB, R0 = Spec::RA0, nbA = NA / R0;
 #ifdef FFT2_TRACE
-    unsigned long long *g_tr = nullptr;
+    unsigned long long *g_tr = a.trace ? a.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (Spec::NT / 64) + threadIdx.x / 64) * 16 : nullptr;
     int g_tri = 0;
+    FFT_STAMP();
 #endif
     // XCD-aware ids: x = 8 * slot + xcd, slot = chunk * units + unit;
     // or (a.xcd_map == 0: one column per grid row) items along x, columns along y
@@ -842,7 +853,6 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
     const Real *xin = (const Real *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
     const int32_t ifb = (int32_t)a.ifs * ES, ofb = (int32_t)a.ofs * ES; // bytes per frame (launcher: 2 N * frame < 2^30)
     auto last_fwd_store = [&](int o, int t, C v) { cur[o + t * (NA / Spec::RA2)] = v; };
-    const Real *Hr = PairTabs<Real>::hr(a);
     const int32_t v0 = a.v0, v1 = a.v0 + hop_out;
     const int64_t pa = (CP ? 1 : 2) * bx * a.hop_periods - a.lead_periods; // first period of the (first) block
     const int64_t ina = pa * a.M, outa = pa * a.L;
@@ -870,26 +880,16 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
         }, last_fwd_store);
     }
     __syncthreads();
+    FFT_STAMP();
 
     // ---- inverse (see k_fft_pair2), outputs straight to HBM -----------------------------------------
     Real *ybase = (Real *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs + (outa + v0) * a.ofs; // outa + v0 >= 0
     const int64_t oleft = (a.out_frames - (outa + v0)) * (int64_t)ofb;
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr((void *)ybase), 0, __builtin_amdgcn_readfirstlane((int)(oleft < 0 ? 0 : oleft > 0x40000000 ? 0x40000000 : oleft)), 0x00020000);
-    auto h_load = [&](int j, int t) -> C {
-        const int n = j + t * (NB / Spec::RB0);
-        const bool neg = n > NB / 2;
-        const int q = neg ? NB - n : n; // |frequency| in bins
-        const Real h = Hr[q];
-        if constexpr (NA >= NB) {
-            const C x = cur[neg ? n + (NA - NB) : n];
-            return C(x.x * h, x.y * h);
-        } else {
-            const bool in_band = q < NA / 2;
-            const C x = cur[in_band ? (neg ? NA - q : q) : 0];
-            return in_band ? C(x.x * h, x.y * h) : C((Real)0, (Real)0);
-        }
-    };
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((void *)PairTabs<Real>::hr(a)), 0,
+                                                                         (NB / 2 + 1) * (int)sizeof(Real), 0x00020000);
+    auto h_load = [&](int j, int t) -> C { return spectrum_load<Spec, Real>(cur, rh, j, t); };
     Spec::inv(FFT_STAMP_ARGS cur, PairTabs<Real>::wb(a), h_load, [&](int o, int t, C wv) {
         const int n = o + t * (NB / Spec::RB2);
         if (n >= v0 && n < v1) {
@@ -901,6 +901,11 @@ __global__ void __launch_bounds__(Spec::NT) k_fft_strided2(FftArgs a)
             }
         }
     });
+#ifdef FFT2_TRACE
+    if (g_tr && (threadIdx.x & 63) == 0) { g_tr[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_tr[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+    g_tri = 15;
+    FFT_STAMP();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -988,11 +993,14 @@ static const char *fft_build(const Plan &p, FftGeom *out, bool small, int force_
     // transforms stay <= 2600 points (one 20 KB LDS buffer, least overlap waste), else the smallest admissible one
     for (int k = force_k ? force_k : 1; k <= (force_k ? force_k : 4096); k *= 2) {
         const int64_t Nin = M * k, Nout = L * k;
-        if (Nin % 2 || Nout % 2) continue;
+        if ((Nin % 2 || Nout % 2) && !force_k) continue; // (the half-length tables of k_fft_block; the paired kernels take odd lengths)
         if (!force_k && Nin < 6 * (int64_t)T) continue;
         if (Nin / 2 > 4096 || Nout / 2 > 4096) break;
         std::vector<int> ra, rb;
-        if (!factor_radices((int)(Nin / 2), ra) || !factor_radices((int)(Nout / 2), rb)) continue;
+        if (!factor_radices((int)(Nin / 2), ra) || !factor_radices((int)(Nout / 2), rb)) {
+            if (!force_k) continue;
+            ra.clear(); rb.clear(); // (k_fft_block's run-time schedule of the half lengths: a forced geometry belongs to a paired kernel, which has its own)
+        }
         if (!force_k && g.k && (small || std::max(Nin, Nout) / 2 > 2600)) break;
         g.k = k; g.N_in = (int32_t)Nin; g.N_out = (int32_t)Nout; g.A = g.N_in / 2; g.B = g.N_out / 2;
         g.nA = (int32_t)ra.size(); g.nB = (int32_t)rb.size();
@@ -1239,7 +1247,7 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                 if (const char *e = ensure_dyn_lds((const void *)kern, lds)) return e;
 #ifdef FFT2_TRACE
                 size_t trace_n = 0;
-                if (switches().dbg_trace && v2ok) {
+                if (switches().dbg_trace) {
                     trace_n = (size_t)grid.x * grid.y * (nt / 64) * 16;
                     HIP_TRY(hipMalloc((void **)&a.trace, trace_n * 8));
                     HIP_TRY(hipMemset(a.trace, 0, trace_n * 8));

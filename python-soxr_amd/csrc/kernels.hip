@@ -71,7 +71,6 @@ const Switches &switches()
 #ifdef HIPSOXR_DEBUG_SWITCHES
         w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR"); w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP");
         w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY"); w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY");
-        if (getenv("HIPSOXR_FFT_X2")) w.fft_x2 = num("HIPSOXR_FFT_X2");
         w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX");
         w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT");
@@ -899,10 +898,12 @@ struct ChainMsg { int64_t in_abs0, in_frames, out_k0, out_frames, d0, p0; uint64
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `pre` runs in every thread before the barrier in front of the output stores; outputs are withheld if *veto has its
 // top bit set after that barrier (the resident form's arbiter, see k_chain_resident)
+// chunk / split: input frames from ring-relative index `split` on are read from `chunk` (a stream's new frames, not yet in its
+// ring: k_chain_multi) instead of the ring
 template <typename IO, typename Real, int MODE, typename Pre = NoHook>
 __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &m, const uint32_t bx, const uint32_t by,
                                            unsigned char *smem_raw, uint32_t *trace = nullptr, Pre pre = Pre(),
-                                           const unsigned long long *veto = nullptr)
+                                           const unsigned long long *veto = nullptr, const void *chunk = nullptr, const int64_t split = 0)
 {
 #ifdef HIPSOXR_RES_TRACE
     const long long tb0 = wall_clock64();
@@ -925,6 +926,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &
     const uint32_t ch = by % a.n_channels, clip = by / a.n_channels;
     const int64_t o_base = (int64_t)bx * NO;
     const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
+    const IO *xchunk = chunk ? (const IO *)chunk + (int64_t)ch * a.ichs - split * a.ifs : nullptr; // (indexed like the ring)
+    auto sample_at = [&](int64_t l) -> const IO * { return (xchunk && l >= split) ? xchunk + l * a.ifs : xin + l * a.ifs; };
     typedef typename Vec4<Real>::type V4;
 
     if ((int)threadIdx.x < NO) { // one thread per output: where it sits
@@ -972,7 +975,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &
             for (int u = 0; u < SPT; ++u) {
                 const int64_t l = nfirst + (int32_t)threadIdx.x + u * 256;
                 const int64_t lc = l < 0 ? 0 : l >= a.in_frames ? a.in_frames - 1 : l;
-                const IO v = xin[lc * a.ifs];
+                const IO v = *sample_at(lc);
                 xv[u] = (l == lc) ? v : (IO)0;
             }
         }
@@ -985,7 +988,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &
             if ((int32_t)threadIdx.x + u * 256 < span) xs[threadIdx.x + u * 256] = (Real)xv[u];
         for (int sidx = threadIdx.x + SPT * 256; sidx < span; sidx += 256) { // (spans beyond 1024 samples: very long filters)
             const int64_t l = nfirst + sidx;
-            xs[sidx] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+            xs[sidx] = (l >= 0 && l < a.in_frames) ? (Real)*sample_at(l) : (Real)0;
         }
     };
     constexpr int EPT = MODE == 0 ? 12 : 8, RPW = HIPSOXR_RPW;
@@ -1112,6 +1115,50 @@ __global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
         if (threadIdx.x == 0)
             __hip_atomic_store(&ca.done_words[blockIdx.y * gridDim.x + blockIdx.x], ca.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chain_multi — k_chain over MANY INDEPENDENT STREAMS in one launch (round 5): grid.y = stream x channel, every stream
+// with its own ring, output buffer, counters and phase (ChainItem).  A stream's new chunk is read where the caller left it
+// and copied into the stream's ring by the same workgroups (share by share: nobody in this launch reads the ring region
+// they write), so a device-chunk stream call is ONE dispatch; N callers' chunks are one dispatch too.
+// ---------------------------------------------------------------------------------------------
+struct ChainMultiArgs {
+    ChainArgs ca;            // what the streams share: plan tables, geometry of a column, NO, LDS layout
+    const ChainItem *items;  // device-readable table, or nullptr: the one item below
+    ChainItem one;
+    uint32_t n_channels;
+};
+template <typename IO, typename Real, int MODE>
+__global__ void __launch_bounds__(256) k_chain_multi(ChainMultiArgs m)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t nch = m.n_channels;
+    const uint32_t item_i = __builtin_amdgcn_readfirstlane(blockIdx.y / nch), ch = __builtin_amdgcn_readfirstlane(blockIdx.y % nch);
+    const ChainItem it = m.items ? m.items[item_i] : m.one;
+    const uint32_t NO = (uint32_t)m.ca.NO;
+    const uint32_t nx = (uint32_t)((it.out_frames + NO - 1) / NO), nxc = nx ? nx : 1; // (a stream without outputs still appends its chunk)
+    if (blockIdx.x >= nxc) return;
+    if (it.chunk && it.chunk_frames > 0) { // this workgroup's share of [the frames the ring keeps, when it moves] + the chunk -> ring_dst
+        const bool moving = it.ring_dst != it.ring;
+        const size_t keep_n = moving ? (size_t)(it.split - it.keep_from) * nch : 0;
+        const size_t total = keep_n + (size_t)it.chunk_frames * nch, W = (size_t)nxc * nch, per = (total + W - 1) / W;
+        const size_t lo = ((size_t)ch * nxc + blockIdx.x) * per, hi = lo + per < total ? lo + per : total;
+        IO *dst = (IO *)it.ring_dst;
+        const IO *old = (const IO *)it.ring + (size_t)it.keep_from * nch, *src = (const IO *)it.chunk;
+        const size_t chunk_at = moving ? keep_n : (size_t)it.split * nch;
+        for (size_t e = lo + threadIdx.x; e < hi; e += 256) {
+            if (e < keep_n) dst[e] = old[e];
+            else dst[chunk_at + (e - keep_n)] = src[e - keep_n];
+        }
+    }
+    if (blockIdx.x >= nx) return;
+    ChainArgs ca = m.ca;
+    GatherArgs &g = ca.ia.g;
+    g.in = it.ring; g.out = it.out; g.n_clips = 1;
+    g.oc.clip_counter = (uint64_t *)it.clip_counter; g.oc.seed = it.dither_seed;
+    const ChainMsg msg = {it.in_abs0, it.in_frames, it.out_k0, it.out_frames, it.d0, it.p0, 0, 0, 0, 0, 0, 0};
+    chain_body<IO, Real, MODE>(ca, msg, blockIdx.x, ch, smem_raw, nullptr, NoHook(), nullptr, it.chunk, it.split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3125,6 +3172,85 @@ const char *launch_copy(void *dst, const void *src, size_t bytes, void *stream)
     }
     HIP_TRY(hipGetLastError());
     return nullptr;
+}
+
+template <typename IO, typename Real>
+static const char *launch_chain_items_typed(Plan *p, uint32_t nch, bool dither, const ChainItem *items, const ChainItem *items_dev, uint32_t n_items,
+                                            hipStream_t st, bool *handled)
+{
+    int64_t max_out = 0;
+    for (uint32_t i = 0; i < n_items; ++i) max_out = std::max(max_out, items[i].out_frames);
+    if (max_out >= 4096 || (uint64_t)n_items * nch > 65535 || switches().no_chain) return nullptr;
+    const DeviceBank &d = p->dev[sizeof(Real) == 4 ? 0 : 1];
+    // geometry of k_chain as launch_gather sets it up: few outputs per workgroup for short chunks, LDS = NO coefficient rows + the span
+    int NO = max_out <= 512 ? 8 : 32;
+    if (switches().dbg_chain_no) NO = switches().dbg_chain_no;
+    const int64_t shift = (p->M + p->L - 1) / p->L + 2;
+    auto chain_lds = [&](int no, int32_t *span_cap) {
+        const int64_t sc = (int64_t)p->T + (int64_t)no * shift + 4;
+        *span_cap = (int32_t)sc;
+        return (size_t)no * (p->T + 16 / sizeof(Real)) * sizeof(Real) + (size_t)((sc + 3) & ~3) * sizeof(Real) + (size_t)no * 16;
+    };
+    int32_t span_cap = 0;
+    while (NO > 2 && chain_lds(NO, &span_cap) > 150 * 1024) NO /= 2;
+    const size_t lds = chain_lds(NO, &span_cap);
+    if (lds > 150 * 1024 || shift >= (1 << 20)) return nullptr;
+    ChainMultiArgs m;
+    std::memset(&m, 0, sizeof m);
+    GatherArgs &a = m.ca.ia.g;
+    a.bank = d.tap_major; a.Lpad = d.Lpad; a.L = p->L; a.M = p->M; a.T = p->T;
+    a.n_clips = 1; a.n_channels = nch;
+    a.ics = 0; a.ifs = nch; a.ichs = 1; a.ocs = 0; a.ofs = nch; a.ochs = 1; // a stream's own layout: interleaved frames
+    a.oc.dither = dither ? 1u : 0u; a.oc.ch0 = 0;
+    a.ch_fast = 0;
+    m.ca.NO = NO; m.ca.span_cap = span_cap;
+    m.n_channels = nch;
+    void (*ck)(ChainMultiArgs) = nullptr;
+    if (p->phases) {
+        m.ca.ia.tab = d.interp_tab; m.ca.ia.P = p->phases;
+        while ((1 << m.ca.ia.lgP) < m.ca.ia.P) ++m.ca.ia.lgP;
+        ck = k_chain_multi<IO, Real, 1>;
+    } else {
+        DeviceBank &dm = p->dev[sizeof(Real) == 4 ? 0 : 1];
+        const char *err = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (!dm.phase_major) {
+                std::vector<Real> pm(p->bank.size());
+                for (size_t i = 0; i < pm.size(); ++i) pm[i] = (Real)p->bank[i];
+                if (hipMalloc(&dm.phase_major, pm.size() * sizeof(Real)) != hipSuccess) err = "hipMalloc failed";
+                else if (hipMemcpy(dm.phase_major, pm.data(), pm.size() * sizeof(Real), hipMemcpyHostToDevice) != hipSuccess) err = "hipMemcpy failed";
+            }
+        }
+        if (err) return err;
+        m.ca.phase_major = dm.phase_major;
+        ck = k_chain_multi<IO, Real, 0>;
+    }
+    if (n_items == 1) m.one = items[0];
+    else if (!items_dev) return "internal: a many-streams launch needs a device-readable item table";
+    else m.items = items_dev;
+    if (const char *e = ensure_dyn_lds((const void *)ck, lds)) return e;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, (max_out + NO - 1) / NO);
+    hipLaunchKernelGGL(ck, dim3(gx, (unsigned)(n_items * nch), 1), dim3(256), lds, st, m);
+    HIP_TRY(hipGetLastError());
+    *handled = true;
+    return nullptr;
+}
+
+const char *launch_chain_items(Plan *p, int elem, uint32_t n_channels, bool dither, const ChainItem *items, const ChainItem *items_dev,
+                               uint32_t n_items, void *stream, bool *handled)
+{
+    *handled = false;
+    if (!n_items || !n_channels) return nullptr;
+    if (const char *e = device_bank_ensure(p, engine_prec(elem))) return e;
+    hipStream_t st = (hipStream_t)stream;
+    switch (elem) {
+    case HIPSOXR_F32: return launch_chain_items_typed<float, float>(p, n_channels, false, items, items_dev, n_items, st, handled);
+    case HIPSOXR_F64: return launch_chain_items_typed<double, double>(p, n_channels, false, items, items_dev, n_items, st, handled);
+    case HIPSOXR_I32: return launch_chain_items_typed<int32_t, double>(p, n_channels, false, items, items_dev, n_items, st, handled);
+    case HIPSOXR_I16: return launch_chain_items_typed<int16_t, float>(p, n_channels, dither, items, items_dev, n_items, st, handled);
+    }
+    return "unknown element type";
 }
 
 const char *launch_job(Plan *p, const hipsoxr_job_t &j, void *stream, const VrPos *vr, ResidentLaunch *res, ChainDone *cd)

@@ -80,7 +80,7 @@ soxr_error_t translate(const soxr_io_spec_t *io, const soxr_quality_spec_t *q, i
 extern "C" {
 
 // reference: src/csoxr_version.cpp:6-8
-char const *soxr_version(void) { return "libsoxr-compatible hipsoxr-0.4.0 (gfx950)"; }
+char const *soxr_version(void) { return "libsoxr-compatible hipsoxr-" HIPSOXR_VERSION_STRING " (gfx950)"; }
 
 // reference: src/soxr_ext.cpp:74, :228, :303, :376
 soxr_quality_spec_t soxr_quality_spec(unsigned long recipe, unsigned long flags)

@@ -103,6 +103,7 @@ SIGNATURES = {
                                       _P(C.c_size_t)]),
     "hipsoxr_stream_process_device": (_err, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                              _P(C.c_size_t), C.c_void_p]),
+    "hipsoxr_streams_process_device": (_err, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hipsoxr_stream_delete": (None, [C.c_void_p]),
     "hipsoxr_stream_clear": (_err, [C.c_void_p]),
     "hipsoxr_stream_delay": (C.c_double, [C.c_void_p]),
@@ -133,7 +134,7 @@ def version():
 
 # The ctypes mirrors above (Job = hipsoxr_job_t with its clip_table fields) are laid out for this ABI generation: a
 # library of another generation would read garbage from the struct's tail, so loading one is an import error.
-ABI_VERSION = "hipsoxr-0.4"
+ABI_VERSION = "hipsoxr-0.5"
 if not version().startswith(ABI_VERSION):
     raise ImportError(f"{LIB_PATH} is {version()!r}; this package binds {ABI_VERSION}.x (rebuild: python-soxr_amd/build.sh)")
 

@@ -266,3 +266,59 @@ class TensorStream:
                     break
                 pos += done.value
         return out[:pos]
+
+
+class TensorStreamGroup:
+    """N INDEPENDENT `TensorStream`s of one conversion served by ONE kernel launch per call (`hipsoxr_streams_process_device`):
+    N live callers each feeding 10 ms chunks cost one dispatch per tick, whatever their phases and pending counts — the
+    MI355X form of N threads around the reference's ResampleStream (src/soxr/__init__.py:56-131, tests/bench.py:71-88).
+
+        grp = TensorStreamGroup(128, 44100, 16000, num_channels=1, dtype=torch.int16, quality="VHQ")
+        y, counts = grp.resample_chunks(x)      # x: [128, frames] (mono) or [128, frames, channels]; stream i gets x[i]
+                                                # y: [128, cap(, channels)]; stream i's frames are y[i, :counts[i]]
+
+    Every stream is an ordinary stream handle: the frames stream i returns are those a `TensorStream` fed the same chunks
+    returns, bit for bit; `streams[i]` IS such a TensorStream and may also be used alone (`grp.streams[i].resample_chunk`,
+    `clear`, `delay`, ...).  Chunks of one call have one length (ragged feeding: call the streams singly, or pad by
+    calling twice); variable-rate streams are not grouped."""
+
+    def __init__(self, n, in_rate, out_rate, num_channels=1, dtype=None, quality="HQ", dither=True, dither_seeds=None):
+        import torch
+        if n < 1:
+            raise ValueError("need at least one stream")
+        self.streams = [TensorStream(in_rate, out_rate, num_channels, dtype, quality, False, dither,
+                                     0 if dither_seeds is None else int(dither_seeds[i])) for i in range(n)]
+        s0 = self.streams[0]
+        self.n, self.channels, self.dtype = int(n), s0.channels, s0.dtype
+        self._ratio, self._slack = s0._ratio, s0._slack
+        self._handles = (_C.c_void_p * n)(*[s._h.value for s in self.streams])
+        self._ins, self._outs = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        self._ilens, self._olens, self._dones = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        self._lane = np.arange(n, dtype=np.uint64)
+        self._es = torch.empty(0, dtype=self.dtype).element_size()
+
+    def resample_chunks(self, x):
+        """x: [n_streams, frames] or [n_streams, frames, channels] device tensor -> (y, counts)."""
+        import torch
+        if not x.is_cuda or x.dtype != self.dtype:
+            raise TypeError("TensorStreamGroup needs a device tensor of the group's dtype")
+        if x.shape[0] != self.n or x.ndim not in (2, 3) or (x.ndim == 2 and self.channels != 1) or (x.ndim == 3 and x.shape[2] != self.channels):
+            raise ValueError("Input must be [n_streams, frames] for one channel or [n_streams, frames, channels]")
+        if any(s._ended for s in self.streams):
+            raise RuntimeError("Input after last input")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        frames = int(x.shape[1])
+        cap = int(frames * self._ratio) + self._slack
+        y = torch.empty((self.n, cap) + tuple(x.shape[2:]), dtype=self.dtype, device=x.device)
+        row = self.channels * self._es
+        np.multiply(self._lane, np.uint64(frames * row), out=self._ins); self._ins += np.uint64(x.data_ptr())
+        np.multiply(self._lane, np.uint64(cap * row), out=self._outs); self._outs += np.uint64(y.data_ptr())
+        self._ilens[:] = frames
+        self._olens[:] = cap
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        err = _n.lib.hipsoxr_streams_process_device(self._handles, self.n, self._ins.ctypes.data, self._ilens.ctypes.data,
+                                                    self._outs.ctypes.data, self._olens.ctypes.data, self._dones.ctypes.data, stream)
+        if err:
+            _n.check(err)
+        return y, self._dones.astype(np.int64)

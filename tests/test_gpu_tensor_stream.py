@@ -123,3 +123,70 @@ def test_tensor_stream_on_a_side_stream_and_mixed_with_host_calls(soxr):
         y = torch.cat(parts)
     side.synchronize()
     assert np.array_equal(y.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype,rates,quality,ch", [(np.int16, (44100, 16000), "VHQ", 1), (np.float32, (48000, 44100), "HQ", 2),
+                                                    (np.float32, (48000, 44101.5), "HQ", 1), (np.int32, (16000, 48000), "MQ", 2)])
+def test_stream_group_one_launch_equals_streams_called_singly(soxr, dtype, rates, quality, ch):
+    """`TensorStreamGroup` / hipsoxr_streams_process_device: N INDEPENDENT handles — different phases, different pending
+    counts (every stream is fed a prefix of its own length first), distinct dither seeds — served by one launch per call.
+    Stream i's frames must be the frames a TensorStream of its own returns for the same chunks, bit for bit, and a group
+    member stays an ordinary stream (used alone in between, flushed alone at the end)."""
+    import torch
+    from soxr_amd import device as dev
+    n, chunk, rounds = 37, 441, 12
+    rng = np.random.default_rng(31)
+    tdt = torch.from_numpy(np.zeros(1, dtype)).dtype
+    seeds = list(range(100, 100 + n))
+    grp = dev.TensorStreamGroup(n, rates[0], rates[1], ch, dtype=tdt, quality=quality, dither_seeds=seeds)
+    solo = [dev.TensorStream(rates[0], rates[1], ch, dtype=tdt, quality=quality, dither_seed=seeds[i]) for i in range(n)]
+    shape = lambda f: (f, ch) if ch > 1 else (f,)            # noqa: E731
+    got = [[] for _ in range(n)]
+    want = [[] for _ in range(n)]
+    for i in range(n):                                       # de-phase the streams: prefixes of 0 .. 36 * 53 frames
+        pre = torch.from_numpy(_sig(rng, shape(i * 53), dtype)).cuda()
+        got[i].append(grp.streams[i].resample_chunk(pre).cpu().numpy())
+        want[i].append(solo[i].resample_chunk(pre).cpu().numpy())
+    for r in range(rounds):
+        x = torch.from_numpy(_sig(rng, (n,) + shape(chunk), dtype)).cuda()
+        y, counts = grp.resample_chunks(x)
+        assert y.shape[0] == n and len(counts) == n
+        for i in range(n):
+            got[i].append(y[i, :counts[i]].cpu().numpy())
+            want[i].append(solo[i].resample_chunk(x[i]).cpu().numpy())
+            assert np.array_equal(got[i][-1], want[i][-1]), (r, i)
+        if r == 5:                                           # a member used alone between two group calls
+            extra = torch.from_numpy(_sig(rng, shape(97), dtype)).cuda()
+            got[3].append(grp.streams[3].resample_chunk(extra).cpu().numpy())
+            want[3].append(solo[3].resample_chunk(extra).cpu().numpy())
+    assert len({len(np.concatenate(g)) for g in got}) > 1    # the streams really are at different positions
+    tail = torch.from_numpy(_sig(rng, shape(10), dtype)).cuda()
+    for i in (0, 3, n - 1):
+        assert np.array_equal(grp.streams[i].resample_chunk(tail, last=True).cpu().numpy(), solo[i].resample_chunk(tail, last=True).cpu().numpy())
+    if np.issubdtype(dtype, np.integer):
+        assert [s.num_clips() for s in grp.streams] == [s.num_clips() for s in solo]
+
+
+def test_stream_group_falls_back_where_one_launch_does_not_apply(soxr):
+    """Chunks of >= 4096 outputs per stream, or thousands of calls (ring compaction inside the group call): same frames."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(33)
+    n = 5
+    grp = dev.TensorStreamGroup(n, 48000, 44100, 1, dtype=torch.float32, quality="HQ")
+    x = torch.from_numpy(_sig(rng, (n, 9000), np.float32)).cuda()      # 8268 outputs each: not the small-launch kernel
+    y, counts = grp.resample_chunks(x)
+    for i in range(n):
+        ts = dev.TensorStream(48000, 44100, 1, dtype=torch.float32, quality="HQ")
+        assert np.array_equal(y[i, :counts[i]].cpu().numpy(), ts.resample_chunk(x[i]).cpu().numpy())
+    grp = dev.TensorStreamGroup(n, 44100, 16000, 1, dtype=torch.float32, quality="VHQ")
+    sig = _sig(rng, (n, 441 * 600), np.float32)
+    xd = torch.from_numpy(sig).cuda()
+    parts = [[] for _ in range(n)]
+    for a in range(0, sig.shape[1], 441):
+        y, counts = grp.resample_chunks(xd[:, a:a + 441])
+        for i in range(n):
+            parts[i].append(y[i, :counts[i]])
+    for i in range(n):
+        tail = grp.streams[i].resample_chunk(xd[i, :0], last=True)
+        assert np.array_equal(torch.cat(parts[i] + [tail]).cpu().numpy(), soxr.resample(sig[i], 44100, 16000, quality="VHQ"))
