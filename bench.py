@@ -47,7 +47,7 @@ KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, paire
 # itself): profiles/<TRAFFIC_FILE> records them TOGETHER WITH the SHA-256 of the kernel sources they were taken on.
 # `measured_counters()` hands a figure out only while that hash still matches the sources in this checkout — a stale
 # constant is reported as null with the reason, never silently.
-TRAFFIC_FILE = "r04_traffic.json"
+TRAFFIC_FILE = "r05_traffic.json"
 KERNEL_SOURCES = ("python-soxr_amd/csrc/fft.hip", "python-soxr_amd/csrc/kernels.hip", "python-soxr_amd/csrc/twostage.hip")
 
 

@@ -354,7 +354,8 @@ __device__ __forceinline__ void fft_ct3(FFT_STAMP_DECL C *buf, const C *W, Load 
         else { const int n = j + t * nb1; return buf[n ^ ((n >> 4) & 15)]; }
     };
     auto swz_store = [&](int o, int t, C v) { // pass 0: Ns = 1, o = R0 j
-        if constexpr (SWZ) buf[o + (t ^ ((o >> 4) & 15))] = v;
+        // 16 j + (t ^ (j & 15)) = (16 j | (j & 15)) ^ t: one XOR of a per-thread byte offset with a constant per element
+        if constexpr (SWZ) *reinterpret_cast<C *>(reinterpret_cast<char *>(buf) + ((unsigned)((o | ((o >> 4) & 15)) * (int)sizeof(C)) ^ (unsigned)(t * (int)sizeof(C)))) = v;
         else buf[o + t] = v;
     };
     // pass 0 (Ns = 1): when its input is not in LDS nothing has to be protected before storing

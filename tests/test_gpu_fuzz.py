@@ -58,3 +58,11 @@ def test_device_chunk_streams_equal_host_streams():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_device_stream.py"), "120", "51"],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_stream_groups_equal_streams_called_singly():
+    """tests/fuzz/fuzz_stream_group.py: TensorStreamGroup (hipsoxr_streams_process_device: N independent handles, one launch)
+    against the same handles as host-array streams — random rates, recipes, dtypes, channels, handle counts, chunk sizes."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_stream_group.py"), "30", "61"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]

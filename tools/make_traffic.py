@@ -3,7 +3,7 @@
 HBM traffic per launch (FETCH_SIZE x 2 — the gfx950 correction of MI355X_MICROARCH.md §HBM for wide coalesced reads —
 plus WRITE_SIZE, both in KiB) and VALU wave-instructions per launch for the three bench workloads, keyed by the SHA-256
 of the kernel sources they were collected on (bench.py `measured_counters` refuses a record whose hash has gone stale).
-    python tools/make_traffic.py gpurun_out/prof profiles/r04_traffic.json"""
+    python tools/make_traffic.py gpurun_out/prof profiles/r05_traffic.json"""
 import collections
 import json
 import os
@@ -18,8 +18,8 @@ WORKLOADS = {  # name -> (kernel-name substring, grid predicate, algorithmic byt
     "configs1": ("k_fft_pair2<hipsoxr::PairSpec<2560, 2352", lambda gx, gy: gy == 1, 4 * (2880000 + 2646000)),
     "batch_shard": ("k_fft_pair2<hipsoxr::PairSpec<5120, 4704", lambda gx, gy: gy == 128, 4 * 128 * (480000 + 441000)),
     "configs2": ("k_fft_strided2<hipsoxr::PairSpec<4410, 1600", lambda gx, gy: True, 4 * 8 * (2646000 + 960000)),
-    "float64": ("double, double, 1>", lambda gx, gy: True, 8 * (2880000 + 2646000)),
-    "arith_f64": ("double, float, 1>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
+    "float64": ("double, double>", lambda gx, gy: True, 8 * (2880000 + 2646000)),
+    "arith_f64": ("double, float>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
     "exact_engine": ("k_tile_mfma_p<float>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
     # the two kernels of the arbitrary-ratio job (48000 -> 44101 stereo 60 s): bytes each kernel has to move
     "two_stage_poly": ("k_poly<float, 16, 0>", lambda gx, gy: True, 4 * 2 * (2880000 + 2 * 2646060)),
