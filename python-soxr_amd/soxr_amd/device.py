@@ -202,6 +202,8 @@ class TensorStream:
         # frames a constant-rate call can return at most: what the chunk adds plus what was pending before it
         self._slack = int((info.taps / 2 + 2) * self._ratio) + 4
         self._min_io = 1.0 / self._ratio  # (variable rate: the smallest io ratio requested so far bounds a call's output)
+        self._arena, self._arena_off, self._arena_ptr = None, 0, 0
+        self._esize = torch.empty(0, dtype=self.dtype).element_size()
 
     def __del__(self, _delete=_n.lib.hipsoxr_stream_delete):  # bound early: module globals may be gone at exit
         h = getattr(self, "_h", None)
@@ -248,9 +250,24 @@ class TensorStream:
             cap = int(_n.lib.hipsoxr_stream_delay(self._h) + n / self._min_io) + 4
         else:
             cap = int(n * self._ratio) + self._slack
-        out = torch.empty((cap,) if x.ndim == 1 else (cap, ch), dtype=self.dtype, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         fn, done = _n.lib.hipsoxr_stream_process_device, self._done
+        if not last and cap <= 4096 and x.ndim == 1:
+            # small mono chunks (the 10 ms case): results are carved out of an arena of 64 calls' worth — one tensor op (the
+            # final view) per call instead of an allocation and a slice; a full arena is simply dropped (views keep it alive)
+            ar = self._arena
+            if ar is None or self._arena_off + cap > ar.shape[0] or ar.device != x.device:
+                ar = self._arena = torch.empty(64 * cap, dtype=self.dtype, device=x.device)
+                self._arena_off, self._arena_ptr = 0, ar.data_ptr()
+            off = self._arena_off
+            optr = self._arena_ptr + off * self._esize
+            err = fn(self._h, x.data_ptr() if n else optr, n, optr, cap, self._done_ref, stream)
+            if err:
+                _n.check(err)
+            pos = done.value
+            self._arena_off = off + ((pos + 7) & ~7)          # (16-byte steps for 2-byte samples: aligned views)
+            return ar[off:off + pos]
+        out = torch.empty((cap,) if x.ndim == 1 else (cap, ch), dtype=self.dtype, device=x.device)
         err = fn(self._h, x.data_ptr() if n else out.data_ptr(), n, out.data_ptr(), cap, self._done_ref, stream)
         if err:
             _n.check(err)
