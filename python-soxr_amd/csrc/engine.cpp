@@ -1457,7 +1457,11 @@ hipsoxr_error_t hipsoxr_streams_process_device(hipsoxr_stream_t *const *handles,
         together = s->plan == s0->plan && s->elem == s0->elem && s->ch == s0->ch && s->device == s0->device &&
                    ((s->flags ^ s0->flags) & HIPSOXR_NO_DITHER) == 0 && !s->vr.on && !s->split && !s->split_io && !s->defer &&
                    !(s->flags & (HIPSOXR_RESIDENT | HIPSOXR_AUTO_RESIDENT)) && !s->ended && ins[i] && ilens[i] && outs[i];
-        for (size_t k = 0; together && k < i; ++k) together = handles[k] != s; // (a handle twice in one call: in order, one by one)
+    }
+    if (together) { // (a handle twice in one call: its calls must run in order, one by one)
+        std::vector<const hipsoxr_stream *> seen(handles, handles + n);
+        std::sort(seen.begin(), seen.end());
+        together = std::adjacent_find(seen.begin(), seen.end()) == seen.end();
     }
     if (!together) {
         for (size_t i = 0; i < n; ++i)
