@@ -190,3 +190,32 @@ def test_stream_group_falls_back_where_one_launch_does_not_apply(soxr):
     for i in range(n):
         tail = grp.streams[i].resample_chunk(xd[i, :0], last=True)
         assert np.array_equal(torch.cat(parts[i] + [tail]).cpu().numpy(), soxr.resample(sig[i], 44100, 16000, quality="VHQ"))
+
+
+def test_streams_entry_through_the_c_abi_mixed_and_repeated_handles(soxr):
+    """`hipsoxr_streams_process_device` called the way a C client would (pointer arrays; ragged chunk lengths per handle, one
+    handle listed TWICE, one of another plan): handles the shared launch cannot take are processed one by one, in index order —
+    every handle's frames equal those of single calls."""
+    import ctypes as C
+    import torch
+    from soxr_amd import _native as nat, device as dev
+    rng = np.random.default_rng(41)
+    mk = lambda a, b: dev.TensorStream(a, b, 1, dtype=torch.float32, quality="HQ")                     # noqa: E731
+    grp = [mk(48000, 44100), mk(48000, 44100), mk(48000, 44100), mk(44100, 16000)]
+    ref = [mk(48000, 44100), mk(48000, 44100), mk(48000, 44100), mk(44100, 16000)]
+    st = torch.cuda.current_stream().cuda_stream
+    for rnd, order in enumerate(([0, 1, 2], [0, 1, 2, 3], [0, 1, 1, 2])):                               # same plan / mixed plans / a repeat
+        n = len(order)
+        lens = [int(rng.integers(100, 900)) for _ in order]
+        xs = [torch.from_numpy(_sig(rng, (l,), np.float32)).cuda() for l in lens]
+        outs = [torch.empty(l + 400, dtype=torch.float32, device="cuda") for l in lens]
+        h = (C.c_void_p * n)(*[grp[i]._h.value for i in order])
+        ins = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        ops = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        il = (C.c_size_t * n)(*lens)
+        ol = (C.c_size_t * n)(*[o.shape[0] for o in outs])
+        od = (C.c_size_t * n)()
+        nat.check(nat.lib.hipsoxr_streams_process_device(h, n, ins, il, ops, ol, od, st))
+        for k, i in enumerate(order):
+            want = ref[i].resample_chunk(xs[k]).cpu().numpy()
+            assert od[k] == len(want) and np.array_equal(outs[k][:od[k]].cpu().numpy(), want), (rnd, k)
