@@ -447,7 +447,8 @@ def configs4_stream(seconds=20):
         xd = torch.from_numpy(x).cuda()
         for chunk in (441, 4410, 96000):
             ts = dev.TensorStream(44100, 16000, 1, dtype=torch.int16, quality="VHQ")
-            ts.resample_chunk(xd[:chunk])
+            for a in range(0, min(len(x), 300 * chunk), chunk):   # warm up: module load, allocator, clocks (a 20 ms leg sees the ramp otherwise)
+                ts.resample_chunk(xd[a:a + chunk])
             ts.clear()
             torch.cuda.synchronize()
             n_calls = 0
