@@ -81,7 +81,7 @@ const Switches &switches()
         w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD");
         w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT");
         w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS");
-        w.dbg_tile_form = num("HIPSOXR_DEBUG_TILE_FORM"); w.dbg_poly_r = num("HIPSOXR_DEBUG_POLY_R"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
+        w.dbg_tile_form = num("HIPSOXR_DEBUG_TILE_FORM"); w.dbg_poly_r = num("HIPSOXR_DEBUG_POLY_R"); w.poly_no_pair = on("HIPSOXR_POLY_NO_PAIR"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
 #endif
         return w;
     }();

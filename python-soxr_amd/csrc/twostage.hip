@@ -44,7 +44,7 @@ struct TwoStage {
     Plan fft;                 // the FFT stage's plan: L/M = 2/1 (up) or 1/2 (down), bank from the owner's prototype
     int32_t T2 = 0, P2 = 0, P2f = 0, row = 0; // polyphase stage: taps, table intervals (float64 / float32 table), records per table row (T2 + 1: bank spreading)
     int64_t Ls = 1, Ms = 1;   // polyphase stage: output k sits at k * Ms / Ls of ITS input samples
-    mutable int sel[2][2] = {{0, 0}, {0, 0}}; // [float32 / float64]: outputs per thread R and lane multiplier of k_poly (launch_poly)
+    mutable int sel[3][2] = {{0, 0}, {0, 0}, {0, 0}}; // [float32 / float64 / float32 channel pairs]: outputs per thread R and lane multiplier of k_poly (launch_poly)
     void *tab_f = nullptr, *tab_d = nullptr; // device: [P2f][row] float4 / [P2][row] double4 records (a0..a3 of the cubic in x in [0, 1))
 };
 
@@ -183,6 +183,7 @@ struct PolyArgs {
 
 // tap counts the polyphase kernel is instantiated for (twostage_build rounds its design up to the next one)
 #define HIPSOXR_POLY_TAPS(X) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56)
+#define HIPSOXR_POLY2_TAPS(X) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) // k_poly2 (two windows in registers: longer ones spill)
 __device__ __forceinline__ int64_t floor_div(int64_t q, int64_t d) // d > 0
 {
     const int64_t n = q / d;
@@ -420,6 +421,171 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
 #endif
 }
 
+// k_poly2: the float32 register-window form of k_poly for a PAIR of interleaved channels (both ends of the stage channel-
+// interleaved, e.g. stereo): a thread produces R consecutive FRAMES of the pair.  The two channels of a frame share the
+// position, the table row and the cubic's argument, so one set of 16-byte record reads serves both (half the per-tap LDS
+// traffic of two k_poly passes), the packed FMAs run over the channel pair — s_d += a_d[j] * (left, right)[j], the
+// coefficient broadcast by op_sel — and source frames / output frames move as 8-byte words (whole lines in ONE pass over
+// the data instead of half lines in two).  Same arithmetic per channel as k_poly's (sums per cubic coefficient, then
+// Horner), in tap order instead of even / odd halves: results agree to rounding.
+template <int TT, int MQ>
+#ifndef POLY2_OCC
+#define POLY2_OCC 3
+#endif
+__global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArgs a) // (two windows of 32+ frames: 2 workgroups per CU, launch_poly sizes the tile for that)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v4f *tab = reinterpret_cast<v4f *>(smem);
+    v2f *xs = reinterpret_cast<v2f *>(smem + (size_t)a.P * a.row * sizeof(v4f));
+    v2f *ys = xs + a.span_max; // the tile's output frames, staged [R][257]
+    const int cg = 1 << a.lg_cg; // channel PAIRS a workgroup takes one after the other
+    const uint32_t col = (blockIdx.y << a.lg_cg) * 2, ch = col % a.n_channels, clip = col / a.n_channels; // first channel of the group
+    const float *src0 = (const float *)a.src + (int64_t)clip * a.scs + (int64_t)ch;
+    float *dst0 = (float *)a.dst + (int64_t)clip * a.dcs + (int64_t)ch;
+    const int tid = (int)threadIdx.x;
+    const int64_t per_tile = 256LL * a.R, n_tiles = (a.n_out + per_tile - 1) / per_tile;
+    constexpr int H = TT / 2;
+#ifdef POLY2_CH
+    constexpr int CH = TT % POLY2_CH == 0 ? POLY2_CH : 4;
+#else
+    constexpr int CH = TT % 16 == 0 ? 16 : TT % 12 == 0 ? 12 : TT % 8 == 0 ? 8 : 4; // taps whose LDS reads are in flight together
+#endif
+    const int64_t nK0 = floor_div(a.k_lo * a.Ms, a.Ls);
+    const uint64_t phK0 = (uint64_t)((double)(a.k_lo * a.Ms - nK0 * a.Ls) * a.fx_per_rem);
+    auto position = [&](int64_t k, uint64_t &ph) -> int64_t { // (as in k_poly)
+        const uint64_t dk = (uint64_t)(k - a.k_lo), lo = dk * a.step_fx;
+        ph = phK0 + lo;
+        return nK0 + (int64_t)dk * a.Mq + (int64_t)__umul64hi(dk, a.step_fx) + (ph < lo ? 1 : 0);
+    };
+    const int slot = (tid * a.lane_mul) & 255;
+#ifdef POLY_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = __builtin_amdgcn_s_memtime();
+    const unsigned long long tq0 = tq;
+#endif
+    constexpr int NPF = 12; // frames per thread of the NEXT tile's span held in registers (launch_poly keeps the span within 12 x 256)
+    v2f pf[NPF];
+    const v2f zero = {0.f, 0.f};
+    auto fetch = [&](int64_t tile, int c) {
+        const float *src = src0 + 2 * c;
+        const int64_t kA = a.k_lo + tile * per_tile, kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
+        uint64_t ph;
+        const int64_t nA = position(kA, ph) - (H - 1), nB = position(kB, ph) + H;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int64_t n = nA + q * 256 + tid;
+            pf[q] = (n <= nB && n >= a.n_lo && n < a.n_src) ? *reinterpret_cast<const v2f *>(src + n * a.sfs) : zero;
+        }
+    };
+    if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x, 0);
+    { // (the table behind the first span's loads: one round trip for both)
+        const v4f *g = (const v4f *)a.tab;
+        for (int i = tid; i < a.P * a.row; i += 256) tab[i] = g[i];
+    }
+    // (staging the next span BEFORE this tile's stores — gfx9 retires loads and stores through one in-order counter — was
+    //  measured: no gain at 16 taps, 50 -> 55 us at 40; profiles/r05_ab_experiments.txt §7)
+    for (int64_t item = 0;; ++item) { // work items: (tile, channel pair of the group), pairs innermost
+        const int64_t tile = blockIdx.x + (item >> a.lg_cg) * gridDim.x;
+        if (tile >= n_tiles) break;
+        const int c = (int)(item & (cg - 1));
+        const float *src = src0 + 2 * c;
+        const int64_t kA = a.k_lo + tile * per_tile;
+        const int64_t kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
+        uint64_t ph_;
+        const int64_t nA = position(kA, ph_) - (H - 1), nB = position(kB, ph_) + H;
+        const int span = (int)(nB - nA + 1);
+#pragma unroll
+        for (int q = 0; q < NPF; ++q)
+            if (q * 256 + tid < span) xs[q * 256 + tid] = pf[q];
+        for (int i = NPF * 256 + tid; i < span; i += 256) { // (not reached with launch_poly's run lengths)
+            const int64_t n = nA + i;
+            xs[i] = (n >= a.n_lo && n < a.n_src) ? *reinterpret_cast<const v2f *>(src + n * a.sfs) : zero;
+        }
+        POLY_STAMP(0);
+        __syncthreads();
+        POLY_STAMP(1);
+        {
+            const int64_t tn = blockIdx.x + ((item + 1) >> a.lg_cg) * gridDim.x;
+            if (tn < n_tiles) fetch(tn, (int)((item + 1) & (cg - 1)));
+        }
+        const int64_t k1 = kA + (int64_t)slot * a.R;
+        if (k1 <= kB) {
+            uint64_t phase;
+            const int64_t n0 = position(k1, phase);
+            const v2f *w = xs + (n0 - nA - (H - 1));
+            v2f u[TT];
+#pragma unroll
+            for (int j = 0; j < TT; ++j) u[j] = w[j];
+            const v2f *wtop = w + (TT - 2);
+            v2f *yo = ys + slot;
+            const int lg = a.lgP;
+            int left = (int)(kB - k1 + 1 < (int64_t)a.R ? kB - k1 + 1 : (int64_t)a.R);
+            for (; left > 0; --left) {
+                const uint32_t hi = (uint32_t)(phase >> 32);
+                const uint32_t i = hi >> (32 - lg);
+                const float x = (float)(uint32_t)(hi << lg) * 0x1p-32f;
+                const v4f *row = tab + i * (uint32_t)a.row;
+                // the cubic per tap ONCE for both channels (three scalar FMAs), then one packed FMA over the channel pair
+                // with the coefficient broadcast: 3 + 1 instructions per tap against k_poly's 2 x 2 for two channels
+                v2f y0 = zero, y1 = zero;
+#pragma unroll
+                for (int j0 = 0; j0 < TT; j0 += CH) {
+                    v4f cf[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) cf[j] = row[j0 + j];
+#pragma unroll
+                    for (int j = 0; j < CH; j += 2) { // (the value lands in the record's first register: its pair is the operand, low half broadcast)
+                        cf[j].x = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(cf[j].w, x, cf[j].z), x, cf[j].y), x, cf[j].x);
+                        cf[j + 1].x = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(cf[j + 1].w, x, cf[j + 1].z), x, cf[j + 1].y), x, cf[j + 1].x);
+                        const v2f c0 = __builtin_shufflevector(cf[j], cf[j], 0, 1), c1 = __builtin_shufflevector(cf[j + 1], cf[j + 1], 0, 1);
+                        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(y0) : "v"(c0), "v"(u[j0 + j]), "v"(y0));
+                        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(y1) : "v"(c1), "v"(u[j0 + j + 1]), "v"(y1));
+                    }
+                }
+                *yo = y0 + y1;
+                yo += 257;
+                const uint64_t next = phase + a.step_fx;
+                const bool adv = next < phase; // the fraction wrapped: one more frame
+                phase = next;
+                wtop += MQ + (adv ? 1 : 0);
+                const v2f e0 = wtop[0], e1 = wtop[1]; // (the span has 4 spare frames behind the last window)
+                // (explicit selects: left to the compiler, a select between two elements of the window becomes a dynamically
+                //  indexed extract — a compare and a select per ELEMENT of the array.  v_bfi_b32 on a lane mask held in a VECTOR
+                //  register: v_cndmask with its mask in a scalar pair issues at half rate on gfx950 — 4.4 against 2.7 cycles,
+                //  tools/ubench/valu_ops.hip)
+                const uint32_t advm = adv ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int j = 0; j < TT - 2; ++j) {
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(u[j].x) : "v"(advm), "v"(u[j + MQ + 1].x), "v"(u[j + MQ].x));
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(u[j].y) : "v"(advm), "v"(u[j + MQ + 1].y), "v"(u[j + MQ].y));
+                }
+                u[TT - 2] = e0; u[TT - 1] = e1;
+            }
+        }
+        POLY_STAMP(2);
+        __syncthreads(); // the tile's outputs are staged and its source span is free
+        POLY_STAMP(3);
+        {
+            float *yo = dst0 + 2 * c + (kA - a.k_lo) * a.dfs;
+            const int cnt = (int)(kB - kA + 1);
+            const float invR = 1.f / (float)a.R;
+            for (int i = tid; i < cnt; i += 256) {
+                const int sl = (int)(((float)i + .5f) * invR), r = i - sl * a.R; // frame i of the tile: run index r of slot sl
+                *reinterpret_cast<v2f *>(yo + (int64_t)i * a.dfs) = ys[r * 257 + sl];
+            }
+        }
+        POLY_STAMP(4);
+    }
+#ifdef POLY_TRACE
+    if (a.trace && (tid & 63) == 0) {
+        unsigned long long *o = a.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid / 64) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = tr[i];
+        o[5] = tq0; o[6] = tq; o[7] = 0;
+    }
+#endif
+}
+
 template <typename Real>
 static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, int64_t n_lo, int64_t n_src, int64_t k_lo, int64_t n_out, uint32_t n_clips, uint32_t n_channels,
                                const int64_t sstr[3], const int64_t dstr[3], hipStream_t st)
@@ -439,13 +605,21 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     a.n_channels = n_channels;
     // channels per workgroup: neighbouring channels of interleaved data (source or destination) share their lines
     a.lg_cg = (sstr[2] == 1 || dstr[2] == 1) ? (n_channels % 4 == 0 ? 2 : n_channels % 2 == 0 ? 1 : 0) : 0;
+    // float32, both ends channel-interleaved with an even channel count and 8-byte aligned frames, windows that move by at
+    // most two frames: channel PAIRS on k_poly2 (one pass over the data, table reads shared by the two channels)
+    const bool pair = sizeof(Real) == 4 && (a.Mq == 0 || a.Mq == 1) && n_channels % 2 == 0 && sstr[2] == 1 && dstr[2] == 1 &&
+                      ((sstr[0] | sstr[1] | dstr[0] | dstr[1]) & 1) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 7) == 0 && ts.T2 <= 40 && !switches().poly_no_pair;
+    if (pair) a.lg_cg = n_channels % 8 == 0 ? 2 : n_channels % 4 == 0 ? 1 : 0;
     const int cg = 1 << a.lg_cg;
+    const size_t unit = pair ? 2 * sizeof(Real) : sizeof(Real); // bytes per staged source / output element
     // outputs per thread: as many as keep the tile's source span within the LDS left beside the table (<= 8)
     const size_t tab_bytes = (size_t)P * ts.row * 4 * sizeof(Real);
-    const size_t lds_cap = (sizeof(Real) == 4 ? (tab_bytes > 40 * 1024 ? 78 : 52) : 96) * 1024; // three or two (float) / one (double) workgroups per CU
+    const size_t lds_cap = (sizeof(Real) == 4 ? (tab_bytes > 40 * 1024 || (pair && ts.T2 >= 32) ? 78 : 52) : 96) * 1024; // three or two (float) / one (double) workgroups per CU
     const double ratio = (double)ts.Ms / (double)ts.Ls;
     int Rmax = 12;
-    while (Rmax > 1 && tab_bytes + (size_t)(256. * Rmax * ratio + 257. * Rmax + ts.T2 + 4) * sizeof(Real) > lds_cap) --Rmax; // (source span + staged outputs)
+    while (Rmax > 1 && (tab_bytes + (size_t)(256. * Rmax * ratio + 257. * Rmax + ts.T2 + 4) * unit > lds_cap || // (source span + staged outputs)
+                        (pair && 256. * Rmax * ratio + ts.T2 + 4 > 12. * 256.)))                                      // (k_poly2 holds a whole span in registers)
+        --Rmax;
     // Thread t owns R consecutive outputs starting ((t * lane_mul) mod 256) * R into the tile (lane_mul odd: a bijection).
     // Lanes l, l + 1 of a wave are then lane_mul * R outputs apart and their table rows form the arithmetic progression
     // floor(c + l s), s = frac(lane_mul R Ms / Ls) P.  A 16-byte LDS read serves a lane group in one cycle when its 16 lanes
@@ -457,7 +631,7 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     {
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
-        int *sel = ts.sel[sizeof(Real) == 8];
+        int *sel = ts.sel[pair ? 2 : sizeof(Real) == 8];
         if (!sel[0]) {
             static const int group[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                              {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
@@ -493,9 +667,9 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     a.lane_mul = lane_mul;
     a.R = R;
     a.span_max = (int)(256. * R * ratio + ts.T2 + 4);
-    const size_t lds = tab_bytes + ((size_t)a.span_max + 257u * (size_t)R) * sizeof(Real);
+    const size_t lds = tab_bytes + ((size_t)a.span_max + 257u * (size_t)R) * unit;
     if (lds > 160 * 1024) return "two-stage: polyphase tile does not fit LDS";
-    const uint64_t cols = (uint64_t)n_clips * n_channels / (uint64_t)cg; // channel groups
+    const uint64_t cols = (uint64_t)n_clips * n_channels / (uint64_t)(pair ? 2 * cg : cg); // channel groups
     if (cols > 65535) return "two-stage: too many columns";
     const int64_t n_tiles = (n_out + 256LL * R - 1) / (256LL * R);
     void (*kern)(PolyArgs) = nullptr;
@@ -504,6 +678,12 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
         HIPSOXR_POLY_TAPS(HIPSOXR_POLY_T)
 #undef HIPSOXR_POLY_T
     }
+    if constexpr (sizeof(Real) == 4)
+        if (pair) switch (ts.T2) {
+#define HIPSOXR_POLY_T(t) case t: kern = a.Mq == 0 ? k_poly2<t, 0> : k_poly2<t, 1>; break;
+            HIPSOXR_POLY2_TAPS(HIPSOXR_POLY_T)
+#undef HIPSOXR_POLY_T
+        }
     if (!kern) return "two-stage: no polyphase instance for this tap count";
     if (const char *e = ensure_dyn_lds((const void *)kern, lds)) return e;
     // workgroups walk tiles (the table is loaded once per workgroup): exactly as many as the chip holds at once — a
