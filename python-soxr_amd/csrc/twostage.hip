@@ -472,11 +472,14 @@ __global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArg
         const int64_t kA = a.k_lo + tile * per_tile, kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
         uint64_t ph;
         const int64_t nA = position(kA, ph) - (H - 1), nB = position(kB, ph) + H;
+        // frames [lo, hi) of the span exist (uniform, 32-bit from here on: one unsigned compare and one pointer step per load)
+        const int64_t lo64 = a.n_lo - nA, hi64 = (nB + 1 < a.n_src ? nB + 1 : a.n_src) - nA;
+        const int lo = (int)(lo64 < 0 ? 0 : lo64 > NPF * 256 ? NPF * 256 : lo64), hi = (int)(hi64 < lo ? lo : hi64 > NPF * 256 ? NPF * 256 : hi64);
+        const float *p = src + (nA + tid) * a.sfs;
+        const int64_t step = 256 * a.sfs;
 #pragma unroll
-        for (int q = 0; q < NPF; ++q) {
-            const int64_t n = nA + q * 256 + tid;
-            pf[q] = (n <= nB && n >= a.n_lo && n < a.n_src) ? *reinterpret_cast<const v2f *>(src + n * a.sfs) : zero;
-        }
+        for (int q = 0; q < NPF; ++q, p += step)
+            pf[q] = (unsigned)(q * 256 + tid - lo) < (unsigned)(hi - lo) ? *reinterpret_cast<const v2f *>(p) : zero;
     };
     if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x, 0);
     { // (the table behind the first span's loads: one round trip for both)
@@ -551,14 +554,14 @@ __global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArg
                 wtop += MQ + (adv ? 1 : 0);
                 const v2f e0 = wtop[0], e1 = wtop[1]; // (the span has 4 spare frames behind the last window)
                 // (explicit selects: left to the compiler, a select between two elements of the window becomes a dynamically
-                //  indexed extract — a compare and a select per ELEMENT of the array.  v_bfi_b32 on a lane mask held in a VECTOR
-                //  register: v_cndmask with its mask in a scalar pair issues at half rate on gfx950 — 4.4 against 2.7 cycles,
-                //  tools/ubench/valu_ops.hip)
-                const uint32_t advm = adv ? 0xffffffffu : 0u;
+                //  indexed extract — a compare and a select per ELEMENT of the array.  v_cndmask with its mask in a scalar pair
+                //  issues at half rate on gfx950, and so does v_bfi_b32 on a mask in a vector register — 4.4 and 4.7 cycles
+                //  against 2.7 for v_fma_f32, tools/ubench/valu_ops.hip: the shift is a quarter of the loop's issue time)
+                const uint64_t advm = __builtin_amdgcn_ballot_w64(adv);
 #pragma unroll
                 for (int j = 0; j < TT - 2; ++j) {
-                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(u[j].x) : "v"(advm), "v"(u[j + MQ + 1].x), "v"(u[j + MQ].x));
-                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(u[j].y) : "v"(advm), "v"(u[j + MQ + 1].y), "v"(u[j + MQ].y));
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(u[j].x) : "v"(u[j + MQ].x), "v"(u[j + MQ + 1].x), "s"(advm));
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(u[j].y) : "v"(u[j + MQ].y), "v"(u[j + MQ + 1].y), "s"(advm));
                 }
                 u[TT - 2] = e0; u[TT - 1] = e1;
             }
@@ -567,12 +570,13 @@ __global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArg
         __syncthreads(); // the tile's outputs are staged and its source span is free
         POLY_STAMP(3);
         {
-            float *yo = dst0 + 2 * c + (kA - a.k_lo) * a.dfs;
+            float *yo = dst0 + 2 * c + (kA - a.k_lo + tid) * a.dfs;
+            const int64_t step = 256 * a.dfs;
             const int cnt = (int)(kB - kA + 1);
             const float invR = 1.f / (float)a.R;
-            for (int i = tid; i < cnt; i += 256) {
+            for (int i = tid; i < cnt; i += 256, yo += step) {
                 const int sl = (int)(((float)i + .5f) * invR), r = i - sl * a.R; // frame i of the tile: run index r of slot sl
-                *reinterpret_cast<v2f *>(yo + (int64_t)i * a.dfs) = ys[r * 257 + sl];
+                *reinterpret_cast<v2f *>(yo) = ys[r * 257 + sl];
             }
         }
         POLY_STAMP(4);

@@ -23,7 +23,6 @@ __global__ void k(float *out, const float *in, int iters)
     float d[8], a[8], b[8], c[8];
     const float s = in[200];
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(in[201 + (threadIdx.x & 63)] > 0.f);
-    if (MODE == 18) asm volatile("s_mov_b64 vcc, %0" : : "s"(mask) : "vcc");
 #pragma unroll
     for (int r = 0; r < 8; ++r) { d[r] = in[(threadIdx.x + r) & 63]; a[r] = in[64 + ((threadIdx.x + r) & 63)]; b[r] = in[128 + ((threadIdx.x + 3 * r) & 63)]; c[r] = in[(threadIdx.x + 5 * r) & 63]; }
     v2f pd[4], pa[4], pb[4];
@@ -49,7 +48,7 @@ __global__ void k(float *out, const float *in, int iters)
                 if (MODE == 15) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(d[r]) : "s"(s), "v"(a[r]));
                 if (MODE == 16) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(d[r]) : "v"(c[0]), "v"(a[r]));
                 if (MODE == 17) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d[r]) : "v"(a[r]), "v"(b[r]), "s"(mask));
-                if (MODE == 18) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(d[r]) : "v"(a[r]), "v"(b[r]) : "vcc");
+                if (MODE == 21) asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(d[r]) : "v"(c[0]), "v"(a[r]), "v"(b[r]));
                 if (MODE == 8) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d[r]) : "v"(a[r]), "v"(b[r]), "v"(d[(r + 7) & 7]));
             }
             if (MODE == 5) {
@@ -70,6 +69,11 @@ __global__ void k(float *out, const float *in, int iters)
                     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[r + 1]) : "v"(c[r]), "v"(b[r + 1]), "v"(t1));
                 }
             }
+            if (MODE == 18) // (one statement: the compiler must not touch vcc between the move and its readers)
+                asm volatile("s_mov_b64 vcc, %8\n\tv_cndmask_b32_e32 %0, %0, %1, vcc\n\tv_cndmask_b32_e32 %1, %1, %2, vcc\n\tv_cndmask_b32_e32 %2, %2, %3, vcc\n\t"
+                             "v_cndmask_b32_e32 %3, %3, %4, vcc\n\tv_cndmask_b32_e32 %4, %4, %5, vcc\n\tv_cndmask_b32_e32 %5, %5, %6, vcc\n\t"
+                             "v_cndmask_b32_e32 %6, %6, %7, vcc\n\tv_cndmask_b32_e32 %7, %7, %0, vcc"
+                             : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]) : "s"(mask) : "vcc");
             if (MODE == 19 || MODE == 20) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -137,7 +141,8 @@ int main()
     run<5>(out, in, "complex multiply (mul mul fma fma)", 8 * 32 / 8 * 8 / 8 * 8); // 32 per u, 8 u's
     run<7>(out, in, "v_pk_add_f32", 64);
     run<17>(out, in, "v_cndmask_b32_e64 (mask in an SGPR pair)", 64);
-    run<18>(out, in, "v_cndmask_b32_e32 (mask in vcc)", 64);
+    run<18>(out, in, "v_cndmask_b32_e32 (mask in vcc; + 1 s_mov per 8)", 64);
+    run<21>(out, in, "v_bfi_b32 (mask in a VGPR)", 64);
     run<19>(out, in, "v_pk_fma_f32 op_sel broadcast (per pk instr)", 64);
     run<20>(out, in, "v_pk_fma_f32 plain (per pk instr)", 64);
     return 0;
