@@ -927,7 +927,7 @@ def main():
             _, k3e, _ = time_workload(plan3, x3, 5, 2, world, device, 6, windows=4)
             bytes3 = 4.0 * (x3.numel() + y3.numel())
             result["arbitrary_ratio"] = {"workload": f"VHQ 48000->44101 float32, {args.seconds} s stereo interleaved, device-resident (interpolated-phase plan: {plan3.phases} intervals x {plan3.taps} taps)",
-                                         "launch_us": k3 * 1e6, "kernel": "two-stage: k_poly<float, T2, MQ> + k_fft (2:1), two launches (csrc/twostage.hip)",
+                                         "launch_us": k3 * 1e6, "kernel": "two-stage: k_poly2<T2, MQ> (interleaved channel pair per pass) + k_fft (2:1), two launches (csrc/twostage.hip)",
                                          "value": x3.numel() / k3 / 1e6, "unit": "Msamples/s", "hbm_frac": bytes3 / k3 / 1e9 / HBM_PEAK_GBS,
                                          "exact_engine_launch_us": k3e * 1e6, "speedup_over_exact": k3e / k3}
             del x3, y3, plan3

@@ -91,6 +91,34 @@ def test_two_stage_batches_and_layouts(oracle):
             assert 0 < rel <= 1e-6, (ch, a, b, rel)
 
 
+def test_two_stage_channel_pairs_on_views():
+    """Round 5: interleaved channel pairs run on k_poly2 (8-byte frames, the table reads and the cubic per tap shared by the
+    two channels) when both ends of the polyphase stage are channel-interleaved, frame strides are even and the data is
+    8-byte aligned; everything else stays on the one-channel-per-pass kernel.  Views that are eligible (two channels of a
+    four-channel tensor at an even offset), views that are not (odd channel offset: 4-byte aligned only; odd frame stride),
+    results written into a view — each within 1e-6 of the exact engine on a contiguous copy, up- and down-sampling."""
+    import torch
+    from soxr_amd import device as dev
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    x4 = torch.randn((260000, 4), device="cuda", generator=g) * 0.25
+    x3 = torch.randn((260000, 3), device="cuda", generator=g) * 0.25
+    for a, b in ((48000, 44101), (44101, 48000), (44100, 16001.5), (16000, 44099)):
+        plan = dev.Plan(a, b, "VHQ")
+        for view in (x4[:, 0:2], x4[:, 1:3], x4[:, 2:4], x3[:, 0:2], x3[:, 1:3], x4):
+            ye = dev.resample_tensor(plan, view.contiguous(), kernel=dev.KERNEL_EXACT).double()
+            y = dev.resample_tensor(plan, view)
+            assert y.shape == ye.shape
+            rel = float((y.double() - ye).pow(2).mean().sqrt() / ye.pow(2).mean().sqrt())
+            assert 0 < rel <= 1e-6, (a, b, tuple(view.stride()), view.storage_offset(), rel)
+            # ... and into two channels of a wider result (even and odd channel offsets)
+            for off in (0, 1):
+                wide = torch.zeros((y.shape[0], view.shape[1] + 2), device="cuda")
+                dev.resample_tensor(plan, view, out=wide[:, off:off + view.shape[1]])
+                assert torch.equal(wide[:, off:off + view.shape[1]], y) or \
+                    float((wide[:, off:off + view.shape[1]].double() - ye).pow(2).mean().sqrt() / ye.pow(2).mean().sqrt()) <= 1e-6
+                assert float(wide[:, :off].abs().sum()) == 0 and float(wide[:, off + view.shape[1]:].abs().sum()) == 0
+
+
 def _edge_pairs():
     r = random.Random(77)
     fixed = [(48000, 48001), (48001, 48000), (44100, 44100.5), (8000, 31999), (8000, 32001), (96000, 24001), (96000, 23999.5),
