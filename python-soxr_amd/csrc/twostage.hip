@@ -179,6 +179,9 @@ struct PolyArgs {
     int64_t n_lo, n_src, k_lo, n_out; // the source column holds samples [n_lo, n_src) (src points at sample 0; zero outside); outputs [k_lo, k_lo + n_out), k_lo may be < 0
     int64_t scs, sfs, schs, dcs, dfs, dchs;
     uint32_t n_channels;
+    // k_poly2<.., IL = false>: member 2 of a split column — element offsets of its sample n / output k from the column's,
+    // its sample n = the column's n + m2_shift, and how many outputs it has (member 1 has n_out)
+    int64_t m2_src, m2_dst, m2_shift, m2_n_out;
 };
 
 // tap counts the polyphase kernel is instantiated for (twostage_build rounds its design up to the next one)
@@ -428,7 +431,11 @@ __global__ void __launch_bounds__(256) k_poly(PolyArgs a)
 // coefficient broadcast by op_sel — and source frames / output frames move as 8-byte words (whole lines in ONE pass over
 // the data instead of half lines in two).  Same arithmetic per channel as k_poly's (sums per cubic coefficient, then
 // Horner), in tap order instead of even / odd halves: results agree to rounding.
-template <int TT, int MQ>
+// IL = false — any OTHER column (mono, planar, odd channel counts): the pair is two SEGMENTS OF ONE COLUMN a whole number of
+// phase periods apart.  Output k + h Ls sits exactly h Ms source samples behind output k (positions are k Ms / Ls), so the
+// two have the same fraction — the same table row and argument — for every k: member 2 of the pair is the column from
+// output h Ls on (PolyArgs::m2_*; launch_poly picks h = half the job's periods), read and written as 4-byte words.
+template <int TT, int MQ, bool IL>
 #ifndef POLY2_OCC
 #define POLY2_OCC 3
 #endif
@@ -440,10 +447,11 @@ __global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArg
     v4f *tab = reinterpret_cast<v4f *>(smem);
     v2f *xs = reinterpret_cast<v2f *>(smem + (size_t)a.P * a.row * sizeof(v4f));
     v2f *ys = xs + a.span_max; // the tile's output frames, staged [R][257]
-    const int cg = 1 << a.lg_cg; // channel PAIRS a workgroup takes one after the other
-    const uint32_t col = (blockIdx.y << a.lg_cg) * 2, ch = col % a.n_channels, clip = col / a.n_channels; // first channel of the group
-    const float *src0 = (const float *)a.src + (int64_t)clip * a.scs + (int64_t)ch;
-    float *dst0 = (float *)a.dst + (int64_t)clip * a.dcs + (int64_t)ch;
+    const int cg = 1 << a.lg_cg; // channel PAIRS (IL) / channels a workgroup takes one after the other
+    const uint32_t col = (blockIdx.y << a.lg_cg) * (IL ? 2 : 1), ch = col % a.n_channels, clip = col / a.n_channels; // first channel of the group
+    const int64_t c_src = IL ? 2 : a.schs, c_dst = IL ? 2 : a.dchs; // from one item of the group to the next
+    const float *src0 = (const float *)a.src + (int64_t)clip * a.scs + (int64_t)ch * (IL ? 1 : a.schs);
+    float *dst0 = (float *)a.dst + (int64_t)clip * a.dcs + (int64_t)ch * (IL ? 1 : a.dchs);
     const int tid = (int)threadIdx.x;
     const int64_t per_tile = 256LL * a.R, n_tiles = (a.n_out + per_tile - 1) / per_tile;
     constexpr int H = TT / 2;
@@ -467,19 +475,27 @@ __global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArg
     constexpr int NPF = 12; // frames per thread of the NEXT tile's span held in registers (launch_poly keeps the span within 12 x 256)
     v2f pf[NPF];
     const v2f zero = {0.f, 0.f};
+    // one frame of the pair at a source position: 8 bytes (IL) or a sample of each member, each with its own range
+    auto load2 = [&](const float *q, bool in1, bool in2) -> v2f {
+        if constexpr (IL) return in1 ? *reinterpret_cast<const v2f *>(q) : zero;
+        else { v2f r; r.x = in1 ? q[0] : 0.f; r.y = in2 ? q[a.m2_src] : 0.f; return r; }
+    };
     auto fetch = [&](int64_t tile, int c) {
-        const float *src = src0 + 2 * c;
+        const float *src = src0 + c * c_src;
         const int64_t kA = a.k_lo + tile * per_tile, kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
         uint64_t ph;
         const int64_t nA = position(kA, ph) - (H - 1), nB = position(kB, ph) + H;
         // frames [lo, hi) of the span exist (uniform, 32-bit from here on: one unsigned compare and one pointer step per load)
         const int64_t lo64 = a.n_lo - nA, hi64 = (nB + 1 < a.n_src ? nB + 1 : a.n_src) - nA;
         const int lo = (int)(lo64 < 0 ? 0 : lo64 > NPF * 256 ? NPF * 256 : lo64), hi = (int)(hi64 < lo ? lo : hi64 > NPF * 256 ? NPF * 256 : hi64);
+        // (member 2 of a split column: its sample n is the column's n + m2_shift)
+        const int64_t lo64b = lo64 - a.m2_shift, hi64b = (nB + 1 < a.n_src - a.m2_shift ? nB + 1 : a.n_src - a.m2_shift) - nA;
+        const int lo2 = IL ? 0 : (int)(lo64b < 0 ? 0 : lo64b > NPF * 256 ? NPF * 256 : lo64b), hi2 = IL ? 0 : (int)(hi64b < lo2 ? lo2 : hi64b > NPF * 256 ? NPF * 256 : hi64b);
         const float *p = src + (nA + tid) * a.sfs;
         const int64_t step = 256 * a.sfs;
 #pragma unroll
         for (int q = 0; q < NPF; ++q, p += step)
-            pf[q] = (unsigned)(q * 256 + tid - lo) < (unsigned)(hi - lo) ? *reinterpret_cast<const v2f *>(p) : zero;
+            pf[q] = load2(p, (unsigned)(q * 256 + tid - lo) < (unsigned)(hi - lo), (unsigned)(q * 256 + tid - lo2) < (unsigned)(hi2 - lo2));
     };
     if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x, 0);
     { // (the table behind the first span's loads: one round trip for both)
@@ -492,7 +508,7 @@ __global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArg
         const int64_t tile = blockIdx.x + (item >> a.lg_cg) * gridDim.x;
         if (tile >= n_tiles) break;
         const int c = (int)(item & (cg - 1));
-        const float *src = src0 + 2 * c;
+        const float *src = src0 + c * c_src;
         const int64_t kA = a.k_lo + tile * per_tile;
         const int64_t kEnd = a.k_lo + a.n_out, kB = (kA + per_tile < kEnd ? kA + per_tile : kEnd) - 1;
         uint64_t ph_;
@@ -503,7 +519,7 @@ __global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArg
             if (q * 256 + tid < span) xs[q * 256 + tid] = pf[q];
         for (int i = NPF * 256 + tid; i < span; i += 256) { // (not reached with launch_poly's run lengths)
             const int64_t n = nA + i;
-            xs[i] = (n >= a.n_lo && n < a.n_src) ? *reinterpret_cast<const v2f *>(src + n * a.sfs) : zero;
+            xs[i] = load2(src + n * a.sfs, n >= a.n_lo && n < a.n_src, n >= a.n_lo - a.m2_shift && n < a.n_src - a.m2_shift);
         }
         POLY_STAMP(0);
         __syncthreads();
@@ -570,13 +586,20 @@ __global__ void __launch_bounds__(256, TT >= 32 ? 2 : POLY2_OCC) k_poly2(PolyArg
         __syncthreads(); // the tile's outputs are staged and its source span is free
         POLY_STAMP(3);
         {
-            float *yo = dst0 + 2 * c + (kA - a.k_lo + tid) * a.dfs;
+            float *yo = dst0 + c * c_dst + (kA - a.k_lo + tid) * a.dfs;
             const int64_t step = 256 * a.dfs;
             const int cnt = (int)(kB - kA + 1);
+            const int64_t left2 = a.m2_n_out - (kA - a.k_lo); // (member 2 of a split column may end inside the tile)
+            const int cnt2 = (int)(left2 < 0 ? 0 : left2 > cnt ? cnt : left2);
             const float invR = 1.f / (float)a.R;
             for (int i = tid; i < cnt; i += 256, yo += step) {
                 const int sl = (int)(((float)i + .5f) * invR), r = i - sl * a.R; // frame i of the tile: run index r of slot sl
-                *reinterpret_cast<v2f *>(yo) = ys[r * 257 + sl];
+                const v2f y = ys[r * 257 + sl];
+                if constexpr (IL) *reinterpret_cast<v2f *>(yo) = y;
+                else {
+                    yo[0] = y.x;
+                    if (i < cnt2) yo[a.m2_dst] = y.y;
+                }
             }
         }
         POLY_STAMP(4);
@@ -614,15 +637,28 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     const bool pair = sizeof(Real) == 4 && (a.Mq == 0 || a.Mq == 1) && n_channels % 2 == 0 && sstr[2] == 1 && dstr[2] == 1 &&
                       ((sstr[0] | sstr[1] | dstr[0] | dstr[1]) & 1) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 7) == 0 && ts.T2 <= 40 && !switches().poly_no_pair;
     if (pair) a.lg_cg = n_channels % 8 == 0 ? 2 : n_channels % 4 == 0 ? 1 : 0;
+    // Any other float32 column of more than ~1.7 phase periods (Ls outputs: integer rate pairs have at most 2 f_out of
+    // them per period): split h periods in — output k + h Ls has output k's fraction — and the two segments run as the pair
+    a.m2_src = a.m2_dst = a.m2_shift = 0; a.m2_n_out = n_out;
+    bool split = false;
+    if (!pair && sizeof(Real) == 4 && (a.Mq == 0 || a.Mq == 1) && ts.T2 <= 40 && !switches().poly_no_pair) {
+        const int64_t h = (n_out + 2 * ts.Ls - 1) / (2 * ts.Ls), n1 = h * ts.Ls, n2 = n_out - n1; // (member 1 is the longer one)
+        if (h >= 1 && 10 * n2 >= 7 * n1 && h * ts.Ms < (1LL << 40)) {
+            split = true;
+            a.n_out = n1; a.m2_n_out = n2; a.m2_shift = h * ts.Ms; a.m2_src = a.m2_shift * sstr[1]; a.m2_dst = n1 * dstr[1];
+        }
+    }
+    const bool two = pair || split; // k_poly2
+    n_out = a.n_out;                // (tiles are counted over member 1 of a split column)
     const int cg = 1 << a.lg_cg;
-    const size_t unit = pair ? 2 * sizeof(Real) : sizeof(Real); // bytes per staged source / output element
+    const size_t unit = two ? 2 * sizeof(Real) : sizeof(Real); // bytes per staged source / output element
     // outputs per thread: as many as keep the tile's source span within the LDS left beside the table (<= 8)
     const size_t tab_bytes = (size_t)P * ts.row * 4 * sizeof(Real);
-    const size_t lds_cap = (sizeof(Real) == 4 ? (tab_bytes > 40 * 1024 || (pair && ts.T2 >= 32) ? 78 : 52) : 96) * 1024; // three or two (float) / one (double) workgroups per CU
+    const size_t lds_cap = (sizeof(Real) == 4 ? (tab_bytes > 40 * 1024 || (two && ts.T2 >= 32) ? 78 : 52) : 96) * 1024; // three or two (float) / one (double) workgroups per CU
     const double ratio = (double)ts.Ms / (double)ts.Ls;
     int Rmax = 12;
     while (Rmax > 1 && (tab_bytes + (size_t)(256. * Rmax * ratio + 257. * Rmax + ts.T2 + 4) * unit > lds_cap || // (source span + staged outputs)
-                        (pair && 256. * Rmax * ratio + ts.T2 + 4 > 12. * 256.)))                                      // (k_poly2 holds a whole span in registers)
+                        (two && 256. * Rmax * ratio + ts.T2 + 4 > 12. * 256.)))                                      // (k_poly2 holds a whole span in registers)
         --Rmax;
     // Thread t owns R consecutive outputs starting ((t * lane_mul) mod 256) * R into the tile (lane_mul odd: a bijection).
     // Lanes l, l + 1 of a wave are then lane_mul * R outputs apart and their table rows form the arithmetic progression
@@ -635,7 +671,7 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     {
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
-        int *sel = ts.sel[pair ? 2 : sizeof(Real) == 8];
+        int *sel = ts.sel[two ? 2 : sizeof(Real) == 8];
         if (!sel[0]) {
             static const int group[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                              {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
@@ -683,8 +719,8 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
 #undef HIPSOXR_POLY_T
     }
     if constexpr (sizeof(Real) == 4)
-        if (pair) switch (ts.T2) {
-#define HIPSOXR_POLY_T(t) case t: kern = a.Mq == 0 ? k_poly2<t, 0> : k_poly2<t, 1>; break;
+        if (two) switch (ts.T2) {
+#define HIPSOXR_POLY_T(t) case t: kern = pair ? (a.Mq == 0 ? k_poly2<t, 0, true> : k_poly2<t, 1, true>) : (a.Mq == 0 ? k_poly2<t, 0, false> : k_poly2<t, 1, false>); break;
             HIPSOXR_POLY2_TAPS(HIPSOXR_POLY_T)
 #undef HIPSOXR_POLY_T
         }

@@ -119,6 +119,32 @@ def test_two_stage_channel_pairs_on_views():
                 assert float(wide[:, :off].abs().sum()) == 0 and float(wide[:, off + view.shape[1]:].abs().sum()) == 0
 
 
+def test_two_stage_split_columns():
+    """Round 5: a column that is not half of an interleaved pair (mono, planar, odd channel counts) is split a whole number
+    of phase periods in and its two segments run as the pair of k_poly2 (output k + h Ls has output k's fraction).  Lengths
+    from below the threshold (single segment) through 1.7 ... 9 periods, the second segment ending inside a tile, mono /
+    planar stereo / 3 interleaved channels, both directions: within 1e-6 of the exact engine overall AND pointwise at the
+    float32 class over the whole signal (a seam or a tail in the wrong place would be O(1))."""
+    import torch
+    from soxr_amd import device as dev
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    for a, b in ((48000, 44101), (44101, 48000), (44100, 16001), (32000, 44099)):
+        plan = dev.Plan(a, b, "VHQ")
+        for frames in (8192, 30000, 41000, 48000, 60001, 100003, 144000, 200017, 400009):
+            for shape in ("mono", "planar2", "inter3"):
+                if shape != "mono" and frames not in (41000, 100003, 400009):
+                    continue
+                x = torch.randn((frames, {"mono": 1, "planar2": 2, "inter3": 3}[shape]), device="cuda", generator=g) * 0.25
+                t = x[:, 0].contiguous() if shape == "mono" else x.t().contiguous().t() if shape == "planar2" else x
+                y = dev.resample_tensor(plan, t).double()
+                ye = dev.resample_tensor(plan, t, kernel=dev.KERNEL_EXACT).double()
+                assert y.shape == ye.shape
+                scale = float(ye.pow(2).mean().sqrt())
+                rel = float((y - ye).pow(2).mean().sqrt()) / scale
+                worst = float((y - ye).abs().max()) / scale
+                assert rel <= 1e-6 and worst <= 1e-5, (a, b, frames, shape, rel, worst)
+
+
 def _edge_pairs():
     r = random.Random(77)
     fixed = [(48000, 48001), (48001, 48000), (44100, 44100.5), (8000, 31999), (8000, 32001), (96000, 24001), (96000, 23999.5),

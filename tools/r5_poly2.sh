@@ -18,9 +18,12 @@ import torch
 from soxr_amd import device as dev
 out = []
 for a, b, fr, ch, q in ((48000, 44101, 2880000, 2, "VHQ"), (44101, 48000, 2880000, 2, "VHQ"), (44100, 16001, 2880000, 2, "VHQ"), (48000, 44101, 2880000, 8, "VHQ"),
-                        (48000, 44101, 2880000, 2, "HQ"), (96000, 88201, 5760000, 2, "VHQ"), (48000, 44101, 480000, 2, "VHQ")):
+                        (48000, 44101, 2880000, 2, "HQ"), (96000, 88201, 5760000, 2, "VHQ"), (48000, 44101, 480000, 2, "VHQ"),
+                        (48000, 44101, 2880000, 1, "VHQ"), (44101, 48000, 2880000, 1, "VHQ"), (44100, 16001, 2880000, 1, "VHQ"), (48000, 44101, 2880000, 3, "VHQ"), (48000, 44101, 2880000, -2, "VHQ")):
     plan = dev.Plan(a, b, q)
-    x = torch.randn((fr, ch), device="cuda") * 0.25
+    x = torch.randn((fr, abs(ch)), device="cuda") * 0.25
+    if ch == 1: x = x[:, 0].contiguous()
+    if ch < 0: x = x.t().contiguous().t()        # planar
     y = dev.resample_tensor(plan, x)
     job = dev.PreparedJob(plan, x, y)
     for _ in range(5): job.launch()
