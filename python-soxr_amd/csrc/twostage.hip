@@ -44,7 +44,8 @@ struct TwoStage {
     Plan fft;                 // the FFT stage's plan: L/M = 2/1 (up) or 1/2 (down), bank from the owner's prototype
     int32_t T2 = 0, P2 = 0, P2f = 0, row = 0; // polyphase stage: taps, table intervals (float64 / float32 table), records per table row (T2 + 1: bank spreading)
     int64_t Ls = 1, Ms = 1;   // polyphase stage: output k sits at k * Ms / Ls of ITS input samples
-    mutable int sel[3][2] = {{0, 0}, {0, 0}, {0, 0}}; // [float32 / float64 / float32 channel pairs]: outputs per thread R and lane multiplier of k_poly (launch_poly)
+    mutable int lane_for[3][16] = {};   // [float32 / float64 / float32 pairs][R]: lane multiplier of k_poly for runs of R outputs per thread (launch_poly; 0 = not simulated yet)
+    mutable float conf_for[3][16] = {}; // ... and its LDS conflict cost (1 = every 16-byte read group in one cycle)
     void *tab_f = nullptr, *tab_d = nullptr; // device: [P2f][row] float4 / [P2][row] double4 records (a0..a3 of the cubic in x in [0, 1))
 };
 
@@ -666,21 +667,35 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     // fall on 16 different bank quads — (row + tap) mod 16 with the table's odd row stride — and takes one more cycle per
     // extra distinct record on a quad.  Random rows cost 2.5-3 cycles; s within ~0.02 of an odd integer costs 1.
     // (R, lane_mul) is picked by simulating the four lane groups of the four waves over 16 starting phases.
+    // R: as long as the tiles fill the workgroups the chip holds, the longest run that fits (a tile's fixed cost is about two
+    // outputs' time: job time = a + b / R with b / a = 2.06 — and a partly filled last round costs its share, not a round:
+    // 60 / 90 / 120 s take 56 / 72 / 88 us); below that, runs short enough to give every resident workgroup a tile
+    // (5 / 10 s stereo 24.3 / 25.0 -> 20.0 / 22.2 us, 10 s mono 26.0 -> 20.2; profiles/r05_ab_experiments.txt §7).
     if (switches().dbg_poly_r > 0) Rmax = std::min(Rmax, switches().dbg_poly_r);
+    const uint64_t cols = (uint64_t)n_clips * n_channels / (uint64_t)(pair ? 2 * cg : cg); // channel groups
+    if (cols > 65535) return "two-stage: too many columns";
+    int dev = 0, n_cu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int occ_limit = two ? (ts.T2 >= 32 ? 2 : 3) : sizeof(Real) == 4 ? 4 : 2; // (registers: k_poly2's launch bounds, k_poly's ~108 / float64's ~200)
+    auto lds_of = [&](int r) { return tab_bytes + ((size_t)(256. * r * ratio + ts.T2 + 4) + 257u * (size_t)r) * unit; };
+    auto slots_of = [&](int r) { // workgroups per column the chip holds at once (launch geometry below)
+        const int per_cu = std::max(1, std::min(occ_limit, (int)((160u * 1024u) / lds_of(r))));
+        return std::max<int64_t>(1, (int64_t)per_cu * n_cu / (int64_t)cols);
+    };
     int R = Rmax, lane_mul = 1;
     {
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
-        int *sel = ts.sel[two ? 2 : sizeof(Real) == 8];
-        if (!sel[0]) {
-            static const int group[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
-                                             {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
-            const int halves = sizeof(Real) == 8 ? 2 : 1; // a double4 record is two 16-byte reads
-            double best = 1e30;
-            sel[0] = Rmax; sel[1] = 1;
-            bool ideal = false; // (every group in one cycle: nothing better to look for — the usual outcome, a few ms of host time once per plan)
-            for (int r = Rmax; r >= std::min(Rmax, std::max(2, Rmax / 3)) && !ideal; --r)
-                for (int am = 1; am < 256 && !ideal; am += 2) {
+        const int which = two ? 2 : sizeof(Real) == 8;
+        auto lanes_for = [&](int r) -> double { // best lane multiplier for runs of r (cached per plan): its conflict cost, 1 = none
+            if (!ts.lane_for[which][r]) {
+                static const int group[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                                 {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+                const int halves = sizeof(Real) == 8 ? 2 : 1; // a double4 record is two 16-byte reads
+                double best = 1e30;
+                int best_am = 1;
+                for (int am = 1; am < 256 && best > 16. * 16. * halves; am += 2) { // (every group in one cycle: nothing better to look for)
                     double cost = 0.;
                     for (int ph = 0; ph < 16 && cost < best; ++ph)
                         for (int wave = 0; wave < 4; ++wave)
@@ -697,20 +712,29 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
                                 }
                                 cost += mx;
                             }
-                    ideal = cost == 16. * 16. * halves;
-                    cost *= 1. + .02 * (Rmax - r); // (a shorter run per thread: more tiles per output)
-                    if (cost < best) { best = cost; sel[0] = r; sel[1] = am; }
+                    if (cost < best) { best = cost; best_am = am; }
                 }
-        }
-        R = std::min(sel[0], Rmax); lane_mul = sel[1];
+                ts.lane_for[which][r] = best_am; ts.conf_for[which][r] = (float)(best / (16. * 16. * halves));
+            }
+            return ts.conf_for[which][r];
+        };
+        const int64_t slots = slots_of(Rmax);
+        if ((n_out + 256LL * Rmax - 1) / (256LL * Rmax) >= slots) { // a round or more: long runs, among them the one whose table reads conflict least
+            double best = 1e30;
+            for (int r = Rmax; r >= std::min(Rmax, std::max(2, Rmax / 3)) && best > 1.; --r) {
+                const double cost = lanes_for(r) * (1. + .02 * (Rmax - r)); // (a shorter run per thread: more tiles per output)
+                if (cost < best) { best = cost; R = r; }
+            }
+        } else // less than one round: shorter runs spread the job over the workgroups the chip holds
+            R = (int)std::max<int64_t>(std::min(Rmax, 2), std::min<int64_t>(Rmax, (n_out + 256 * slots - 1) / (256 * slots)));
+        lanes_for(R);
+        lane_mul = ts.lane_for[which][R];
     }
     a.lane_mul = lane_mul;
     a.R = R;
     a.span_max = (int)(256. * R * ratio + ts.T2 + 4);
     const size_t lds = tab_bytes + ((size_t)a.span_max + 257u * (size_t)R) * unit;
     if (lds > 160 * 1024) return "two-stage: polyphase tile does not fit LDS";
-    const uint64_t cols = (uint64_t)n_clips * n_channels / (uint64_t)(pair ? 2 * cg : cg); // channel groups
-    if (cols > 65535) return "two-stage: too many columns";
     const int64_t n_tiles = (n_out + 256LL * R - 1) / (256LL * R);
     void (*kern)(PolyArgs) = nullptr;
     switch (ts.T2) {
@@ -728,10 +752,8 @@ static const char *launch_poly(const TwoStage &ts, const void *src, void *dst, i
     if (const char *e = ensure_dyn_lds((const void *)kern, lds)) return e;
     // workgroups walk tiles (the table is loaded once per workgroup): exactly as many as the chip holds at once — a
     // partly filled second round of workgroups would double the launch
-    int per_cu = 0, dev = 0, n_cu = 256;
+    int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 256, lds));
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t want = std::max<int64_t>(1, (int64_t)std::max(per_cu, 1) * n_cu / (int64_t)cols);
     unsigned gx = (unsigned)std::min<int64_t>(n_tiles, want);
     if (gx > 8) gx &= ~7u; // columns' workgroups of one tile index on ONE XCD (workgroup b -> XCD b mod 8): interleaved channels share their lines in its L2
