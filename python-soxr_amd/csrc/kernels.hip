@@ -81,7 +81,7 @@ const Switches &switches()
         w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD");
         w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT");
         w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS");
-        w.dbg_tile_form = num("HIPSOXR_DEBUG_TILE_FORM"); w.dbg_poly_r = num("HIPSOXR_DEBUG_POLY_R"); w.poly_no_pair = on("HIPSOXR_POLY_NO_PAIR"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
+        w.dbg_tile_form = num("HIPSOXR_DEBUG_TILE_FORM"); w.dbg_poly_r = num("HIPSOXR_DEBUG_POLY_R"); w.no_interp_pair = on("HIPSOXR_NO_INTERP_PAIR"); w.dbg_interp_pair_always = on("HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS"); w.poly_no_pair = on("HIPSOXR_POLY_NO_PAIR"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
 #endif
         return w;
     }();
@@ -522,6 +522,14 @@ struct InterpTileArgs {
     InterpArgs ia;
     int32_t KO;        // outputs per workgroup
     int32_t span_cap;  // staged input samples (>= span of any workgroup)
+    // PAIR instances: a lane carries TWO outputs that share position, interval and cubic argument — the neighbouring channel
+    // (ch + 1), or the same column h periods of L outputs further on (output k + h L sits exactly h M input samples behind
+    // output k with the same remainder) — so the interval's records stream through the scalar cache once for both and the
+    // cubic per tap is evaluated once; each member's own FMA chain is untouched (bit-identical results).
+    uint32_t cols_per_clip, ch_step; // column -> (clip, first channel): col / cols_per_clip, (col % cols_per_clip) * ch_step
+    int64_t m2_in, m2_out;           // member 2: element offsets of its input frame l / output k from member 1's
+    int64_t m2_l, m2_k, m2_n;        // ... its input frame = l + m2_l, its output index = k + m2_k, and how many outputs it has
+    int32_t m2_dch;                  // ... its channel = ch + m2_dch (dither / clip-counter context)
 };
 
 template <typename Real> struct InterpPos { int64_t n0; uint32_t iv; uint64_t xq; };
@@ -723,9 +731,10 @@ __global__ void __launch_bounds__(256) k_interp_wave(InterpWaveArgs wa)
     }
 }
 
-template <typename IO, typename Real, bool VR>
+template <typename IO, typename Real, bool VR, bool PAIR>
 __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
 {
+    constexpr int NM = PAIR ? 2 : 1; // members per lane; the staged span is [sample][member]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const InterpArgs &ia = ta.ia;
     const GatherArgs &a = ia.g;
@@ -740,15 +749,15 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     //  interval, three workgroups per CU: 628 us; 15: 1013): a group of <= 64 outputs walks its interval's whole row of
     //  cubic records, 4.8 KB, through the scalar cache, which it misses — 423 MB per launch, ~6 bytes per cycle per scalar
     //  cache.  Coefficient delivery is the bound; requesting a block ahead (one block is all the SGPRs hold) was slower.)
-    Real *xs = reinterpret_cast<Real *>(smem_raw);                       // [span_cap]
-    uint16_t *order = reinterpret_cast<uint16_t *>(xs + ta.span_cap);    // [KO]  outputs sorted by interval
+    Real *xs = reinterpret_cast<Real *>(smem_raw);                       // [span_cap][NM]
+    uint16_t *order = reinterpret_cast<uint16_t *>(xs + (size_t)ta.span_cap * NM); // [KO]  outputs sorted by interval
     uint32_t *off = reinterpret_cast<uint32_t *>(order + ((KO + 1) & ~1)); // [P + 1] bucket offsets
     uint32_t *cur = off + (P + 1);                                       // [P]     scatter cursors
 
     const uint32_t col = blockIdx.y;
     // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
     // address derived from them) on the scalar side
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
+    const uint32_t ch = __builtin_amdgcn_readfirstlane((col % ta.cols_per_clip) * ta.ch_step), clip = __builtin_amdgcn_readfirstlane(col / ta.cols_per_clip);
     const int64_t o_base = (int64_t)blockIdx.x * KO;
     const int32_t n_here = (int32_t)((a.out_frames - o_base) < KO ? (a.out_frames - o_base) : KO);
     const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
@@ -781,7 +790,8 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     // 2. stage the input span (zero outside the signal), converted to the engine precision
     for (int m = threadIdx.x; m < span; m += blockDim.x) {
         const int64_t l = n_first + m - a.in_abs0;
-        xs[m] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+        xs[NM * m] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+        if constexpr (PAIR) xs[NM * m + 1] = (l + ta.m2_l >= 0 && l + ta.m2_l < a.in_frames) ? (Real)xin[ta.m2_in + l * a.ifs] : (Real)0;
     }
     __syncthreads();
     if (threadIdx.x < 64) { // inclusive scan of off[1..P] (P <= 256 = 64 lanes x 4) by the first wave
@@ -836,30 +846,47 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
             const bool live = key != 0xFFFFu;
             const int i = live ? (int)key : (int)order[b0];
             const InterpPos<Real> rc = locate(i);
-            const Real *xl = xs + (uint32_t)(rc.n0 - n_first);
+            const Real *xl = xs + NM * (uint32_t)(rc.n0 - n_first);
             const Real xx = (Real)(uint32_t)rc.xq * (Real)(1. / (double)(1ULL << SH));
-            Real accL = 0, accR = 0;
+            Real accL = 0, accR = 0, accL2 = 0, accR2 = 0;
+            // (one tap: the canonical cubic, then each member's own chain FMA)
+            // (PAIR: the two members' samples in ONE 8- / 16-byte LDS read — separate 4-byte reads at a stride of two words
+            //  would use every other bank)
+            typedef Real RealX2 __attribute__((ext_vector_type(2)));
+#define HIPSOXR_ITILE_TAP(c0, c1, c2, c3, t, L, L2)                                   \
+    {                                                                                \
+        const Real cj = fma_r(fma_r(fma_r(c3, xx, c2), xx, c1), xx, c0);             \
+        if constexpr (PAIR) {                                                        \
+            const RealX2 xv = reinterpret_cast<const RealX2 *>(x4)[t];               \
+            L = fma_r(cj, xv.x, L);                                                  \
+            L2 = fma_r(cj, xv.y, L2);                                                \
+        } else                                                                       \
+            L = fma_r(cj, x4[t], L);                                                 \
+    }
 #pragma unroll 2
             for (int b = 0; b < H / 4; ++b) { // T is a multiple of 8: H is a multiple of 4
                 const RealX16 c = row[b];
-                const Real *x4 = xl + 4 * b;
-                accL = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accL);
-                accL = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accL);
-                accL = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accL);
-                accL = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accL);
+                const Real *x4 = xl + NM * 4 * b;
+                HIPSOXR_ITILE_TAP(c[0], c[1], c[2], c[3], 0, accL, accL2)
+                HIPSOXR_ITILE_TAP(c[4], c[5], c[6], c[7], 1, accL, accL2)
+                HIPSOXR_ITILE_TAP(c[8], c[9], c[10], c[11], 2, accL, accL2)
+                HIPSOXR_ITILE_TAP(c[12], c[13], c[14], c[15], 3, accL, accL2)
             }
 #pragma unroll 2
             for (int b = T / 4 - 1; b >= H / 4; --b) { // descending taps
                 const RealX16 c = row[b];
-                const Real *x4 = xl + 4 * b;
-                accR = fma_r(fma_r(fma_r(fma_r(c[15], xx, c[14]), xx, c[13]), xx, c[12]), x4[3], accR);
-                accR = fma_r(fma_r(fma_r(fma_r(c[11], xx, c[10]), xx, c[9]), xx, c[8]), x4[2], accR);
-                accR = fma_r(fma_r(fma_r(fma_r(c[7], xx, c[6]), xx, c[5]), xx, c[4]), x4[1], accR);
-                accR = fma_r(fma_r(fma_r(fma_r(c[3], xx, c[2]), xx, c[1]), xx, c[0]), x4[0], accR);
+                const Real *x4 = xl + NM * 4 * b;
+                HIPSOXR_ITILE_TAP(c[12], c[13], c[14], c[15], 3, accR, accR2)
+                HIPSOXR_ITILE_TAP(c[8], c[9], c[10], c[11], 2, accR, accR2)
+                HIPSOXR_ITILE_TAP(c[4], c[5], c[6], c[7], 1, accR, accR2)
+                HIPSOXR_ITILE_TAP(c[0], c[1], c[2], c[3], 0, accR, accR2)
             }
+#undef HIPSOXR_ITILE_TAP
             if (live) {
                 const int64_t idx = o_base + i;
                 store_out<Real>(yo + idx * a.ofs, accL + accR, a.oc, ch, a.out_k0 + idx);
+                if constexpr (PAIR)
+                    if (idx < ta.m2_n) store_out<Real>(yo + ta.m2_out + idx * a.ofs, accL2 + accR2, a.oc, ch + ta.m2_dch, a.out_k0 + idx + ta.m2_k);
             }
         }
     }
@@ -2694,6 +2721,8 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             // (input span + 2 bytes of bookkeeping per output), at least ~32 outputs per interval
             const bool no_itile = switches().no_interp_tile;
             int64_t KO = 0, span_cap = 0;
+            int pair_mode = 0;          // k_interp_tile: 0 one output per lane, 1 channel pairs, 2 the column's two halves
+            int64_t split_h = 0, nf_t = nf; // (outputs the tiles are counted over: member 1's)
             // position of this launch's first output on the variable-rate clock: (T0, S0) advanced by `done` outputs
             auto vr_advance = [&](InterpArgs &x) {
                 typedef unsigned __int128 u128;
@@ -2719,17 +2748,38 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 // (round 3: among the sizes that fit, the one that leaves the fewest workgroup-layers x outputs per
                 //  workgroup on the 256 CUs — 48000 -> 44101 stereo 60 s: 60 per interval are 346 workgroups, two layers
                 //  of which the second is a third full; 41 per interval are 506)
-                double best_cost = 1e300;
-                const double cols_ = (double)j.n_clips * j.n_channels;
-                for (int per = 64; per >= 15; --per) {
-                    const int64_t k = (int64_t)per * p->phases;
-                    if (k > 16384 || k > nf) continue;
-                    const int64_t sc = (int64_t)std::ceil((double)k * step) + p->T + 8;
-                    const int64_t bytes = sc * (int64_t)sizeof(Real) + k * 2 + (2 * p->phases + 2) * 4 + 64;
-                    if (bytes > 150 * 1024) continue;
-                    const double wgs_ = std::ceil((double)nf / (double)k) * cols_;
-                    const double cost = std::ceil(wgs_ / 256.) * (double)k * (per >= 30 ? 1. : 30. / per); // (thin buckets: idle lanes)
-                    if (cost < best_cost) { best_cost = cost; KO = k; span_cap = sc; }
+                // two outputs per lane (InterpTileArgs): neighbouring channels of an even channel count, else — constant rate —
+                // the column's own second half, split h periods of L outputs in when that half has >= 0.7 of the first's outputs
+                // — taken when the launch's workgroup layers x outputs per workgroup come out cheaper than with one output
+                // per lane (a pair workgroup takes ~1.7x a single one: 60 s stereo 393 -> 348 us, 8 channels 1622 -> 1120,
+                // mono 232 -> 190; a 10 s stereo job has too few workgroups to halve them)
+                constexpr double kPairWg = 1.7;
+                int cand_mode = 0;
+                int64_t cand_h = 0, cand_nf = nf;
+                if (!switches().no_interp_pair) {
+                    if (j.n_channels % 2 == 0) cand_mode = 1;
+                    else if (!vr) {
+                        const int64_t h = (nf + 2 * p->L - 1) / (2 * p->L), n1 = h * p->L;
+                        if (h >= 1 && n1 < nf && 10 * (nf - n1) >= 7 * n1 && h * p->M < ((int64_t)1 << 40)) { cand_mode = 2; cand_h = h; cand_nf = n1; }
+                    }
+                }
+                double best_cost = 1e300, cols_ = (double)j.n_clips * j.n_channels;
+                for (int mode : {0, cand_mode}) {
+                    if (mode == 0 && cand_mode && switches().dbg_interp_pair_always) continue;
+                    const int nm = mode ? 2 : 1;
+                    const int64_t nft = mode == 2 ? cand_nf : nf;
+                    const double cols_m = (double)j.n_clips * j.n_channels / (mode == 1 ? 2 : 1);
+                    for (int per = 64; per >= 15; --per) {
+                        const int64_t k = (int64_t)per * p->phases;
+                        if (k > 16384 || k > nft) continue;
+                        const int64_t sc = (int64_t)std::ceil((double)k * step) + p->T + 8;
+                        const int64_t bytes = sc * nm * (int64_t)sizeof(Real) + k * 2 + (2 * p->phases + 2) * 4 + 64;
+                        if (bytes > 150 * 1024) continue;
+                        const double wgs_ = std::ceil((double)nft / (double)k) * cols_m;
+                        const double cost = std::ceil(wgs_ / 256.) * (double)k * (per >= 30 ? 1. : 30. / per) * (mode ? kPairWg : 1.); // (thin buckets: idle lanes)
+                        if (cost < best_cost) { best_cost = cost; KO = k; span_cap = sc; pair_mode = mode; split_h = mode == 2 ? cand_h : 0; nf_t = nft; cols_ = cols_m; }
+                    }
+                    if (!cand_mode) break;
                 }
                 // ... which pays off once the launch fills the chip.  A workgroup of it is long (KO outputs x T taps one
                 // interval at a time: ~130 us at VHQ, 1.5 ms with the variable-rate clock), so a launch of a few of them
@@ -2738,9 +2788,9 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 // 96 000-frame variable-rate chunk 1.5 ms -> 0.1 ms on k_interp; 10 s stereo constant rate 134 us on
                 // the tile kernel (503 on k_interp); 1 s stereo 75 us on k_interp (127 on the tile kernel).
                 if (KO) {
-                    const double cols = (double)j.n_clips * j.n_channels, wgs = (double)((nf + KO - 1) / KO) * cols;
-                    const double t_tile = std::ceil(wgs / 256.) * (double)KO * p->T * (vr ? 2.9e-4 : 6.3e-5);
-                    const double t_lane = (wave_ok ? kWaveUsPerTap : 2.5e-6) * (double)nf * cols * p->T;
+                    const double wgs = (double)((nf_t + KO - 1) / KO) * cols_;
+                    const double t_tile = std::ceil(wgs / 256.) * (double)KO * p->T * (vr ? 2.9e-4 : 6.3e-5) * (pair_mode ? kPairWg : 1.);
+                    const double t_lane = (wave_ok ? kWaveUsPerTap : 2.5e-6) * (double)nf * ((double)j.n_clips * j.n_channels) * p->T;
                     if (t_lane < t_tile) KO = 0;
                 }
             }
@@ -2773,9 +2823,17 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     ta.ia.s_hi = (uint64_t)(S1 >> 64); ta.ia.s_lo = (uint64_t)S1;
                     ta.ia.d_hi = vr->d_hi; ta.ia.d_lo = vr->d_lo;
                 }
-                const size_t lds = (size_t)ta.span_cap * sizeof(Real) + (size_t)KO * 2 + (size_t)(2 * p->phases + 2) * 4 + 64;
-                const dim3 tgrid((unsigned)((nf + KO - 1) / KO), (unsigned)((uint64_t)j.n_clips * j.n_channels), 1);
-                void (*tk)(InterpTileArgs) = vr ? k_interp_tile<IO, Real, true> : k_interp_tile<IO, Real, false>;
+                ta.cols_per_clip = pair_mode == 1 ? j.n_channels / 2 : j.n_channels; ta.ch_step = pair_mode == 1 ? 2 : 1;
+                ta.m2_in = ta.m2_out = ta.m2_l = ta.m2_k = 0; ta.m2_n = nf; ta.m2_dch = 0;
+                if (pair_mode == 1) { ta.m2_in = j.in_chan_stride; ta.m2_out = j.out_chan_stride; ta.m2_dch = 1; }
+                if (pair_mode == 2) {
+                    ta.m2_l = split_h * p->M; ta.m2_k = split_h * p->L; ta.m2_in = ta.m2_l * j.in_frame_stride; ta.m2_out = ta.m2_k * j.out_frame_stride;
+                    ta.m2_n = nf - nf_t; ta.ia.g.out_frames = nf_t;
+                }
+                const size_t lds = (size_t)ta.span_cap * (pair_mode ? 2 : 1) * sizeof(Real) + (size_t)KO * 2 + (size_t)(2 * p->phases + 2) * 4 + 64;
+                const dim3 tgrid((unsigned)((nf_t + KO - 1) / KO), (unsigned)((uint64_t)j.n_clips * ta.cols_per_clip), 1);
+                void (*tk)(InterpTileArgs) = pair_mode ? (vr ? k_interp_tile<IO, Real, true, true> : k_interp_tile<IO, Real, false, true>)
+                                                       : (vr ? k_interp_tile<IO, Real, true, false> : k_interp_tile<IO, Real, false, false>);
                 if (const char *e = ensure_dyn_lds((const void *)tk, lds)) return e;
                 hipLaunchKernelGGL(tk, tgrid, dim3(1024), lds, st, ta);
                 HIP_TRY(hipGetLastError());
