@@ -64,5 +64,15 @@ xl = torch.from_numpy((rng.standard_normal((40, 200000, 1)) * 0.25).astype(np.fl
 yl = dev.resample_tensor(plan, xl)
 out["fft_large_sha"] = sha(yl.cpu().numpy())
 out["fft_large"] = rel(yl[3, :, 0].cpu().numpy(), dev.resample_tensor(plan, xl[3, :, 0].contiguous(), kernel=dev.KERNEL_EXACT).cpu().numpy())
+# interpolated-phase plans at the tile kernel's sizes (round 5: two outputs per lane — channel pairs / a column's two halves):
+# canonical order, so bit for bit whatever serves them; and the two-stage form (AUTO) within 1e-6 of it
+plan3 = dev.Plan(48000, 44101, "VHQ")
+xt = torch.from_numpy((rng.standard_normal((300000, 3)) * 0.25).astype(np.float32)).cuda()
+e1 = dev.resample_tensor(plan3, xt[:, 0].contiguous(), kernel=dev.KERNEL_EXACT)
+e2 = dev.resample_tensor(plan3, xt[:, :2].contiguous(), kernel=dev.KERNEL_EXACT)
+e3 = dev.resample_tensor(plan3, (xt * 20000).to(torch.int16), kernel=dev.KERNEL_EXACT, dither=True)
+out["dev_interp_tile"] = sha(e1.cpu().numpy()) + sha(e2.cpu().numpy()) + sha(e3.cpu().numpy())
+out["two_stage_mono"] = rel(dev.resample_tensor(plan3, xt[:, 0].contiguous()).cpu().numpy(), e1.cpu().numpy())
+out["two_stage_2ch"] = rel(dev.resample_tensor(plan3, xt[:, :2].contiguous()).cpu().numpy(), e2.cpu().numpy())
 torch.cuda.synchronize()
 print("SWITCH_PROBE " + json.dumps(out))

@@ -17,9 +17,10 @@ SWITCHES = ["HIPSOXR_NO_FFT", "HIPSOXR_FFT_NO_PAIR", "HIPSOXR_FFT_NO_CHPAIR", "H
             "HIPSOXR_FFT_LARGE_ONLY", "HIPSOXR_FFT_SMALL_ONLY", "HIPSOXR_FFT_NO_TINY",
             "HIPSOXR_NO_PLANES", "HIPSOXR_NO_HOST_RING", "HIPSOXR_NO_CHAIN",
             "HIPSOXR_NO_DONE_WORDS", "HIPSOXR_RESIDENT", "HIPSOXR_AUTO_RESIDENT", "HIPSOXR_RESIDENT_NO_BAR", "HIPSOXR_NO_XCD_SPLIT", "HIPSOXR_NO_TILE_SPLIT",
-            "HIPSOXR_NO_INTERP_TILE", "HIPSOXR_NO_INTERP_WAVE", "HIPSOXR_NO_GATHER_WAVE"]
+            "HIPSOXR_NO_INTERP_TILE", "HIPSOXR_NO_INTERP_WAVE", "HIPSOXR_NO_GATHER_WAVE",
+            "HIPSOXR_NO_INTERP_PAIR", "HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS", "HIPSOXR_POLY_NO_PAIR", "HIPSOXR_NO_TWO_STAGE"]
 EXACT_KEYS = ["host_f32", "host_i16", "host_interp", "host_interp_2ch", "stream_vr", "stream_20000", "dev_gather", "stream", "stream_resident", "stream_deferred", "dev_exact", "dev_exact_f64",
-              "dev_exact_8ch"]
+              "dev_exact_8ch", "dev_interp_tile"]
 
 
 def _probe(env_extra):
@@ -37,7 +38,7 @@ def _probe(env_extra):
 def baseline():
     b = _probe({})
     assert b["stream"] == b["stream_resident"] == b["stream_deferred"]      # the three stream modes agree to begin with
-    for k in ("fft_batch", "fft_8ch", "fft_large"):
+    for k in ("fft_batch", "fft_8ch", "fft_large", "two_stage_mono", "two_stage_2ch"):
         assert 0 < b[k] <= 1e-6, (k, b[k])
     return b
 
@@ -53,6 +54,12 @@ def test_switch_does_not_change_results(baseline, switch):
             assert got[k] == 0.0, (switch, k)          # AUTO stays on the exact engine
         else:
             assert 0 < got[k] <= 1e-6, (switch, k, got[k])
+    for k in ("two_stage_mono", "two_stage_2ch"):       # the two-stage form (its polyphase stage on pairs or not) stays in its class
+        if switch in ("HIPSOXR_NO_FFT", "HIPSOXR_NO_TWO_STAGE"):
+            assert got[k] == 0.0, (switch, k)
+        else:                                            # (0: a switch took the FFT stage's kernel away and AUTO fell back to the exact engine)
+            assert got[k] <= 1e-6, (switch, k, got[k])
+            assert got[k] > 0 or switch.startswith("HIPSOXR_FFT_"), (switch, k)
     # switches that only re-route the SAME transform chain of the large unit-stride job leave it bit-identical
     if switch in ("HIPSOXR_FFT_NO_CHPAIR", "HIPSOXR_FFT_NO_XCD_MAP",
                   "HIPSOXR_NO_PLANES", "HIPSOXR_NO_CHAIN", "HIPSOXR_RESIDENT", "HIPSOXR_FFT_LARGE_ONLY", "HIPSOXR_FFT_NO_TINY"):
