@@ -22,7 +22,7 @@ WORKLOADS = {  # name -> (kernel-name substring, grid predicate, algorithmic byt
     "arith_f64": ("double, float>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
     "exact_engine": ("k_tile_mfma_p<float>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
     # the two kernels of the arbitrary-ratio job (48000 -> 44101 stereo 60 s): bytes each kernel has to move
-    "two_stage_poly": ("k_poly<float, 16, 0>", lambda gx, gy: True, 4 * 2 * (2880000 + 2 * 2646060)),
+    "two_stage_poly": ("k_poly2<16, 0, true>", lambda gx, gy: True, 4 * 2 * (2880000 + 2 * 2646060)),
     "two_stage_fft": ("k_fft_strided2<hipsoxr::PairSpec<4096, 2048", lambda gx, gy: True, 4 * 2 * (2 * 2646060 + 2646060)),
 }
 
