@@ -930,7 +930,12 @@ def main():
                                          "launch_us": k3 * 1e6, "kernel": "two-stage: k_poly2<T2, MQ> (interleaved channel pair per pass) + k_fft (2:1), two launches (csrc/twostage.hip)",
                                          "value": x3.numel() / k3 / 1e6, "unit": "Msamples/s", "hbm_frac": bytes3 / k3 / 1e9 / HBM_PEAK_GBS,
                                          "exact_engine_launch_us": k3e * 1e6, "speedup_over_exact": k3e / k3}
-            del x3, y3, plan3
+            # ... and the same ratio mono (round 5: the column's two halves run as the pair of k_poly2 / of k_interp_tile's lanes)
+            x3m = x3[:, 0].contiguous()
+            _, k3m, _ = time_workload(plan3, x3m, max(5, args.steps // 10), 2, world, device, 0, windows=10)
+            _, k3me, _ = time_workload(plan3, x3m, 5, 2, world, device, 6, windows=4)
+            result["arbitrary_ratio"].update({"mono_launch_us": k3m * 1e6, "mono_exact_engine_launch_us": k3me * 1e6})
+            del x3, x3m, y3, plan3
         except RuntimeError as e:  # context only
             result["arbitrary_ratio"] = {"error": str(e)}
 
