@@ -44,6 +44,27 @@ def test_tensor_stream_equals_oneshot_and_host_stream(soxr, dtype, rates, qualit
     assert np.array_equal(again, got)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.int16])
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_tensor_stream_large_chunks_of_an_irrational_ratio(soxr, dtype, ch):
+    """Round 5: calls large enough for the interpolated-phase tile kernel, whose lanes carry two outputs (the neighbouring
+    channel, or the column's second half a whole number of periods on — here 180 000-frame calls are 3.75 periods of 44101
+    outputs).  Stream position, ring start and dither context differ from call to call; the frames must still be the
+    one-shot's, bit for bit (reference contract tests/test_resample.py:105-116)."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(5 + ch)
+    n = 400000
+    x = _sig(rng, (n, ch) if ch > 1 else (n,), dtype)
+    want = soxr.resample(x, 48000, 44101, quality="VHQ")
+    xd = torch.from_numpy(x).cuda()
+    ts = dev.TensorStream(48000, 44101, ch, dtype=xd.dtype, quality="VHQ")
+    cuts = [0, 180000, 360000, 360017, n]
+    got = [ts.resample_chunk(xd[a:b], last=(b == n)).cpu().numpy() for a, b in zip(cuts[:-1], cuts[1:])]
+    got = np.concatenate(got)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_tensor_stream_long_run_retires_input(soxr):
     """Thousands of small calls: the device ring is compacted, never grows without bound, and the result is the
     one-shot result."""
