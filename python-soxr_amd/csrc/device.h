@@ -118,6 +118,7 @@ struct Switches {
     size_t dbg_fft_lds = 0;       // HIPSOXR_DEBUG_FFT_LDS    the same for the frequency-domain kernels
     int dbg_poly_r = 0;           // HIPSOXR_DEBUG_POLY_R     k_poly: force the outputs per thread and tile
     bool no_interp_pair = false;  // HIPSOXR_NO_INTERP_PAIR   k_interp_tile: one output per lane (A/B)
+    bool dbg_interp_no_twin = false;     // HIPSOXR_DEBUG_INTERP_NO_TWIN      ... float pairs on ONE copy of the staged span (8-byte reads) always (A/B, tests)
     bool dbg_interp_pair_always = false; // HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS  ... two per lane wherever a pair exists, whatever the cost model says (tests)
     bool poly_no_pair = false;    // HIPSOXR_POLY_NO_PAIR     interleaved channel pairs on k_poly (one channel per pass) instead of k_poly2 (A/B)
     int dbg_tile_form = 0;        // HIPSOXR_DEBUG_TILE_FORM  k_tile_mfma_p: force launch form 1..4 (slab 64 whole / 64 split / 32 whole / 32 split)

@@ -81,7 +81,7 @@ const Switches &switches()
         w.dbg_slab32 = on("HIPSOXR_DEBUG_SLAB32"); w.no_halves = on("HIPSOXR_DEBUG_NO_HALVES"); w.dbg_pad = on("HIPSOXR_DEBUG_PAD");
         w.dbg_slab64 = on("HIPSOXR_DEBUG_SLAB64"); w.dbg_mfma64_pb = num("HIPSOXR_DEBUG_MFMA64_PB"); w.dbg_mfma64_split = on("HIPSOXR_DEBUG_MFMA64_SPLIT");
         w.dbg_mfma64_lds = (size_t)num("HIPSOXR_DEBUG_MFMA64_LDS"); w.dbg_fft_lds = (size_t)num("HIPSOXR_DEBUG_FFT_LDS");
-        w.dbg_tile_form = num("HIPSOXR_DEBUG_TILE_FORM"); w.dbg_poly_r = num("HIPSOXR_DEBUG_POLY_R"); w.no_interp_pair = on("HIPSOXR_NO_INTERP_PAIR"); w.dbg_interp_pair_always = on("HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS"); w.poly_no_pair = on("HIPSOXR_POLY_NO_PAIR"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
+        w.dbg_tile_form = num("HIPSOXR_DEBUG_TILE_FORM"); w.dbg_poly_r = num("HIPSOXR_DEBUG_POLY_R"); w.no_interp_pair = on("HIPSOXR_NO_INTERP_PAIR"); w.dbg_interp_pair_always = on("HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS"); w.dbg_interp_no_twin = on("HIPSOXR_DEBUG_INTERP_NO_TWIN"); w.poly_no_pair = on("HIPSOXR_POLY_NO_PAIR"); w.dbg_trace = getenv("HIPSOXR_DEBUG_TRACE");
 #endif
         return w;
     }();
@@ -731,9 +731,10 @@ __global__ void __launch_bounds__(256) k_interp_wave(InterpWaveArgs wa)
     }
 }
 
-template <typename IO, typename Real, bool VR, bool PAIR>
+template <typename IO, typename Real, bool VR, bool PAIR, bool TWIN = false>
 __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
 {
+    static_assert(!TWIN || (PAIR && sizeof(Real) == 4), "TWIN: float pairs only");
     constexpr int NM = PAIR ? 2 : 1; // members per lane; the staged span is [sample][member]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const InterpArgs &ia = ta.ia;
@@ -750,7 +751,12 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     //  cubic records, 4.8 KB, through the scalar cache, which it misses — 423 MB per launch, ~6 bytes per cycle per scalar
     //  cache.  Coefficient delivery is the bound; requesting a block ahead (one block is all the SGPRs hold) was slower.)
     Real *xs = reinterpret_cast<Real *>(smem_raw);                       // [span_cap][NM]
-    uint16_t *order = reinterpret_cast<uint16_t *>(xs + (size_t)ta.span_cap * NM); // [KO]  outputs sorted by interval
+    // float pairs: the span TWICE, the second copy one sample further on — a lane reads the copy in which its window starts
+    // 16-byte aligned, two taps x two members per ds_read_b128 (256 B/clk) instead of one tap per half of a ds_read2_b64 (128)
+    // (TWIN; where two copies leave too few outputs per workgroup — long steps, long filters — the pair runs on one)
+    constexpr int NCOPY = TWIN ? 2 : 1;
+    Real *xsB = xs + (size_t)(ta.span_cap + 2) * NM; // (span_cap is even: 16-byte aligned)
+    uint16_t *order = reinterpret_cast<uint16_t *>(xs + (size_t)(NCOPY == 2 ? 2 * (ta.span_cap + 2) : ta.span_cap) * NM); // [KO]  outputs sorted by interval
     uint32_t *off = reinterpret_cast<uint32_t *>(order + ((KO + 1) & ~1)); // [P + 1] bucket offsets
     uint32_t *cur = off + (P + 1);                                       // [P]     scatter cursors
 
@@ -790,8 +796,13 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
     // 2. stage the input span (zero outside the signal), converted to the engine precision
     for (int m = threadIdx.x; m < span; m += blockDim.x) {
         const int64_t l = n_first + m - a.in_abs0;
-        xs[NM * m] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-        if constexpr (PAIR) xs[NM * m + 1] = (l + ta.m2_l >= 0 && l + ta.m2_l < a.in_frames) ? (Real)xin[ta.m2_in + l * a.ifs] : (Real)0;
+        const Real v1 = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
+        xs[NM * m] = v1;
+        if constexpr (PAIR) {
+            const Real v2 = (l + ta.m2_l >= 0 && l + ta.m2_l < a.in_frames) ? (Real)xin[ta.m2_in + l * a.ifs] : (Real)0;
+            xs[NM * m + 1] = v2;
+            if constexpr (NCOPY == 2) { xsB[NM * (m + 1)] = v1; xsB[NM * (m + 1) + 1] = v2; }
+        }
     }
     __syncthreads();
     if (threadIdx.x < 64) { // inclusive scan of off[1..P] (P <= 256 = 64 lanes x 4) by the first wave
@@ -846,7 +857,8 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
             const bool live = key != 0xFFFFu;
             const int i = live ? (int)key : (int)order[b0];
             const InterpPos<Real> rc = locate(i);
-            const Real *xl = xs + NM * (uint32_t)(rc.n0 - n_first);
+            const uint32_t m_first = (uint32_t)(rc.n0 - n_first);
+            const Real *xl = (NCOPY == 2 && (m_first & 1)) ? xsB + NM * (m_first + 1) : xs + NM * m_first;
             const Real xx = (Real)(uint32_t)rc.xq * (Real)(1. / (double)(1ULL << SH));
             Real accL = 0, accR = 0, accL2 = 0, accR2 = 0;
             // (one tap: the canonical cubic, then each member's own chain FMA)
@@ -856,17 +868,29 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
 #define HIPSOXR_ITILE_TAP(c0, c1, c2, c3, t, L, L2)                                   \
     {                                                                                \
         const Real cj = fma_r(fma_r(fma_r(c3, xx, c2), xx, c1), xx, c0);             \
-        if constexpr (PAIR) {                                                        \
+        if constexpr (NCOPY == 2) {                                                  \
+            L = fma_r(cj, xq[(t) >> 1][2 * ((t) & 1)], L);                           \
+            L2 = fma_r(cj, xq[(t) >> 1][2 * ((t) & 1) + 1], L2);                     \
+        } else if constexpr (PAIR) {                                                 \
             const RealX2 xv = reinterpret_cast<const RealX2 *>(x4)[t];               \
             L = fma_r(cj, xv.x, L);                                                  \
             L2 = fma_r(cj, xv.y, L2);                                                \
         } else                                                                       \
             L = fma_r(cj, x4[t], L);                                                 \
     }
+            typedef Real RealX4 __attribute__((ext_vector_type(4)));
+#define HIPSOXR_ITILE_QUADS                                                                                              \
+    RealX4 xq[2];                                                                                                        \
+    if constexpr (NCOPY == 2) {                                                                                          \
+        xq[0] = *reinterpret_cast<const RealX4 *>(__builtin_assume_aligned(x4, 16));                                     \
+        xq[1] = *reinterpret_cast<const RealX4 *>(__builtin_assume_aligned(x4 + 4, 16));                                 \
+    }                                                                                                                    \
+    (void)xq;
 #pragma unroll 2
             for (int b = 0; b < H / 4; ++b) { // T is a multiple of 8: H is a multiple of 4
                 const RealX16 c = row[b];
                 const Real *x4 = xl + NM * 4 * b;
+                HIPSOXR_ITILE_QUADS
                 HIPSOXR_ITILE_TAP(c[0], c[1], c[2], c[3], 0, accL, accL2)
                 HIPSOXR_ITILE_TAP(c[4], c[5], c[6], c[7], 1, accL, accL2)
                 HIPSOXR_ITILE_TAP(c[8], c[9], c[10], c[11], 2, accL, accL2)
@@ -876,12 +900,14 @@ __global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
             for (int b = T / 4 - 1; b >= H / 4; --b) { // descending taps
                 const RealX16 c = row[b];
                 const Real *x4 = xl + NM * 4 * b;
+                HIPSOXR_ITILE_QUADS
                 HIPSOXR_ITILE_TAP(c[12], c[13], c[14], c[15], 3, accR, accR2)
                 HIPSOXR_ITILE_TAP(c[8], c[9], c[10], c[11], 2, accR, accR2)
                 HIPSOXR_ITILE_TAP(c[4], c[5], c[6], c[7], 1, accR, accR2)
                 HIPSOXR_ITILE_TAP(c[0], c[1], c[2], c[3], 0, accR, accR2)
             }
 #undef HIPSOXR_ITILE_TAP
+#undef HIPSOXR_ITILE_QUADS
             if (live) {
                 const int64_t idx = o_base + i;
                 store_out<Real>(yo + idx * a.ofs, accL + accR, a.oc, ch, a.out_k0 + idx);
@@ -2722,6 +2748,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
             const bool no_itile = switches().no_interp_tile;
             int64_t KO = 0, span_cap = 0;
             int pair_mode = 0;          // k_interp_tile: 0 one output per lane, 1 channel pairs, 2 the column's two halves
+            bool twin = false;          // ... pairs with the span staged twice (float: 16-byte aligned reads)
             int64_t split_h = 0, nf_t = nf; // (outputs the tiles are counted over: member 1's)
             // position of this launch's first output on the variable-rate clock: (T0, S0) advanced by `done` outputs
             auto vr_advance = [&](InterpArgs &x) {
@@ -2753,7 +2780,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 // — taken when the launch's workgroup layers x outputs per workgroup come out cheaper than with one output
                 // per lane (a pair workgroup takes ~1.7x a single one: 60 s stereo 393 -> 348 us, 8 channels 1622 -> 1120,
                 // mono 232 -> 190; a 10 s stereo job has too few workgroups to halve them)
-                constexpr double kPairWg = 1.7;
+                constexpr double kPairWg = 1.7, kTwinWg = 1.4; // (... 1.4 with the span staged twice for 16-byte reads: stereo 348 -> 296, mono 190 -> 145)
                 int cand_mode = 0;
                 int64_t cand_h = 0, cand_nf = nf;
                 if (!switches().no_interp_pair) {
@@ -2769,16 +2796,17 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     const int nm = mode ? 2 : 1;
                     const int64_t nft = mode == 2 ? cand_nf : nf;
                     const double cols_m = (double)j.n_clips * j.n_channels / (mode == 1 ? 2 : 1);
-                    for (int per = 64; per >= 15; --per) {
-                        const int64_t k = (int64_t)per * p->phases;
-                        if (k > 16384 || k > nft) continue;
-                        const int64_t sc = (int64_t)std::ceil((double)k * step) + p->T + 8;
-                        const int64_t bytes = sc * nm * (int64_t)sizeof(Real) + k * 2 + (2 * p->phases + 2) * 4 + 64;
-                        if (bytes > 150 * 1024) continue;
-                        const double wgs_ = std::ceil((double)nft / (double)k) * cols_m;
-                        const double cost = std::ceil(wgs_ / 256.) * (double)k * (per >= 30 ? 1. : 30. / per) * (mode ? kPairWg : 1.); // (thin buckets: idle lanes)
-                        if (cost < best_cost) { best_cost = cost; KO = k; span_cap = sc; pair_mode = mode; split_h = mode == 2 ? cand_h : 0; nf_t = nft; cols_ = cols_m; }
-                    }
+                    for (int tw = 0; tw <= (mode && sizeof(Real) == 4 && !switches().dbg_interp_no_twin ? 1 : 0); ++tw) // float pairs: one or two copies of the span
+                        for (int per = 64; per >= 15; --per) {
+                            const int64_t k = (int64_t)per * p->phases;
+                            if (k > 16384 || k > nft) continue;
+                            const int64_t sc = (int64_t)std::ceil((double)k * step) + p->T + 8;
+                            const int64_t bytes = (tw ? 2 * (sc + 4) : sc) * nm * (int64_t)sizeof(Real) + k * 2 + (2 * p->phases + 2) * 4 + 64;
+                            if (bytes > 150 * 1024) continue;
+                            const double wgs_ = std::ceil((double)nft / (double)k) * cols_m;
+                            const double cost = std::ceil(wgs_ / 256.) * (double)k * (per >= 30 ? 1. : 30. / per) * (tw ? kTwinWg : mode ? kPairWg : 1.); // (thin buckets: idle lanes)
+                            if (cost < best_cost) { best_cost = cost; KO = k; span_cap = sc; pair_mode = mode; twin = tw != 0; split_h = mode == 2 ? cand_h : 0; nf_t = nft; cols_ = cols_m; }
+                        }
                     if (!cand_mode) break;
                 }
                 // ... which pays off once the launch fills the chip.  A workgroup of it is long (KO outputs x T taps one
@@ -2789,7 +2817,7 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                 // the tile kernel (503 on k_interp); 1 s stereo 75 us on k_interp (127 on the tile kernel).
                 if (KO) {
                     const double wgs = (double)((nf_t + KO - 1) / KO) * cols_;
-                    const double t_tile = std::ceil(wgs / 256.) * (double)KO * p->T * (vr ? 2.9e-4 : 6.3e-5) * (pair_mode ? kPairWg : 1.);
+                    const double t_tile = std::ceil(wgs / 256.) * (double)KO * p->T * (vr ? 2.9e-4 : 6.3e-5) * (twin ? kTwinWg : pair_mode ? kPairWg : 1.);
                     const double t_lane = (wave_ok ? kWaveUsPerTap : 2.5e-6) * (double)nf * ((double)j.n_clips * j.n_channels) * p->T;
                     if (t_lane < t_tile) KO = 0;
                 }
@@ -2830,10 +2858,12 @@ static const char *launch_gather(Plan *p, const hipsoxr_job_t &j, hipStream_t st
                     ta.m2_l = split_h * p->M; ta.m2_k = split_h * p->L; ta.m2_in = ta.m2_l * j.in_frame_stride; ta.m2_out = ta.m2_k * j.out_frame_stride;
                     ta.m2_n = nf - nf_t; ta.ia.g.out_frames = nf_t;
                 }
-                const size_t lds = (size_t)ta.span_cap * (pair_mode ? 2 : 1) * sizeof(Real) + (size_t)KO * 2 + (size_t)(2 * p->phases + 2) * 4 + 64;
+                const size_t lds = (size_t)(twin ? 2 * (ta.span_cap + 2) : ta.span_cap) * (pair_mode ? 2 : 1) * sizeof(Real) + (size_t)KO * 2 + (size_t)(2 * p->phases + 2) * 4 + 64;
                 const dim3 tgrid((unsigned)((nf_t + KO - 1) / KO), (unsigned)((uint64_t)j.n_clips * ta.cols_per_clip), 1);
                 void (*tk)(InterpTileArgs) = pair_mode ? (vr ? k_interp_tile<IO, Real, true, true> : k_interp_tile<IO, Real, false, true>)
                                                        : (vr ? k_interp_tile<IO, Real, true, false> : k_interp_tile<IO, Real, false, false>);
+                if constexpr (sizeof(Real) == 4)
+                    if (twin) tk = vr ? k_interp_tile<IO, Real, true, true, true> : k_interp_tile<IO, Real, false, true, true>;
                 if (const char *e = ensure_dyn_lds((const void *)tk, lds)) return e;
                 hipLaunchKernelGGL(tk, tgrid, dim3(1024), lds, st, ta);
                 HIP_TRY(hipGetLastError());

@@ -18,7 +18,7 @@ SWITCHES = ["HIPSOXR_NO_FFT", "HIPSOXR_FFT_NO_PAIR", "HIPSOXR_FFT_NO_CHPAIR", "H
             "HIPSOXR_NO_PLANES", "HIPSOXR_NO_HOST_RING", "HIPSOXR_NO_CHAIN",
             "HIPSOXR_NO_DONE_WORDS", "HIPSOXR_RESIDENT", "HIPSOXR_AUTO_RESIDENT", "HIPSOXR_RESIDENT_NO_BAR", "HIPSOXR_NO_XCD_SPLIT", "HIPSOXR_NO_TILE_SPLIT",
             "HIPSOXR_NO_INTERP_TILE", "HIPSOXR_NO_INTERP_WAVE", "HIPSOXR_NO_GATHER_WAVE",
-            "HIPSOXR_NO_INTERP_PAIR", "HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS", "HIPSOXR_POLY_NO_PAIR", "HIPSOXR_NO_TWO_STAGE"]
+            "HIPSOXR_NO_INTERP_PAIR", "HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS", "HIPSOXR_DEBUG_INTERP_NO_TWIN", "HIPSOXR_POLY_NO_PAIR", "HIPSOXR_NO_TWO_STAGE"]
 EXACT_KEYS = ["host_f32", "host_i16", "host_interp", "host_interp_2ch", "stream_vr", "stream_20000", "dev_gather", "stream", "stream_resident", "stream_deferred", "dev_exact", "dev_exact_f64",
               "dev_exact_8ch", "dev_interp_tile"]
 

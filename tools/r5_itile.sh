@@ -33,17 +33,21 @@ open("/tmp/itile_cmp.py", "w").write(code)
 env = dict(os.environ)
 env["HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS"] = "1"   # (also where the cost model would keep one output per lane)
 subprocess.check_call([sys.executable, "/tmp/itile_cmp.py", "/tmp/itile_pair.pkl"], env=env)
-del env["HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS"]
+env["HIPSOXR_DEBUG_INTERP_NO_TWIN"] = "1"       # (float pairs on one copy of the span)
+subprocess.check_call([sys.executable, "/tmp/itile_cmp.py", "/tmp/itile_pair1.pkl"], env=env)
+del env["HIPSOXR_DEBUG_INTERP_PAIR_ALWAYS"], env["HIPSOXR_DEBUG_INTERP_NO_TWIN"]
 env["HIPSOXR_NO_INTERP_PAIR"] = "1"
 subprocess.check_call([sys.executable, "/tmp/itile_cmp.py", "/tmp/itile_single.pkl"], env=env)
 import torch
-A, B = pickle.load(open("/tmp/itile_pair.pkl", "rb")), pickle.load(open("/tmp/itile_single.pkl", "rb"))
-bad = [k for k in A if not torch.equal(A[k], B[k])]
-print("pair vs single: %d cases, %d differ" % (len(A), len(bad)), bad[:5])
+A, A1, B = pickle.load(open("/tmp/itile_pair.pkl", "rb")), pickle.load(open("/tmp/itile_pair1.pkl", "rb")), pickle.load(open("/tmp/itile_single.pkl", "rb"))
+bad = [k for k in A if not (torch.equal(A[k], B[k]) and torch.equal(A1[k], B[k]))]
+print("pair (two copies / one copy of the span) vs single: %d cases, %d differ" % (len(A), len(bad)), bad[:5])
 PY
 for rep in 1 2; do
-for v in pair single; do
-  if [ $v = single ]; then export HIPSOXR_NO_INTERP_PAIR=1; else unset HIPSOXR_NO_INTERP_PAIR; fi
+for v in pair pair1 single; do
+  unset HIPSOXR_NO_INTERP_PAIR HIPSOXR_DEBUG_INTERP_NO_TWIN
+  if [ $v = single ]; then export HIPSOXR_NO_INTERP_PAIR=1; fi
+  if [ $v = pair1 ]; then export HIPSOXR_DEBUG_INTERP_NO_TWIN=1; fi
   echo -n "[$v] "
   python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import sys
