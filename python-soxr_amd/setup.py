@@ -11,13 +11,28 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(HERE, "soxr_amd")
 INCLUDE = os.path.join(HERE, "..", "include")
 
+
+
+def header_version():
+    """The ONE version number: HIPSOXR_VERSION_STRING in include/hipsoxr.h (what hipsoxr_version() / soxr_version() report,
+    what soxr_amd.__version__ is derived from at import, and what the wheel and soxr.pc carry)."""
+    import re
+    with open(os.path.join(INCLUDE, "hipsoxr.h")) as f:
+        m = re.search(r'#define\s+HIPSOXR_VERSION_STRING\s+"([0-9][^"]*)"', f.read())
+    if not m:
+        raise RuntimeError("HIPSOXR_VERSION_STRING not found in include/hipsoxr.h")
+    return m.group(1)
+
+
+VERSION = header_version()
+
 PC = """prefix=${pcfiledir}/../..
 libdir=${prefix}/lib
 includedir=${prefix}/include
 
 Name: soxr
 Description: libsoxr-compatible ABI of the MI355X (gfx950) resampler (hipsoxr)
-Version: 0.1.3
+Version: @VERSION@
 Libs: -L${libdir} -lsoxr -Wl,-rpath,${libdir}
 Cflags: -I${includedir}
 """
@@ -46,13 +61,13 @@ class build_with_hip(build_py):
         for h in ("soxr.h", "hipsoxr.h"):
             shutil.copy2(os.path.join(INCLUDE, h), os.path.join(prefix, "include", h))
         with open(os.path.join(prefix, "lib", "pkgconfig", "soxr.pc"), "w") as f:
-            f.write(PC)
+            f.write(PC.replace("@VERSION@", VERSION))
         super().run()
 
 
 setup(
     name="soxr-amd",
-    version="0.2.0",
+    version=VERSION,
     description="MI355X (gfx950) implementation of python-soxr's resampling hot path: soxr.resample / "
                 "ResampleStream over hand-written HIP kernels",
     python_requires=">=3.9",

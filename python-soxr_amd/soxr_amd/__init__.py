@@ -17,9 +17,9 @@ import numpy as np
 from . import _native as _n
 from ._native import QQ, LQ, MQ, HQ, VHQ
 
-__version__ = "0.2.0"
 __libsoxr_version__ = _n.version()  # reference: soxr_ext.libsoxr_version(), src/soxr/__init__.py:18
-
+# one version number: the native library's (include/hipsoxr.h HIPSOXR_VERSION_STRING; setup.py gives the wheel the same)
+__version__ = __libsoxr_version__.split("-", 1)[-1].split(" ", 1)[0]   # "hipsoxr-0.6.0 (gfx950)" -> "0.6.0"
 
 
 def prefix():

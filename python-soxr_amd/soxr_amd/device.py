@@ -202,7 +202,7 @@ class TensorStream:
         # frames a constant-rate call can return at most: what the chunk adds plus what was pending before it
         self._slack = int((info.taps / 2 + 2) * self._ratio) + 4
         self._min_io = 1.0 / self._ratio  # (variable rate: the smallest io ratio requested so far bounds a call's output)
-        self._arena, self._arena_off, self._arena_ptr = None, 0, 0
+        self._arena, self._arena_off, self._arena_ptr, self._arena_stream = None, 0, 0, None
         self._esize = torch.empty(0, dtype=self.dtype).element_size()
 
     def __del__(self, _delete=_n.lib.hipsoxr_stream_delete):  # bound early: module globals may be gone at exit
@@ -255,10 +255,13 @@ class TensorStream:
         if not last and cap <= 4096 and x.ndim == 1:
             # small mono chunks (the 10 ms case): results are carved out of an arena of 64 calls' worth — one tensor op (the
             # final view) per call instead of an allocation and a slice; a full arena is simply dropped (views keep it alive)
+            # (an arena belongs to the HIP stream it was allocated on: a caller who moves to another stream gets a fresh one —
+            #  the caching allocator may otherwise hand a dropped arena back to the first stream while this one still writes it.
+            #  Results are VIEWS of the arena: keeping one 10 ms result alive keeps 64 calls' worth of HBM alive.)
             ar = self._arena
-            if ar is None or self._arena_off + cap > ar.shape[0] or ar.device != x.device:
+            if ar is None or self._arena_off + cap > ar.shape[0] or ar.device != x.device or self._arena_stream != stream:
                 ar = self._arena = torch.empty(64 * cap, dtype=self.dtype, device=x.device)
-                self._arena_off, self._arena_ptr = 0, ar.data_ptr()
+                self._arena_off, self._arena_ptr, self._arena_stream = 0, ar.data_ptr(), stream
             off = self._arena_off
             optr = self._arena_ptr + off * self._esize
             err = fn(self._h, x.data_ptr() if n else optr, n, optr, cap, self._done_ref, stream)
@@ -329,7 +332,9 @@ class TensorStreamGroup:
         cap = int(frames * self._ratio) + self._slack
         y = torch.empty((self.n, cap) + tuple(x.shape[2:]), dtype=self.dtype, device=x.device)
         row = self.channels * self._es
-        np.multiply(self._lane, np.uint64(frames * row), out=self._ins); self._ins += np.uint64(x.data_ptr())
+        # a zero-frame tick: an empty tensor's data_ptr() is 0, and a NULL input is the C entry's "end of input" — point at
+        # something non-null instead (nothing is read through it: ilens are 0), as TensorStream.resample_chunk does
+        np.multiply(self._lane, np.uint64(frames * row), out=self._ins); self._ins += np.uint64(x.data_ptr() if frames else y.data_ptr())
         np.multiply(self._lane, np.uint64(cap * row), out=self._outs); self._outs += np.uint64(y.data_ptr())
         self._ilens[:] = frames
         self._olens[:] = cap

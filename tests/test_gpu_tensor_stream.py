@@ -213,6 +213,35 @@ def test_stream_group_falls_back_where_one_launch_does_not_apply(soxr):
         assert np.array_equal(torch.cat(parts[i] + [tail]).cpu().numpy(), soxr.resample(sig[i], 44100, 16000, quality="VHQ"))
 
 
+def test_stream_group_zero_frame_tick_is_not_a_flush(soxr):
+    """A tick without input (x.shape[1] == 0: an empty device tensor's data_ptr() is NULL) must not be read as "end of input"
+    by the C entry: the streams stay open, later ticks go on, and the frames are those of streams that never saw the empty
+    tick (advisor, round 5).  The single-stream path is held to the same."""
+    import torch
+    from soxr_amd import device as dev
+    rng = np.random.default_rng(35)
+    n = 6
+    grp = dev.TensorStreamGroup(n, 44100, 16000, 1, dtype=torch.int16, quality="HQ", dither_seeds=list(range(n)))
+    solo = [dev.TensorStream(44100, 16000, 1, dtype=torch.int16, quality="HQ", dither_seed=i) for i in range(n)]
+    sig = torch.from_numpy(_sig(rng, (n, 441 * 6), np.int16)).cuda()
+    got = [[] for _ in range(n)]
+    for r in range(6):
+        if r in (0, 3):                                      # empty ticks: first call ever, and one in mid-stream
+            y, counts = grp.resample_chunks(sig[:, :0])
+            assert y.shape[0] == n and not any(s._ended for s in grp.streams)
+            for i in range(n):
+                got[i].append(y[i, :counts[i]])
+            e1 = grp.streams[1].resample_chunk(sig[1, :0])   # ... and the single-stream form of the same
+            assert e1.numel() == 0 and not grp.streams[1]._ended
+        y, counts = grp.resample_chunks(sig[:, r * 441:(r + 1) * 441])
+        for i in range(n):
+            got[i].append(y[i, :counts[i]])
+    for i in range(n):
+        tail = grp.streams[i].resample_chunk(sig[i, :0], last=True)
+        want = torch.cat([solo[i].resample_chunk(sig[i, r * 441:(r + 1) * 441], last=(r == 5)) for r in range(6)])
+        assert np.array_equal(torch.cat(got[i] + [tail]).cpu().numpy(), want.cpu().numpy()), i
+
+
 def test_streams_entry_through_the_c_abi_mixed_and_repeated_handles(soxr):
     """`hipsoxr_streams_process_device` called the way a C client would (pointer arrays; ragged chunk lengths per handle, one
     handle listed TWICE, one of another plan): handles the shared launch cannot take are processed one by one, in index order —

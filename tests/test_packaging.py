@@ -48,6 +48,22 @@ def test_wheel_installs_and_imports_without_the_source_tree(installed):
         assert os.path.exists(os.path.join(prefix, rel)), rel
 
 
+def test_one_version_number_everywhere(installed):
+    """include/hipsoxr.h's HIPSOXR_VERSION_STRING == the native library's report == soxr_amd.__version__ == the wheel's
+    metadata == soxr.pc (hygiene: three strings used to disagree)."""
+    import re
+    hdr = re.search(r'#define\s+HIPSOXR_VERSION_STRING\s+"([^"]+)"', open(os.path.join(ROOT, "include", "hipsoxr.h")).read()).group(1)
+    p = _py(installed, "import soxr_amd, importlib.metadata as md; print(soxr_amd.__version__); print(soxr_amd.__libsoxr_version__); "
+                       "print(md.version('soxr-amd'))")
+    assert p.returncode == 0, p.stderr
+    pyver, native, wheel = p.stdout.split("\n")[:3]
+    assert pyver == hdr and wheel == hdr and native == "hipsoxr-%s (gfx950)" % hdr, (hdr, pyver, native, wheel)
+    pc = open(os.path.join(installed, "soxr_amd", "prefix", "lib", "pkgconfig", "soxr.pc")).read()
+    assert "Version: %s\n" % hdr in pc
+    whl_dirs = [d for d in os.listdir(installed) if d.endswith(".dist-info")]
+    assert whl_dirs == ["soxr_amd-%s.dist-info" % hdr], whl_dirs
+
+
 @pytest.fixture(scope="module")
 def client(installed, tmp_path_factory):
     """tests/c/soxr_client.c built the way a libsoxr user would: header and library found below the
