@@ -39,8 +39,9 @@ FFTFLAGS="${HIPSOXR_FFTFLAGS:--ffp-contract=fast -fno-slp-vectorize}"
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=1 -c "$SRC/fft.hip" -o "$OBJ/fft1.o" & P6=$!
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -DFFT_PART=2 -c "$SRC/fft.hip" -o "$OBJ/fft2.o" & P7=$!
 "$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/twostage.hip" -o "$OBJ/twostage.o" & P9=$!
-wait $P1; wait $P2; wait $P3; wait $P4; wait $P5; wait $P6; wait $P7; wait $P9   # set -e: any failed compile aborts here
-OBJS="$OBJ/plan.o $OBJ/engine.o $OBJ/kernels.o $OBJ/fft.o $OBJ/fft1.o $OBJ/fft2.o $OBJ/twostage.o $OBJ/soxr_abi.o"
+"$HIPCC" $COMMON $FFTFLAGS ${HIPSOXR_EXTRA_FLAGS} -c "$SRC/fftwave.hip" -o "$OBJ/fftwave.o" & P10=$!
+wait $P1; wait $P2; wait $P3; wait $P4; wait $P5; wait $P6; wait $P7; wait $P9; wait $P10   # set -e: any failed compile aborts here
+OBJS="$OBJ/plan.o $OBJ/engine.o $OBJ/kernels.o $OBJ/fft.o $OBJ/fft1.o $OBJ/fft2.o $OBJ/twostage.o $OBJ/fftwave.o $OBJ/soxr_abi.o"
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT"
 # The same engine under libsoxr's name: what `find_library(SOXR_LIBRARY NAMES soxr)` of the
 # reference's USE_SYSTEM_LIBSOXR build picks up (reference CMakeLists.txt:83-93).

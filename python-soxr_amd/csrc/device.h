@@ -88,6 +88,9 @@ struct Switches {
     bool fft_large_only = false;  // HIPSOXR_FFT_LARGE_ONLY   never the small-block variant
     bool fft_small_only = false;  // HIPSOXR_FFT_SMALL_ONLY   always the small-block variant
     bool fft_no_tiny = false;     // HIPSOXR_FFT_NO_TINY      never the quarter-size blocks
+    bool fft_no_wave = false;     // HIPSOXR_FFT_NO_WAVE      never the one-wave-per-pair kernel (fftwave.hip)
+    int dbg_wave_min = 0;         // HIPSOXR_DEBUG_WAVE_MIN   ... from this many block pairs up (default 4096)
+    int dbg_wave_slots = 0;       // HIPSOXR_DEBUG_WAVE_SLOTS ... at most this many persistent waves per launch (default: what the chip holds)
     bool no_planes = false;       // HIPSOXR_NO_PLANES        k_tile_mfma instead of k_tile_mfma_p
     bool no_mfma64 = false;       // HIPSOXR_NO_MFMA64        float64 engine (float64 / int32 I/O) on the vector ALU (k_tile) instead of v_mfma_f64
     bool no_host_ring = false;    // HIPSOXR_NO_HOST_RING     small-chunk streams keep their ring in device memory (copy per call)

@@ -71,6 +71,7 @@ const Switches &switches()
 #ifdef HIPSOXR_DEBUG_SWITCHES
         w.fft_no_pair = on("HIPSOXR_FFT_NO_PAIR"); w.fft_no_chpair = on("HIPSOXR_FFT_NO_CHPAIR"); w.fft_no_xcd_map = on("HIPSOXR_FFT_NO_XCD_MAP");
         w.fft_large_only = on("HIPSOXR_FFT_LARGE_ONLY"); w.fft_small_only = on("HIPSOXR_FFT_SMALL_ONLY"); w.fft_no_tiny = on("HIPSOXR_FFT_NO_TINY");
+        w.fft_no_wave = on("HIPSOXR_FFT_NO_WAVE"); w.dbg_wave_min = num("HIPSOXR_DEBUG_WAVE_MIN"); w.dbg_wave_slots = num("HIPSOXR_DEBUG_WAVE_SLOTS");
         w.no_planes = on("HIPSOXR_NO_PLANES"); w.no_mfma64 = on("HIPSOXR_NO_MFMA64"); w.no_host_ring = on("HIPSOXR_NO_HOST_RING");
         w.no_chain = on("HIPSOXR_NO_CHAIN"); w.no_done_words = on("HIPSOXR_NO_DONE_WORDS"); w.direct_max = num("HIPSOXR_DEBUG_DIRECT_MAX");
         w.resident_no_bar = on("HIPSOXR_RESIDENT_NO_BAR"); w.no_xcd_split = on("HIPSOXR_NO_XCD_SPLIT"); w.no_tile_split = on("HIPSOXR_NO_TILE_SPLIT");

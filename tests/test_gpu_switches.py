@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 DBG_LIB = os.path.join(os.path.dirname(HERE), "python-soxr_amd", "_variants", "dbg", "libhipsoxr.so")
 SWITCHES = ["HIPSOXR_NO_FFT", "HIPSOXR_FFT_NO_PAIR", "HIPSOXR_FFT_NO_CHPAIR", "HIPSOXR_FFT_NO_XCD_MAP",
-            "HIPSOXR_FFT_LARGE_ONLY", "HIPSOXR_FFT_SMALL_ONLY", "HIPSOXR_FFT_NO_TINY",
+            "HIPSOXR_FFT_LARGE_ONLY", "HIPSOXR_FFT_SMALL_ONLY", "HIPSOXR_FFT_NO_TINY", "HIPSOXR_FFT_NO_WAVE",
             "HIPSOXR_NO_PLANES", "HIPSOXR_NO_HOST_RING", "HIPSOXR_NO_CHAIN",
             "HIPSOXR_NO_DONE_WORDS", "HIPSOXR_RESIDENT", "HIPSOXR_AUTO_RESIDENT", "HIPSOXR_RESIDENT_NO_BAR", "HIPSOXR_NO_XCD_SPLIT", "HIPSOXR_NO_TILE_SPLIT",
             "HIPSOXR_NO_INTERP_TILE", "HIPSOXR_NO_INTERP_WAVE", "HIPSOXR_NO_GATHER_WAVE",
