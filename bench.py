@@ -743,6 +743,8 @@ def _compact(v, key=None):
     if isinstance(v, float):
         return float("%.5g" % v) if v == v and abs(v) != float("inf") else None
     if isinstance(v, str):
+        if key == "bank_sha256":
+            return v[:16]
         return v if len(v) <= 80 else v[:77] + "..."
     if isinstance(v, (list, tuple)):
         return [_compact(e) for e in v]
@@ -963,6 +965,11 @@ def main():
             "scaling": "strong", "value": args.batch_clips * IN_RATE * 10 * bsteps / swall / 1e6, "unit": "Msamples/s",
             "ms_per_step": swall / bsteps * 1e3, "launch_us_rank0": skern * 1e6,
             "hbm_frac_rank0": 4.0 * (xs.numel() + ys.numel()) / skern / 1e9 / HBM_PEAK_GBS}
+        if world > 1:  # which clips every rank really held (a partition of [0, batch_clips): tests/test_gpu_multi.py)
+            import torch.distributed as dist
+            held = [None] * world
+            dist.all_gather_object(held, [slo, shi])
+            result["batch_strong"]["shards"] = held
         del xs, ys
 
     # ---- configs[2] (context line, not the headline): 60 s x 8 channels interleaved, 44.1k -> 16k VHQ

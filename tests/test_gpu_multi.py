@@ -144,6 +144,29 @@ def test_bench_gpus_2_starts_its_own_ranks_gloo_harness():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_8_gloo_harness_partitions_the_batch():
+    """The driver's largest line, `--gpus 8`, proven before hardware runs it: eight self-started ranks (sharing this box's GPU
+    over gloo), every rank seen, one bank, and the strong-scaling batch partitioned [0, 128) ... [896, 1024) with no clip
+    dropped or held twice.  (The scaling model is the reference's threads over independent calls,
+    /root/reference/tests/gil_bench.py:22-56: nothing is exchanged but the bank.)"""
+    import time
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--kernels-only", "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["ranks"]["ranks_seen"] == 8 and len(d["ranks"]["ranks"]) == 8 and d["ranks"]["backend"] == "gloo" and d["ranks"]["banks_identical"]
+    assert sorted(r["rank"] for r in d["ranks"]["ranks"]) == list(range(8))
+    assert d["batch_strong"]["shards"] == [[128 * r, 128 * (r + 1)] for r in range(8)]
+    assert wall < 120, wall
+
+
+@pytest.mark.gpu
 def test_bench_refuses_more_gpus_than_the_box_has():
     n = _n_dev() + 1
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
