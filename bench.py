@@ -47,8 +47,9 @@ KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, paire
 # itself): profiles/<TRAFFIC_FILE> records them TOGETHER WITH the SHA-256 of the kernel sources they were taken on.
 # `measured_counters()` hands a figure out only while that hash still matches the sources in this checkout — a stale
 # constant is reported as null with the reason, never silently.
-TRAFFIC_FILE = "r05_traffic.json"
-KERNEL_SOURCES = ("python-soxr_amd/csrc/fft.hip", "python-soxr_amd/csrc/kernels.hip", "python-soxr_amd/csrc/twostage.hip")
+TRAFFIC_FILE = "r06_traffic.json"
+KERNEL_SOURCES = ("python-soxr_amd/csrc/fft.hip", "python-soxr_amd/csrc/fft_dev.h", "python-soxr_amd/csrc/fftwave.hip", "python-soxr_amd/csrc/kernels.hip",
+                  "python-soxr_amd/csrc/twostage.hip")
 
 
 def kernel_sources_sha16():
@@ -731,7 +732,7 @@ def power_leg(plan, xs, seconds, device, kernel, nbytes):
 LINE_BUDGET = 6144
 _HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline")
-_TAIL_KEYS = ("dtype_matrix", "arith_f64", "arbitrary_ratio", "exact_engine", "batch_strong", "configs2", "batch_shard", "throughput_roofline")
+_TAIL_KEYS = ("dtype_matrix", "arith_f64", "arbitrary_ratio", "exact_engine", "batch_up", "batch_strong", "configs2", "batch_shard", "throughput_roofline")
 _DROP_KEYS = {"note", "launch_us_window", "smi_samples", "taken_on_kernel_sources_sha16", "usable_cpus", "host_cpus", "calls", "regime_note"}
 # context legs given up first (in this order) if a line still exceeds the budget
 _SHED_ORDER = ("host_batch", "host_api", "configs4", "hbm_ceiling", "ranks", "dtype_matrix", "arith_f64")
@@ -907,6 +908,7 @@ def main():
                   if k in ("power_W", "sclk_MHz", "energy_mJ_per_launch", "smi_samples")})
 
     # ---- configs[3] shard: 1024 x 10 s clips over 8 GPUs -> 128 clips per GPU ----------------
+    f64_tp = None
     if not args.no_batch:
         lo, hi = shard(args.batch_clips, args.batch_gpus, rank % args.batch_gpus)
         clips = hi - lo
@@ -952,7 +954,31 @@ def main():
                 cn, cdt, _ = sustained_leg(plan, xbs[:1], min(1.0, args.sustained_s), device, args.kernel)
                 result["batch_shard"]["one_buffer_set"] = {"us_per_launch": cdt / cn * 1e6, "frac": bbytes / (cdt / cn) / 1e9 / HBM_PEAK_GBS,
                                                            "note": "input re-read from the Infinity Cache: not HBM traffic"}
+        # ... and the same batch at the arithmetic width libsoxr's VHQ recipe computes in (float32 I/O, float64 arithmetic):
+        # the throughput figure of the `arith_f64` leg — rotating buffer sets, back to back, >= 1 s
+        if world == 1 and args.kernel == 0 and not args.no_sustained:
+            try:
+                fn, fdt, _ = sustained_leg(plan, xbs, min(1.5, args.sustained_s), device, 8)
+                f64_tp = {"workload": "batch_shard", "us_per_launch": fdt / fn * 1e6, "launches": fn,
+                          "frac": bbytes / (fdt / fn) / 1e9 / HBM_PEAK_GBS, "read_frac": 4.0 * b_in / (fdt / fn) / 1e9 / HBM_PEAK_GBS}
+            except RuntimeError as e:
+                f64_tp = {"error": str(e)}
         del xbs, yb
+        # the same batch in the UP direction (44.1k -> 48k): 8832 block pairs, which the product hands to the one-wave-per-pair
+        # kernel (csrc/fftwave.hip, round 6) — context line: rotating buffer sets, HIP-event windows
+        if world == 1 and args.kernel == 0:
+            try:
+                plan_up = dev.Plan(float(OUT_RATE), float(IN_RATE), QUALITY)
+                xus = [torch.randn((clips, OUT_RATE * 10, 1), device=device, dtype=torch.float32, generator=g) * 0.25 for _ in range(min(n_sets, 3))]
+                _, uk, yu = time_workload(plan_up, xus, bsteps, 2, world, device, 0, windows=6, min_window=50)
+                ubytes = 4.0 * (clips * OUT_RATE * 10 + clips * yu.shape[1])
+                u_traffic, _, u_prov = measured_counters("batch_up") if clips == 128 else (None, None, {})
+                result["batch_up"] = {"workload": f"{clips} x 10 s clips, VHQ 44.1k->48k float32", "kernel": "k_fft_wave<3528 x 3840> (one wave per block pair)",
+                                      "launch_us": uk * 1e6, "frac": ubytes / uk / 1e9 / HBM_PEAK_GBS, "traffic": u_traffic,
+                                      "rocprof_avg_us": u_prov.get("rocprof_avg_us")}
+                del xus, yu, plan_up
+            except RuntimeError as e:
+                result["batch_up"] = {"error": str(e)}
         # the same batch partitioned over THIS job's ranks (strong scaling: 1024 clips in total whatever N is; at N = 1
         # all 1024 clips run on the one GPU — 3.8 GB of signal — which anchors the strong-scaling curve and exercises
         # configs[3] whole)
@@ -1041,6 +1067,8 @@ def main():
                                    "frac": algo_bytes / fk / 1e9 / HBM_PEAK_GBS, "read_frac": 4.0 * n_in / fk / 1e9 / HBM_PEAK_GBS}
         except RuntimeError as e:
             result["arith_f64"] = {"error": str(e)}
+        if not args.no_batch and f64_tp is not None:
+            result["arith_f64"]["throughput"] = f64_tp
 
     if rank == 0:
         ceil = hbm_ceiling(device) if not args.kernels_only else {"skipped": "--kernels-only"}

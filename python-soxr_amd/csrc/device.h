@@ -27,6 +27,9 @@ struct VrPos {
 // Resident form of the small-launch kernel (kernels.hip, k_chain_resident): the mailbox in pinned host memory
 // and what a launch of an instance needs.
 static constexpr unsigned kResidentMaxWgs = 64;
+// Watchdog: whatever HIPSOXR_RESIDENT_IDLE_US says, an instance that has heard nothing for this long leaves — a kernel that
+// spins holds every device-wide synchronisation of the process (torch.cuda.synchronize() included) until it does.
+static constexpr int kResidentWatchdogUs = 20000;
 struct ResidentBox {
     uint64_t w[16];                 // lines 0-1: host -> device (tagged words, see k_chain_resident): 5 of them for a constant-rate
                                     // message, 14 with a variable-rate clock (three 128-bit numbers in 48-bit pieces); w[15] = leave
@@ -80,7 +83,7 @@ struct Switches {
     bool no_fft = false;          // HIPSOXR_NO_FFT           AUTO never picks the frequency-domain engine (every job bit-exact)
     bool resident = false;        // HIPSOXR_RESIDENT         small-chunk synchronous streams use the resident kernel (as the HIPSOXR_RESIDENT flag)
     bool auto_resident = false;   // HIPSOXR_AUTO_RESIDENT    streams turn the resident path on by themselves after 16 small back-to-back calls
-    int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long
+    int resident_idle_us = 1000;  // HIPSOXR_RESIDENT_IDLE_US an idle resident kernel leaves after this long (at most kResidentWatchdogUs = 20 ms)
     // ---- debug builds only (-DHIPSOXR_DEBUG_SWITCHES) ----
     bool fft_no_pair = false;     // HIPSOXR_FFT_NO_PAIR      one block per workgroup instead of the paired kernels
     bool fft_no_chpair = false;   // HIPSOXR_FFT_NO_CHPAIR    pair blocks even for interleaved even-channel data

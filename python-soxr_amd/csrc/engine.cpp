@@ -739,7 +739,7 @@ static const char *resident_emit(hipsoxr_stream *s, const hipsoxr_job_t &j, bool
         ResidentLaunch rl;
         rl.box = r.box; rl.words = (const uint64_t *)r.words; rl.ctl = r.ctl + r.ctl_next++; rl.base_seq = base_seq;
         if (++r.epoch == 0) ++r.epoch;
-        rl.epoch = r.epoch; rl.idle_us = std::max(50, switches().resident_idle_us);
+        rl.epoch = r.epoch; rl.idle_us = std::min(kResidentWatchdogUs, std::max(50, switches().resident_idle_us));
         hipsoxr_job_t cap = jr; // room for chunks a quarter longer than this one
         cap.out_frames = std::max<int64_t>(64, j.out_frames + j.out_frames / 4 + 2);
         std::lock_guard<std::mutex> reserve(g_resident_mu);
@@ -876,7 +876,7 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
     }
     if (!s->resident && s->resident_auto_ok) {
         const auto now = std::chrono::steady_clock::now();
-        const auto gap = std::chrono::microseconds(std::max(50, switches().resident_idle_us) / 2);
+        const auto gap = std::chrono::microseconds(std::min(kResidentWatchdogUs, std::max(50, switches().resident_idle_us)) / 2);
         s->small_run = (small_call && (s->small_run == 0 || now - s->last_small < gap)) ? s->small_run + 1 : 0;
         s->last_small = now;
         if (s->small_run >= kAutoResidentRun) s->resident = s->resident_by_auto = true;
@@ -884,7 +884,7 @@ static const char *stream_emit_once(hipsoxr_stream *s, void *out, size_t olen, s
         // a stream that turned resident by itself drops back the moment the run breaks: a call that is not small, one
         // that comes after a gap (its instance has idled out or is about to), or an instance that left on its own
         const auto now = std::chrono::steady_clock::now();
-        const auto gap = std::chrono::microseconds(std::max(50, switches().resident_idle_us) / 2);
+        const auto gap = std::chrono::microseconds(std::min(kResidentWatchdogUs, std::max(50, switches().resident_idle_us)) / 2);
         if (!small_call || now - s->last_small >= gap || (s->res.running && s->res.box->exited == s->res.epoch)) {
             resident_stop(s);
             s->resident = s->resident_by_auto = false;

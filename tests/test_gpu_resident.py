@@ -219,3 +219,36 @@ def test_default_streams_never_park_a_kernel_and_auto_ones_do_so_only_while_fed(
     auto3.resample_chunk(x[:441])                                    # ordinary path again
     t0 = time.perf_counter(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     assert dt < 0.5e-3, dt
+
+
+def test_watchdog_bounds_an_idle_resident_instance_whatever_the_environment_says():
+    """HIPSOXR_RESIDENT_IDLE_US = 5 s in a process of its own: the instance still leaves after the 20 ms watchdog
+    (csrc/device.h kResidentWatchdogUs), so a device-wide synchronisation behind an idle resident stream returns in
+    tens of milliseconds, not seconds — and the stream carries on afterwards with the same frames."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, time, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import soxr_amd as soxr
+rng = np.random.default_rng(5)
+x = (rng.standard_normal(441 * 60) * 5000).astype(np.int16)
+ref = soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ")
+rs = soxr.ResampleStream(44100, 16000, 1, dtype=np.int16, quality="VHQ", resident=True)
+a = [rs.resample_chunk(x[i:i + 441]) for i in range(0, 441 * 30, 441)]
+b = [ref.resample_chunk(x[i:i + 441]) for i in range(0, 441 * 30, 441)]
+t0 = time.perf_counter(); torch.cuda.synchronize(); wait = time.perf_counter() - t0      # the instance is idle and spinning
+a += [rs.resample_chunk(x[i:i + 441]) for i in range(441 * 30, 441 * 60, 441)]
+b += [ref.resample_chunk(x[i:i + 441]) for i in range(441 * 30, 441 * 60, 441)]
+print("WATCHDOG " + json.dumps({"wait": wait, "same": bool(np.array_equal(np.concatenate(a), np.concatenate(b)))}))
+""" % (ROOT, os.path.join(ROOT, "python-soxr_amd"))
+    env = dict(os.environ, HIPSOXR_RESIDENT_IDLE_US="5000000")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    import json
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("WATCHDOG ")][-1][len("WATCHDOG "):])
+    assert d["same"]
+    assert d["wait"] < 0.2, d            # 20 ms watchdog (+ relaunch slack); 5 s if the environment were obeyed

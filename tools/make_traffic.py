@@ -17,6 +17,7 @@ import bench  # noqa: E402  (kernel_sources_sha16, KERNEL_SOURCES)
 WORKLOADS = {  # name -> (kernel-name substring, grid predicate, algorithmic bytes)
     "configs1": ("k_fft_pair2<hipsoxr::PairSpec<2560, 2352", lambda gx, gy: gy == 1, 4 * (2880000 + 2646000)),
     "batch_shard": ("k_fft_pair2<hipsoxr::PairSpec<5120, 4704", lambda gx, gy: gy == 128, 4 * 128 * (480000 + 441000)),
+    "batch_up": ("k_fft_wave<hipsoxr::WaveSpec<3528, 3840", lambda gx, gy: True, 4 * 128 * (441000 + 480000)),
     "configs2": ("k_fft_strided2<hipsoxr::PairSpec<4410, 1600", lambda gx, gy: True, 4 * 8 * (2646000 + 960000)),
     "float64": ("double, double>", lambda gx, gy: True, 8 * (2880000 + 2646000)),
     "arith_f64": ("double, float>", lambda gx, gy: True, 4 * (2880000 + 2646000)),
