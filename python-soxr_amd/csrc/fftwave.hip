@@ -15,9 +15,13 @@
 // literals), three LDS exchanges per pair instead of five.  The exchanges move the real parts, then the imaginary parts,
 // through ONE buffer of N floats: 15.6 KB per wave, so a CU holds eight waves (two per SIMD, 256 registers each) — what a
 // lone wave cannot do (one vector instruction per 4.4-4.8 cycles, tools/ubench/valu_issue.hip) two waves per SIMD can.
-// Kept outputs: 22 of 24 periods (k_fft_pair2: 30 of 32).
-// Serves float32 unit-stride columns (mono / planar / batches, ragged included) from `wave_min_pairs` work items up;
-// smaller jobs are latency-bound and stay on k_fft_pair2, whose 6-wave workgroups finish a pair sooner.
+// Kept outputs: 22 of 24 periods (k_fft_pair2: 30 of 32).  5300 vector instructions per pair of 3234-output blocks (4540 with the
+// packed FMAs of fft_dev.h) against k_fft_pair2's 8770 per pair of 4410.
+// Measured (profiles/NOTES_r06.md §1-§2, the 128 x 10 s batch, one box): 44.1k -> 48k 116.6-116.9 us against 124.9-127.0 for
+// k_fft_pair2 — taken, from 8192 pairs up (four full rounds of the 2048 wave slots; below that the partly filled last round
+// costs more than the form gains, and a single pair's latency is 39 k cycles on one wave); 48k -> 44.1k 117.0 against 114.0 —
+// NOT taken (`min_pairs` in the table below; HIPSOXR_DEBUG_WAVE_MIN in the debug-switch build forces either, which is how
+// tests/test_gpu_fft_wave.py covers both).  Float32 unit-stride columns (mono / planar / batches, ragged included).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
