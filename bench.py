@@ -49,6 +49,7 @@ KERNEL_NAMES = {0: "k_fft_pair2<.., float> (AUTO: frequency-domain engine, paire
 # constant is reported as null with the reason, never silently.
 TRAFFIC_FILE = "r06_traffic.json"
 KERNEL_SOURCES = ("python-soxr_amd/csrc/fft.hip", "python-soxr_amd/csrc/fft_dev.h", "python-soxr_amd/csrc/fftwave.hip", "python-soxr_amd/csrc/kernels.hip",
+                  "python-soxr_amd/csrc/kernels_interp.h", "python-soxr_amd/csrc/kernels_chain.h", "python-soxr_amd/csrc/kernels_tile.h",
                   "python-soxr_amd/csrc/twostage.hip")
 
 
@@ -976,6 +977,10 @@ def main():
                 result["batch_up"] = {"workload": f"{clips} x 10 s clips, VHQ 44.1k->48k float32", "kernel": "k_fft_wave<3528 x 3840> (one wave per block pair)",
                                       "launch_us": uk * 1e6, "frac": ubytes / uk / 1e9 / HBM_PEAK_GBS, "traffic": u_traffic,
                                       "rocprof_avg_us": u_prov.get("rocprof_avg_us")}
+                if not args.no_sustained:   # back to back >= 1 s with rocm-smi beside it: the power and clock this kernel runs at
+                    un, udt, upower = sustained_leg(plan_up, xus, min(1.0, args.sustained_s), device, 0, sample_power=(rank == 0))
+                    result["batch_up"]["sustained"] = {"us_per_launch": udt / un * 1e6, "frac": ubytes / (udt / un) / 1e9 / HBM_PEAK_GBS, **upower,
+                                                       "energy_mJ_per_launch": upower["power_W"] * udt / un * 1e3 if upower.get("power_W") else None}
                 del xus, yu, plan_up
             except RuntimeError as e:
                 result["batch_up"] = {"error": str(e)}

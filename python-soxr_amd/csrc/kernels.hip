@@ -48,7 +48,10 @@
 //                   per output sample + shuffle reduction): 587 us where k_tile_mfma_p takes 32 —
 //                   6 cross-lane steps and two LDS reads per ~4.6 FMAs.  Never chosen automatically.
 // The frequency-domain engine (1e-6-class, not bit-identical: whole-signal float32/float64 device jobs)
-// lives in fft.hip.
+// lives in fft.hip / fftwave.hip.
+// Layout (round 6): this file holds the switches, the conversions, k_gather / k_wave_dot and the whole host side (tables,
+// launchers); the kernel families are cut into kernels_interp.h, kernels_chain.h and kernels_tile.h, included below — one
+// translation unit still (27 s of the build; the frequency-domain engine's three are the long pole).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -263,1934 +266,9 @@ __global__ void __launch_bounds__(256) k_wave_dot(GatherArgs a, const Real *__re
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_interp — interpolated-phase plans (ratios without a small rational form; plan.cpp)
-// ---------------------------------------------------------------------------------------------
-// One lane per output sample, as k_gather, but the coefficient of tap j is evaluated from the cubic
-// of the output's phase interval:  c = fma(fma(fma(a3, x, a2), x, a1), x, a0), one 16/32-byte load
-// per tap.  Interval and residual come from exact integer arithmetic on (k*M) mod L, so the result
-// is again a pure function of the absolute output index (chunk / launch invariant) and equals
-// oracle_interp_port_* bit for bit.
-template <typename Real, int N> struct VecN;
-template <> struct VecN<float, 4> { typedef float4 type; };
-template <> struct VecN<double, 2> { typedef double2 type; };
-template <typename Real> struct Vec4;
-template <> struct Vec4<float> { typedef float4 type; };
-template <> struct Vec4<double> { typedef double4 type; };
-
-//
-// VR = true (variable-rate streams, engine.cpp): the position of local output i is the Q64.64
-// fixed-point quadratic  t(i) = T0 + i*S0 + D*i(i-1)/2  (constant step: D = 0; linear slew of the
-// step: D != 0), evaluated in 128-bit integers — again exact and launch-invariant.  P is a power
-// of two, so interval and residual are bit fields of the fraction.
-struct InterpArgs {
-    GatherArgs g;   // bank/Lpad unused
-    const void *tab; // [P][T] of Vec4<Real>
-    int32_t P, lgP;
-    uint64_t t_hi, t_lo, s_hi, s_lo, d_hi, d_lo; // VR: T0, S0, D (two's complement), Q64.64
-};
-
-template <typename IO, typename Real, bool VR>
-__global__ void __launch_bounds__(256) k_interp(InterpArgs ia)
-{
-    typedef typename Vec4<Real>::type V4;
-    const GatherArgs &a = ia.g;
-    int64_t idx;
-    uint32_t ch, clip;
-    if (a.ch_fast) {
-        int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        idx = e / a.n_channels;
-        ch = (uint32_t)(e - idx * a.n_channels);
-        clip = blockIdx.y;
-    } else {
-        idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        ch = blockIdx.y % a.n_channels;
-        clip = blockIdx.y / a.n_channels;
-    }
-    if (idx >= a.out_frames) return;
-    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
-    const int32_t T = a.T, H = T / 2;
-    uint64_t iv, xq;
-    int64_t n0;
-    if (VR) {
-        typedef unsigned __int128 u128;
-        const u128 T0 = ((u128)ia.t_hi << 64) | ia.t_lo, S0 = ((u128)ia.s_hi << 64) | ia.s_lo,
-                   D = ((u128)ia.d_hi << 64) | ia.d_lo;
-        const uint64_t i = (uint64_t)idx, m = i * (i - 1) / 2; // i = 0: 0 * (2^64-1) / 2 ... handled below
-        const u128 tt = T0 + (u128)i * S0 + D * (u128)(i ? m : 0); // modular arithmetic == signed D
-        const uint64_t frac = (uint64_t)tt;
-        n0 = (int64_t)(uint64_t)(tt >> 64) - (H - 1);
-        iv = ia.lgP ? frac >> (64 - ia.lgP) : 0;
-        xq = (frac << ia.lgP) >> (64 - SH);
-    } else {
-        const int64_t t = a.p0 + idx * a.M;
-        const int64_t q = t / a.L;
-        const uint64_t r = (uint64_t)(t - q * a.L);
-        const uint64_t tp = r * (uint64_t)ia.P, rem = tp % (uint64_t)a.L;
-        iv = tp / (uint64_t)a.L;
-        xq = (rem << SH) / (uint64_t)a.L;
-        n0 = a.d0 + q - (H - 1);
-    }
-    const Real xx = (Real)xq * (Real)(1. / (double)(1ULL << SH));
-    const int64_t loc0 = n0 - a.in_abs0;
-    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-    const V4 *c = (const V4 *)ia.tab + (int64_t)iv * T;
-    Real accL = 0, accR = 0;
-    auto coef = [&](int j) -> Real {
-        const V4 v = c[j];
-        return fma_r(fma_r(fma_r(v.w, xx, v.z), xx, v.y), xx, v.x);
-    };
-    if (loc0 >= 0 && loc0 + T <= a.in_frames) {
-        const IO *xp = xin + loc0 * a.ifs;
-        for (int j = 0; j < H; ++j) accL = fma_r(coef(j), (Real)xp[(int64_t)j * a.ifs], accL);
-        for (int j = T - 1; j >= H; --j) accR = fma_r(coef(j), (Real)xp[(int64_t)j * a.ifs], accR);
-    } else {
-        for (int j = 0; j < H; ++j) {
-            int64_t l = loc0 + j;
-            Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-            accL = fma_r(coef(j), xv, accL);
-        }
-        for (int j = T - 1; j >= H; --j) {
-            int64_t l = loc0 + j;
-            Real xv = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-            accR = fma_r(coef(j), xv, accR);
-        }
-    }
-    IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + idx * a.ofs + (int64_t)ch * a.ochs;
-    store_out<Real>(yo, accL + accR, a.oc, ch, a.out_k0 + idx);
-}
-
-// the value lane K of the quad holds, in all four of its lanes (DPP quad_perm)
-template <int K> __device__ __forceinline__ float quad_bcast_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
-}
-template <int K> __device__ __forceinline__ double quad_bcast_f(double v)
-{
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)u, K * 0x55, 0xf, 0xf, true);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), K * 0x55, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_gather_wave — exact-bank jobs too small to fill the chip with period tiles (a stream's 96 000-frame chunk, 1 s clips)
-// ---------------------------------------------------------------------------------------------
-// The tile kernels share a phase's coefficients among the periods of a slab: 96 000 frames at 44.1k -> 16k are 218 periods
-// = 14 sixteen-period slabs, 14 workgroups on 256 CUs (15.7 us).  k_interp_wave's shape needs no sharing to fill the
-// chip: a half-chain per QUAD of lanes, here with the phase's own row of the phase-major bank [L][T] — lane k holds taps
-// 16 s + 4 k .. + 3 of step s as one 16-byte (float) / 32-byte (double) load, a quad reads 64 / 128 contiguous bytes
-// per step, requested 8 steps ahead; the chain takes the sixteen coefficients in canonical order by DPP.  Same
-// arithmetic per output as k_gather and the tile kernels: bit-identical.
-struct GatherWaveArgs {
-    GatherArgs g;            // .bank unused
-    const void *phase_major; // [L][T] Real
-    int32_t span_cap;        // staged samples per workgroup (>= 31 window shifts + T)
-    uint32_t *done_words;    // (optional) completion words, as ChainArgs::done_words
-    uint32_t done_seq;
-};
-
-template <typename IO, typename Real>
-__global__ void __launch_bounds__(256) k_gather_wave(GatherWaveArgs wa)
-{
-    typedef typename Vec4<Real>::type V4;
-    constexpr int U = 8; // steps (of sixteen taps) requested ahead
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ int64_t s_loc[4];
-    const GatherArgs &a = wa.g;
-    const int lane = threadIdx.x & 63, k = lane & 3, quad = lane >> 2;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), half = wave & 1, grp = wave >> 1;
-    Real *xs = reinterpret_cast<Real *>(smem_raw);
-    Real *accx = xs + wa.span_cap; // [32]
-    const int32_t T = a.T, H = T / 2, NS = (H + 15) / 16; // T is a multiple of 8: H of 4
-    const uint32_t col = blockIdx.y;
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-
-    const int64_t o = (int64_t)blockIdx.x * 32 + grp * 16 + quad;
-    const int64_t oc = o < a.out_frames ? o : a.out_frames - 1;
-    const int64_t t = a.p0 + oc * a.M, q = t / a.L, ph = t - q * a.L; // (out_k0 + o) * M = L * (d0 + q) + ph
-    const int64_t loc0 = a.d0 + q - (H - 1) - a.in_abs0;
-    if (half == 0 && (lane == 0 || lane == 63)) s_loc[grp * 2 + (lane ? 1 : 0)] = loc0;
-    __syncthreads();
-    const int64_t base = s_loc[0];
-    int32_t span = (int32_t)(s_loc[3] - base) + T;
-    if (span > wa.span_cap) span = wa.span_cap; // (never: the host sized span_cap from M / L)
-    const int32_t rel = (int32_t)(loc0 - base);
-    for (int m = (int)threadIdx.x; m < span; m += 256) {
-        const int64_t l = base + m;
-        xs[m] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-    }
-    __syncthreads();
-
-    const Real *row = (const Real *)wa.phase_major + ph * T;
-    Real acc = 0;
-    auto run = [&](auto half_c) {
-        constexpr bool HALF = decltype(half_c)::value;
-        // step s: taps 16 s .. 16 s + 15 of the first half-chain (upwards), T-1-16 s .. T-16-16 s of the second
-        // (downwards); lane k holds four of them, ascending in memory either way.  Loads are unconditional and clamped
-        // to the last step (a load under a condition is waited for at once: k_interp_wave).  A last step of fewer than
-        // sixteen taps reads past the half-chain, inside the row (T >= 32).
-        auto at = [&](int s_) {
-            const Real *p4 = row + (HALF ? T - 16 * (s_ + 1) : 16 * s_) + 4 * k;
-            return *reinterpret_cast<const V4 *>(p4);
-        };
-        const Real *xp = xs + rel + (HALF ? T - 1 : 0);
-        V4 r[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = at(u < NS ? u : NS - 1);
-        auto four = [&](const V4 c, const Real *xq, auto lane_c) { // the four taps lane M holds, in chain order
-            constexpr int M = decltype(lane_c)::value;
-            if (!HALF) {
-                acc = fma_r(quad_bcast_f<M>(c.x), xq[4 * M + 0], acc);
-                acc = fma_r(quad_bcast_f<M>(c.y), xq[4 * M + 1], acc);
-                acc = fma_r(quad_bcast_f<M>(c.z), xq[4 * M + 2], acc);
-                acc = fma_r(quad_bcast_f<M>(c.w), xq[4 * M + 3], acc);
-            } else { // xq points at the step's HIGHEST tap; lane M's taps sit 15 - 4 M - e below it
-                acc = fma_r(quad_bcast_f<M>(c.w), xq[-(12 - 4 * M) - 0], acc);
-                acc = fma_r(quad_bcast_f<M>(c.z), xq[-(12 - 4 * M) - 1], acc);
-                acc = fma_r(quad_bcast_f<M>(c.y), xq[-(12 - 4 * M) - 2], acc);
-                acc = fma_r(quad_bcast_f<M>(c.x), xq[-(12 - 4 * M) - 3], acc);
-            }
-        };
-        auto chain = [&](const V4 c, int s_, int taps) { // taps: 16, or what is left of the half-chain in its last step
-            const Real *xq = HALF ? xp - 16 * s_ : xp + 16 * s_;
-            if (!HALF) {
-                four(c, xq, std::integral_constant<int, 0>());
-                if (taps > 4) four(c, xq, std::integral_constant<int, 1>());
-                if (taps > 8) four(c, xq, std::integral_constant<int, 2>());
-                if (taps > 12) four(c, xq, std::integral_constant<int, 3>());
-            } else {
-                four(c, xq, std::integral_constant<int, 3>());
-                if (taps > 4) four(c, xq, std::integral_constant<int, 2>());
-                if (taps > 8) four(c, xq, std::integral_constant<int, 1>());
-                if (taps > 12) four(c, xq, std::integral_constant<int, 0>());
-            }
-        };
-        const int full = H / 16; // steps of sixteen taps; a shorter last one follows when H is not a multiple of 16
-        int s0 = 0;
-        for (; s0 + 2 * U <= full; s0 += U) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const V4 v = r[u];
-                r[u] = at(s0 + u + U);
-                chain(v, s0 + u, 16);
-            }
-        }
-        for (; s0 + U <= full; s0 += U) { // (the look-ahead reaches the end: clamped)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const V4 v = r[u];
-                const int sn = s0 + u + U;
-                r[u] = at(sn < NS ? sn : NS - 1);
-                chain(v, s0 + u, 16);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { // fewer than U steps left, already requested; the last may be short
-            const int s_ = s0 + u;
-            if (s_ < full) chain(r[u], s_, 16);
-            else if (s_ < NS) chain(r[u], s_, H - 16 * full);
-        }
-    };
-    if (half) run(std::integral_constant<bool, true>());
-    else run(std::integral_constant<bool, false>());
-    if (half && k == 0) accx[grp * 16 + quad] = acc;
-    __syncthreads();
-    if (!half && k == 0 && o < a.out_frames) {
-        IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + o * a.ofs + (int64_t)ch * a.ochs;
-        store_out<Real>(yo, acc + accx[grp * 16 + quad], a.oc, ch, a.out_k0 + o);
-    }
-    if (wa.done_words) {
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_store(&wa.done_words[blockIdx.y * gridDim.x + blockIdx.x], wa.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_interp_tile — throughput kernel for interpolated-phase plans and variable-rate launches
-// ---------------------------------------------------------------------------------------------
-// k_interp is bound by the texture-address path: the 64 lanes of a wave sit in 64 different phase
-// intervals, so every tap fetches 64 different 16-byte cubic records (1.9 Gsamples/s at VHQ).
-// Here a workgroup takes KO consecutive outputs of one column, stages their input span in LDS, and
-// SORTS the outputs by phase interval (counting sort in LDS).  A wave then processes outputs of ONE
-// interval at a time: the interval's cubic records are wave-uniform (one broadcast load per tap
-// instead of 64 scattered ones), each lane reads its own input window from LDS.
-// Same canonical arithmetic per output as k_interp / the oracle, so results stay bit-identical.
-struct InterpTileArgs {
-    InterpArgs ia;
-    int32_t KO;        // outputs per workgroup
-    int32_t span_cap;  // staged input samples (>= span of any workgroup)
-    // PAIR instances: a lane carries TWO outputs that share position, interval and cubic argument — the neighbouring channel
-    // (ch + 1), or the same column h periods of L outputs further on (output k + h L sits exactly h M input samples behind
-    // output k with the same remainder) — so the interval's records stream through the scalar cache once for both and the
-    // cubic per tap is evaluated once; each member's own FMA chain is untouched (bit-identical results).
-    uint32_t cols_per_clip, ch_step; // column -> (clip, first channel): col / cols_per_clip, (col % cols_per_clip) * ch_step
-    int64_t m2_in, m2_out;           // member 2: element offsets of its input frame l / output k from member 1's
-    int64_t m2_l, m2_k, m2_n;        // ... its input frame = l + m2_l, its output index = k + m2_k, and how many outputs it has
-    int32_t m2_dch;                  // ... its channel = ch + m2_dch (dither / clip-counter context)
-};
-
-template <typename Real> struct InterpPos { int64_t n0; uint32_t iv; uint64_t xq; };
-
-template <typename Real, bool VR>
-__device__ __forceinline__ InterpPos<Real> interp_locate(const InterpArgs &ia, int64_t idx)
-{
-    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
-    const GatherArgs &a = ia.g;
-    InterpPos<Real> r;
-    const int32_t H = a.T / 2;
-    if (VR) {
-        typedef unsigned __int128 u128;
-        const u128 T0 = ((u128)ia.t_hi << 64) | ia.t_lo, S0 = ((u128)ia.s_hi << 64) | ia.s_lo,
-                   D = ((u128)ia.d_hi << 64) | ia.d_lo;
-        const uint64_t i = (uint64_t)idx, m = i * (i - 1) / 2;
-        const u128 tt = T0 + (u128)i * S0 + D * (u128)(i ? m : 0);
-        const uint64_t frac = (uint64_t)tt;
-        r.n0 = (int64_t)(uint64_t)(tt >> 64) - (H - 1);
-        r.iv = ia.lgP ? (uint32_t)(frac >> (64 - ia.lgP)) : 0u;
-        r.xq = (frac << ia.lgP) >> (64 - SH);
-    } else {
-        const int64_t t = a.p0 + idx * a.M;
-        const int64_t q = t / a.L;
-        const uint64_t rr = (uint64_t)(t - q * a.L);
-        const uint64_t tp = rr * (uint64_t)ia.P, rem = tp % (uint64_t)a.L;
-        r.iv = (uint32_t)(tp / (uint64_t)a.L);
-        r.xq = (rem << SH) / (uint64_t)a.L;
-        r.n0 = a.d0 + q - (H - 1);
-    }
-    return r;
-}
-
-// floor(t / L) and t mod L for 0 <= t < 2^51, 0 < L < 2^31, through one double-precision multiply
-// and a +-1 correction (exact: the estimate is off by at most one).  Integer division proper costs
-// ~80 VALU instructions on this hardware and the tile kernel needs three per output.
-__device__ __forceinline__ uint64_t divmod_small(uint64_t t, uint32_t L, double invL, uint32_t *rem)
-{
-    uint64_t q = (uint64_t)((double)t * invL);
-    int64_t r = (int64_t)(t - q * (uint64_t)L);
-    if (r < 0) { --q; r += L; }
-    else if (r >= (int64_t)L) { ++q; r -= L; }
-    *rem = (uint32_t)r;
-    return q;
-}
-
-// interp_locate for local output i of a workgroup whose first output sits at (q_base, r_base):
-// (k_base + i) * M = L * (q_base + q) + r  with  r_base + i*M = L*q + r,  i*M < 2^45.
-template <typename Real>
-__device__ __forceinline__ InterpPos<Real> interp_locate_local(const InterpArgs &ia, int64_t n0_base, uint32_t r_base,
-                                                               double invL, int32_t i)
-{
-    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
-    const uint32_t L = (uint32_t)ia.g.L;
-    InterpPos<Real> p;
-    uint32_t r, rem;
-    const uint64_t q = divmod_small((uint64_t)r_base + (uint64_t)i * (uint64_t)ia.g.M, L, invL, &r);
-    p.n0 = n0_base + (int64_t)q;
-    p.iv = (uint32_t)divmod_small((uint64_t)r * (uint64_t)ia.P, L, invL, &rem);
-    // floor(rem * 2^SH / L) by long division in two digits of SH/2 bits (each dividend < 2^47)
-    uint32_t rem2;
-    const uint64_t hi = divmod_small((uint64_t)rem << (SH / 2), L, invL, &rem2);
-    const uint64_t lo = divmod_small((uint64_t)rem2 << (SH / 2), L, invL, &rem);
-    p.xq = (hi << (SH / 2)) | lo;
-    return p;
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_interp_wave — mid-size interpolated-phase and variable-rate launches (a stream's 96 000-frame chunk)
-// ---------------------------------------------------------------------------------------------
-// k_interp gives every output one lane: 64 lanes in 64 different phase intervals fetch 64 different 16-byte cubic
-// records per tap (each pulling a 128-byte line through the texture path for 16 bytes of use), a chunk of 35 000
-// outputs is one wave per SIMD at best, and every wave walks its T taps through ~T/8 serialised round trips to the L2:
-// 227 us for 34 830 outputs x 736 taps (44.1k -> 16k VHQ, variable rate).  Here a half-chain — the canonical order has
-// exactly two per output — is a QUAD of lanes:
-//   * lane k of the quad fetches the record of tap 4s + k of step s and evaluates its cubic: a quad reads 64 contiguous
-//     bytes of its row per step (128 in float64), a wave 16 such runs — no over-fetch, no transposition, a quarter of
-//     the cubic arithmetic per lane, and eight times the waves of k_interp (16 half-chains per wave instead of 64
-//     outputs), each a quarter as long;
-//   * the chain itself — the only serial part — takes the four coefficients in order out of the quad's lanes by DPP
-//     (`quad_perm` broadcast, folded into v_fmac_f32_dpp where the compiler can): acc = fma(c_k, x, acc), k = 0..3,
-//     computed by all four lanes alike;
-//   * records are requested U steps ahead (a register is refilled as soon as its cubic is taken);
-//   * the input span of a workgroup's 32 consecutive outputs (<= 31 steps + T samples) is staged once in LDS, converted,
-//     zero-extended; a quad's four samples per step are one broadcast LDS read.
-// Per output the arithmetic is k_interp's to the letter (cubic by three fma, then the chain fma, accL + accR), so results
-// are bit-identical to it and to the oracle, however the outputs spread over the phase intervals (a constant step of
-// exactly 2.0 puts every output in ONE interval, a generic step in all of them).
-struct InterpWaveArgs {
-    InterpArgs ia;
-    int32_t span_cap; // staged samples per workgroup (>= 31 steps + T)
-    uint32_t *done_words; // (optional, pinned host memory) completion words, as ChainArgs::done_words
-    uint32_t done_seq;
-};
-
-template <typename IO, typename Real, bool VR>
-__global__ void __launch_bounds__(256) k_interp_wave(InterpWaveArgs wa)
-{
-    typedef typename Vec4<Real>::type V4;
-    constexpr int U = 8; // steps (of four taps) requested ahead
-    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ int64_t s_loc[4]; // first / last window start of the two output groups
-    const InterpArgs &ia = wa.ia;
-    const GatherArgs &a = ia.g;
-    const int lane = threadIdx.x & 63, k = lane & 3, quad = lane >> 2;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), half = wave & 1, grp = wave >> 1;
-    Real *xs = reinterpret_cast<Real *>(smem_raw);
-    Real *accx = xs + wa.span_cap; // [32] the second half-chains' sums
-    const int32_t T = a.T, H = T / 2, NS = H / 4; // T is a multiple of 8
-    const uint32_t col = blockIdx.y;
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-
-    const int64_t o = (int64_t)blockIdx.x * 32 + grp * 16 + quad;
-    const int64_t oc = o < a.out_frames ? o : a.out_frames - 1; // (quads past the end repeat the last output and store nothing)
-    const InterpPos<Real> pos = interp_locate<Real, VR>(ia, oc);
-    const Real xx = (Real)pos.xq * (Real)(1. / (double)(1ULL << SH));
-    const int64_t loc0 = pos.n0 - a.in_abs0;
-    // positions grow with the output index: the first quad of group 0 holds the span's first sample, the last quad of group 1 its last window
-    if (half == 0 && (lane == 0 || lane == 63)) s_loc[grp * 2 + (lane ? 1 : 0)] = loc0;
-    __syncthreads();
-    const int64_t base = s_loc[0];
-    int32_t span = (int32_t)(s_loc[3] - base) + T;
-    if (span > wa.span_cap) span = wa.span_cap; // (never: the host sized span_cap from the launch's largest step)
-    const int32_t rel = (int32_t)(loc0 - base);
-    for (int m = (int)threadIdx.x; m < span; m += 256) {
-        const int64_t l = base + m;
-        xs[m] = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-    }
-    __syncthreads();
-
-    const unsigned char *row = (const unsigned char *)ia.tab + (size_t)pos.iv * (size_t)T * sizeof(V4);
-    Real acc = 0;
-    auto run = [&](auto half_c) {
-        constexpr bool HALF = decltype(half_c)::value;
-        // step s: taps 4s .. 4s+3 of the first half-chain (upwards), T-1-4s .. T-4-4s of the second (downwards);
-        // lane k holds tap 4s + k / T-4-4s + k — ascending in memory either way
-        const V4 *rp = reinterpret_cast<const V4 *>(row) + (HALF ? T - 4 + k : k);
-        const Real *xp = xs + rel + (HALF ? T - 1 : 0);
-        // (every load below is unconditional — a load under a condition merges with the register's old value, and the
-        //  copy that merge needs waits for the load at once: 380 cycles per step, measured — so indices are clamped
-        //  to the last step instead, and the loop is cut where the look-ahead reaches the end)
-        auto at = [&](int s_) { return rp[HALF ? -4 * s_ : 4 * s_]; };
-        V4 r[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = at(u < NS ? u : NS - 1);
-        auto chain = [&](const V4 v, int s_) {
-            const Real c = fma_r(fma_r(fma_r(v.w, xx, v.z), xx, v.y), xx, v.x);
-            const Real *xq = HALF ? xp - 4 * s_ : xp + 4 * s_;
-            if (!HALF) {
-                acc = fma_r(quad_bcast_f<0>(c), xq[0], acc);
-                acc = fma_r(quad_bcast_f<1>(c), xq[1], acc);
-                acc = fma_r(quad_bcast_f<2>(c), xq[2], acc);
-                acc = fma_r(quad_bcast_f<3>(c), xq[3], acc);
-            } else {
-                acc = fma_r(quad_bcast_f<3>(c), xq[0], acc);
-                acc = fma_r(quad_bcast_f<2>(c), xq[-1], acc);
-                acc = fma_r(quad_bcast_f<1>(c), xq[-2], acc);
-                acc = fma_r(quad_bcast_f<0>(c), xq[-3], acc);
-            }
-        };
-        int s0 = 0;
-        for (; s0 + 2 * U <= NS; s0 += U) { // the look-ahead stays inside the half-chain: immediate offsets
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const V4 v = r[u];
-                r[u] = at(s0 + u + U);
-                chain(v, s0 + u);
-            }
-        }
-        if (s0 + U <= NS) { // the last full group: its look-ahead is the tail (clamped)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const V4 v = r[u];
-                const int sn = s0 + u + U;
-                r[u] = at(sn < NS ? sn : NS - 1);
-                chain(v, s0 + u);
-            }
-            s0 += U;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) // the tail: fewer than U steps, already requested
-            if (s0 + u < NS) chain(r[u], s0 + u);
-    };
-    if (half) run(std::integral_constant<bool, true>());
-    else run(std::integral_constant<bool, false>());
-    if (half && k == 0) accx[grp * 16 + quad] = acc;
-    __syncthreads();
-    if (!half && k == 0 && o < a.out_frames) {
-        IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + o * a.ofs + (int64_t)ch * a.ochs;
-        store_out<Real>(yo, acc + accx[grp * 16 + quad], a.oc, ch, a.out_k0 + o);
-    }
-    if (wa.done_words) {
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_store(&wa.done_words[blockIdx.y * gridDim.x + blockIdx.x], wa.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-template <typename IO, typename Real, bool VR, bool PAIR, bool TWIN = false>
-__global__ void __launch_bounds__(1024) k_interp_tile(InterpTileArgs ta)
-{
-    static_assert(!TWIN || (PAIR && sizeof(Real) == 4), "TWIN: float pairs only");
-    constexpr int NM = PAIR ? 2 : 1; // members per lane; the staged span is [sample][member]
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const InterpArgs &ia = ta.ia;
-    const GatherArgs &a = ia.g;
-    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
-    const int32_t KO = ta.KO, P = ia.P, T = a.T, H = T / 2;
-    // (round 3: no per-output record in LDS any more — 8 of the 10 bytes of bookkeeping per output; an output's position
-    //  is located again where it is needed, ~50 vector-ALU instructions against the ~1500 of its taps.  LDS then holds
-    //  twice the outputs per workgroup, a bucket — the outputs of one phase interval, served 64 at a time — 60 instead
-    //  of 30.  48000 -> 44101: mono 60 s 254 -> 242 us, 200 000 frames 152 -> 114; stereo 60 s stays at 402.  The kernel issues
-    //  one vector-ALU instruction per 7 cycles per SIMD, and it is not the LDS: with every lane reading lane 0's window — no
-    //  bank conflict left — it takes 382 us.  Time goes with the NUMBER OF GROUPS, whatever the occupancy (30 outputs per
-    //  interval, three workgroups per CU: 628 us; 15: 1013): a group of <= 64 outputs walks its interval's whole row of
-    //  cubic records, 4.8 KB, through the scalar cache, which it misses — 423 MB per launch, ~6 bytes per cycle per scalar
-    //  cache.  Coefficient delivery is the bound; requesting a block ahead (one block is all the SGPRs hold) was slower.)
-    Real *xs = reinterpret_cast<Real *>(smem_raw);                       // [span_cap][NM]
-    // float pairs: the span TWICE, the second copy one sample further on — a lane reads the copy in which its window starts
-    // 16-byte aligned, two taps x two members per ds_read_b128 (256 B/clk) instead of one tap per half of a ds_read2_b64 (128)
-    // (TWIN; where two copies leave too few outputs per workgroup — long steps, long filters — the pair runs on one)
-    constexpr int NCOPY = TWIN ? 2 : 1;
-    Real *xsB = xs + (size_t)(ta.span_cap + 2) * NM; // (span_cap is even: 16-byte aligned)
-    uint16_t *order = reinterpret_cast<uint16_t *>(xs + (size_t)(NCOPY == 2 ? 2 * (ta.span_cap + 2) : ta.span_cap) * NM); // [KO]  outputs sorted by interval
-    uint32_t *off = reinterpret_cast<uint32_t *>(order + ((KO + 1) & ~1)); // [P + 1] bucket offsets
-    uint32_t *cur = off + (P + 1);                                       // [P]     scatter cursors
-
-    const uint32_t col = blockIdx.y;
-    // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
-    // address derived from them) on the scalar side
-    const uint32_t ch = __builtin_amdgcn_readfirstlane((col % ta.cols_per_clip) * ta.ch_step), clip = __builtin_amdgcn_readfirstlane(col / ta.cols_per_clip);
-    const int64_t o_base = (int64_t)blockIdx.x * KO;
-    const int32_t n_here = (int32_t)((a.out_frames - o_base) < KO ? (a.out_frames - o_base) : KO);
-    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-    IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
-
-    // span of inputs this workgroup needs (positions are monotonic in the output index)
-    const int64_t n_first = interp_locate<Real, VR>(ia, o_base).n0;
-    const int64_t n_end = interp_locate<Real, VR>(ia, o_base + n_here - 1).n0 + T;
-    const int32_t span = (int32_t)(n_end - n_first);
-    // rational mode: position of the workgroup's first output, then cheap local arithmetic
-    uint32_t r_base = 0;
-    double invL = 0.;
-    if (!VR) {
-        const int64_t t = a.p0 + o_base * a.M;
-        r_base = (uint32_t)(t - (t / a.L) * a.L);
-        invL = 1. / (double)a.L;
-    }
-    auto locate = [&](int i) -> InterpPos<Real> {
-        if (VR) return interp_locate<Real, VR>(ia, o_base + i);
-        return interp_locate_local<Real>(ia, n_first, r_base, invL, i);
-    };
-
-    for (int i = threadIdx.x; i <= 2 * P; i += blockDim.x) off[i] = 0; // off[0..P] and cur[0..P-1] are contiguous
-    __syncthreads();
-    // 1. locate every output once; histogram of intervals
-    for (int i = threadIdx.x; i < n_here; i += blockDim.x) {
-        const InterpPos<Real> r = locate(i);
-        atomicAdd(&off[r.iv + 1], 1u);
-    }
-    // 2. stage the input span (zero outside the signal), converted to the engine precision
-    for (int m = threadIdx.x; m < span; m += blockDim.x) {
-        const int64_t l = n_first + m - a.in_abs0;
-        const Real v1 = (l >= 0 && l < a.in_frames) ? (Real)xin[l * a.ifs] : (Real)0;
-        xs[NM * m] = v1;
-        if constexpr (PAIR) {
-            const Real v2 = (l + ta.m2_l >= 0 && l + ta.m2_l < a.in_frames) ? (Real)xin[ta.m2_in + l * a.ifs] : (Real)0;
-            xs[NM * m + 1] = v2;
-            if constexpr (NCOPY == 2) { xsB[NM * (m + 1)] = v1; xsB[NM * (m + 1) + 1] = v2; }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) { // inclusive scan of off[1..P] (P <= 256 = 64 lanes x 4) by the first wave
-        const int l = threadIdx.x;
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = (4 * l + e < P) ? off[1 + 4 * l + e] : 0u; sum += v[e]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if (l >= d) incl += up;
-        }
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { run += v[e]; if (4 * l + e < P) off[1 + 4 * l + e] = run; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_here; i += blockDim.x) {
-        const uint32_t iv = locate(i).iv;
-        order[off[iv] + atomicAdd(&cur[iv], 1u)] = (uint16_t)i;
-    }
-    __syncthreads();
-
-    // 3. one interval at a time per wave.  The interval's cubic records are the same for all 64
-    //    lanes, so they must not go through the vector memory path (a lane-uniform
-    //    global_load_dwordx4 still costs 64 x 16 bytes of texture-address bandwidth: measured
-    //    TA-bound at 640 us) — they are read four taps at a time with one scalar s_load_dwordx16
-    //    (wave-uniform pointer in the constant address space) and used as SGPR operands.
-    const int lane = threadIdx.x & 63;
-    const int n_waves = blockDim.x >> 6;
-    typedef Real RealX16 __attribute__((ext_vector_type(16)));
-    typedef const __attribute__((address_space(4))) RealX16 *CPtr16;
-    for (int iv_ = threadIdx.x >> 6; iv_ < P; iv_ += n_waves) {
-        const int iv = __builtin_amdgcn_readfirstlane(iv_);
-        const uint32_t b0 = __builtin_amdgcn_readfirstlane(off[iv]), b1 = __builtin_amdgcn_readfirstlane(off[iv + 1]);
-        CPtr16 row = (CPtr16)((const Real *)ia.tab + (size_t)iv * T * 4); // row[b] = taps 4b .. 4b+3
-        for (uint32_t g = b0; g < b1; g += 64) {
-            // the 64 outputs of this group, sorted by index across the lanes (bitonic, in registers):
-            // consecutive lanes then read input windows a near-constant distance apart, which keeps
-            // the per-tap ds_read_b32 spread over the LDS banks (the counting sort scatters within a
-            // bucket in arrival order)
-            uint32_t key = g + lane < b1 ? order[g + lane] : 0xFFFFu;
-#pragma unroll
-            for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
-                for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                    const uint32_t other = __shfl_xor(key, jj, 64);
-                    const bool take_min = ((lane & k) == 0) == ((lane & jj) == 0);
-                    key = take_min ? (key < other ? key : other) : (key > other ? key : other);
-                }
-            const bool live = key != 0xFFFFu;
-            const int i = live ? (int)key : (int)order[b0];
-            const InterpPos<Real> rc = locate(i);
-            const uint32_t m_first = (uint32_t)(rc.n0 - n_first);
-            const Real *xl = (NCOPY == 2 && (m_first & 1)) ? xsB + NM * (m_first + 1) : xs + NM * m_first;
-            const Real xx = (Real)(uint32_t)rc.xq * (Real)(1. / (double)(1ULL << SH));
-            Real accL = 0, accR = 0, accL2 = 0, accR2 = 0;
-            // (one tap: the canonical cubic, then each member's own chain FMA)
-            // (PAIR: the two members' samples in ONE 8- / 16-byte LDS read — separate 4-byte reads at a stride of two words
-            //  would use every other bank)
-            typedef Real RealX2 __attribute__((ext_vector_type(2)));
-#define HIPSOXR_ITILE_TAP(c0, c1, c2, c3, t, L, L2)                                   \
-    {                                                                                \
-        const Real cj = fma_r(fma_r(fma_r(c3, xx, c2), xx, c1), xx, c0);             \
-        if constexpr (NCOPY == 2) {                                                  \
-            L = fma_r(cj, xq[(t) >> 1][2 * ((t) & 1)], L);                           \
-            L2 = fma_r(cj, xq[(t) >> 1][2 * ((t) & 1) + 1], L2);                     \
-        } else if constexpr (PAIR) {                                                 \
-            const RealX2 xv = reinterpret_cast<const RealX2 *>(x4)[t];               \
-            L = fma_r(cj, xv.x, L);                                                  \
-            L2 = fma_r(cj, xv.y, L2);                                                \
-        } else                                                                       \
-            L = fma_r(cj, x4[t], L);                                                 \
-    }
-            typedef Real RealX4 __attribute__((ext_vector_type(4)));
-#define HIPSOXR_ITILE_QUADS                                                                                              \
-    RealX4 xq[2];                                                                                                        \
-    if constexpr (NCOPY == 2) {                                                                                          \
-        xq[0] = *reinterpret_cast<const RealX4 *>(__builtin_assume_aligned(x4, 16));                                     \
-        xq[1] = *reinterpret_cast<const RealX4 *>(__builtin_assume_aligned(x4 + 4, 16));                                 \
-    }                                                                                                                    \
-    (void)xq;
-#pragma unroll 2
-            for (int b = 0; b < H / 4; ++b) { // T is a multiple of 8: H is a multiple of 4
-                const RealX16 c = row[b];
-                const Real *x4 = xl + NM * 4 * b;
-                HIPSOXR_ITILE_QUADS
-                HIPSOXR_ITILE_TAP(c[0], c[1], c[2], c[3], 0, accL, accL2)
-                HIPSOXR_ITILE_TAP(c[4], c[5], c[6], c[7], 1, accL, accL2)
-                HIPSOXR_ITILE_TAP(c[8], c[9], c[10], c[11], 2, accL, accL2)
-                HIPSOXR_ITILE_TAP(c[12], c[13], c[14], c[15], 3, accL, accL2)
-            }
-#pragma unroll 2
-            for (int b = T / 4 - 1; b >= H / 4; --b) { // descending taps
-                const RealX16 c = row[b];
-                const Real *x4 = xl + NM * 4 * b;
-                HIPSOXR_ITILE_QUADS
-                HIPSOXR_ITILE_TAP(c[12], c[13], c[14], c[15], 3, accR, accR2)
-                HIPSOXR_ITILE_TAP(c[8], c[9], c[10], c[11], 2, accR, accR2)
-                HIPSOXR_ITILE_TAP(c[4], c[5], c[6], c[7], 1, accR, accR2)
-                HIPSOXR_ITILE_TAP(c[0], c[1], c[2], c[3], 0, accR, accR2)
-            }
-#undef HIPSOXR_ITILE_TAP
-#undef HIPSOXR_ITILE_QUADS
-            if (live) {
-                const int64_t idx = o_base + i;
-                store_out<Real>(yo + idx * a.ofs, accL + accR, a.oc, ch, a.out_k0 + idx);
-                if constexpr (PAIR)
-                    if (idx < ta.m2_n) store_out<Real>(yo + ta.m2_out + idx * a.ofs, accL2 + accR2, a.oc, ch + ta.m2_dch, a.out_k0 + idx + ta.m2_k);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_chain — low-latency kernel for SMALL launches (streaming chunks: tens to a few thousand outputs)
-// ---------------------------------------------------------------------------------------------
-// k_gather's cost on a small launch is pure latency: every lane walks T taps, each a pair of L2 loads
-// feeding a dependent FMA (81 us for T = 736, whatever the chunk size).  Here a workgroup of 256
-// threads takes NO consecutive outputs: ALL threads first stage the operands into LDS — the NO
-// coefficient rows, and ONCE the input span the NO windows share (consecutive windows are shifted by
-// M/L samples: 8 windows of 736 taps are 756 distinct samples, not 5888) — with every load of the
-// workgroup in flight at once (one round trip for T <= 768, not T); then 2*NO lanes run the canonical
-// half-chains out of LDS (lane o: left half of output o, lane NO+o: right half), four taps per
-// 16-byte coefficient read, and the two halves are added.  Same arithmetic, bit for bit.
-// The input may be pinned host memory (small-chunk streams keep their ring there, engine.cpp): the span
-// is then the only thing that crosses PCIe, once.
-// MODE 0: exact bank (phase-major [L][T]); 1: interpolated-phase plan; 2: variable rate.  In the
-// interpolated modes the staging thread evaluates the tap's cubic (the canonical Horner FMAs).
-struct ChainArgs {
-    InterpArgs ia;           // .g: job geometry; .tab/.P/...: interpolated plans
-    const void *phase_major; // exact plans: [L][T] Real
-    int32_t NO;              // outputs per workgroup (power of two, <= 32)
-    int32_t span_cap;        // LDS room for the shared input span, in samples
-    uint32_t *done_words;    // (optional, pinned host memory) workgroup w stores done_seq into done_words[w] once its
-    uint32_t done_seq;       //  results are in host memory: the host polls these instead of an event (ChainDone)
-};
-
-// what changes from one launch (or one message to the resident form, below) to the next
-struct ChainMsg { int64_t in_abs0, in_frames, out_k0, out_frames, d0, p0; uint64_t t_hi, t_lo, s_hi, s_lo, d_hi, d_lo; /* MODE 2: the Q64.64 clock of this launch / message */ };
-
-#ifndef HIPSOXR_RPW
-#define HIPSOXR_RPW 2
-#endif
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// `pre` runs in every thread before the barrier in front of the output stores; outputs are withheld if *veto has its
-// top bit set after that barrier (the resident form's arbiter, see k_chain_resident)
-// chunk / split: input frames from ring-relative index `split` on are read from `chunk` (a stream's new frames, not yet in its
-// ring: k_chain_multi) instead of the ring
-template <typename IO, typename Real, int MODE, typename Pre = NoHook>
-__device__ __forceinline__ void chain_body(const ChainArgs &ca, const ChainMsg &m, const uint32_t bx, const uint32_t by,
-                                           unsigned char *smem_raw, uint32_t *trace = nullptr, Pre pre = Pre(),
-                                           const unsigned long long *veto = nullptr, const void *chunk = nullptr, const int64_t split = 0)
-{
-#ifdef HIPSOXR_RES_TRACE
-    const long long tb0 = wall_clock64();
-#define HIPSOXR_CB_STAMP(k) do { if (trace && threadIdx.x == 0) trace[k] = (uint32_t)(wall_clock64() - tb0); } while (0)
-#else
-#define HIPSOXR_CB_STAMP(k) do { } while (0)
-#endif
-    InterpArgs ia = ca.ia;
-    GatherArgs &a = ia.g;
-    a.in_abs0 = m.in_abs0; a.in_frames = m.in_frames; a.out_k0 = m.out_k0; a.out_frames = m.out_frames; a.d0 = m.d0; a.p0 = m.p0;
-    if (MODE == 2) { ia.t_hi = m.t_hi; ia.t_lo = m.t_lo; ia.s_hi = m.s_hi; ia.s_lo = m.s_lo; ia.d_hi = m.d_hi; ia.d_lo = m.d_lo; }
-    constexpr int SH = sizeof(Real) == 4 ? 24 : 32;
-    constexpr int V = 16 / (int)sizeof(Real);      // taps per 16-byte coefficient read: 4 (f32) or 2 (f64)
-    const int32_t T = a.T, H = T / 2, NO = ca.NO, RS = T + V; // RS: row stride (rows 16-byte aligned, banks rotate by V per row)
-    Real *cs = reinterpret_cast<Real *>(smem_raw); // [NO][RS] coefficients, row-major
-    Real *xs = cs + (size_t)NO * RS;               // [span_cap] the input span shared by the NO windows
-    int64_t *n0s = reinterpret_cast<int64_t *>(xs + ((ca.span_cap + 3) & ~3)); // [NO] first-tap input index (relative to in[0])
-    uint64_t *aux = reinterpret_cast<uint64_t *>(n0s + NO);                    // [NO] phase (MODE 0) or iv<<32 | xq (MODE 1, 2)
-
-    const uint32_t ch = by % a.n_channels, clip = by / a.n_channels;
-    const int64_t o_base = (int64_t)bx * NO;
-    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-    const IO *xchunk = chunk ? (const IO *)chunk + (int64_t)ch * a.ichs - split * a.ifs : nullptr; // (indexed like the ring)
-    auto sample_at = [&](int64_t l) -> const IO * { return (xchunk && l >= split) ? xchunk + l * a.ifs : xin + l * a.ifs; };
-    typedef typename Vec4<Real>::type V4;
-
-    if ((int)threadIdx.x < NO) { // one thread per output: where it sits
-        const int64_t idx = o_base + threadIdx.x < a.out_frames ? o_base + threadIdx.x : a.out_frames - 1;
-        if (MODE == 0) {
-            const int64_t t = a.p0 + idx * a.M;
-            int64_t q;
-            uint32_t rem;
-            if (a.L < (1LL << 31) && t < (1LL << 51)) { // (integer division proper: ~1 us of this kernel's latency)
-                q = (int64_t)divmod_small((uint64_t)t, (uint32_t)a.L, 1. / (double)a.L, &rem);
-            } else {
-                q = t / a.L;
-                rem = (uint32_t)(t - q * a.L); // (banks are L*T coefficients: L < 2^32)
-            }
-            n0s[threadIdx.x] = a.d0 + q - (H - 1) - a.in_abs0;
-            aux[threadIdx.x] = (uint64_t)rem;
-        } else {
-            const InterpPos<Real> r = interp_locate<Real, MODE == 2>(ia, idx);
-            n0s[threadIdx.x] = r.n0 - a.in_abs0;
-            aux[threadIdx.x] = ((uint64_t)r.iv << 32) | (uint64_t)(uint32_t)r.xq; // xq < 2^32
-        }
-    }
-    __syncthreads();
-    HIPSOXR_CB_STAMP(0);
-    // ---- stage.  Wave w takes coefficient rows w, w+4, ...; a lane takes taps lane, lane+64, ... of a row (no
-    //      run-time division in the index arithmetic: that alone was a quarter of this kernel), EPT taps per
-    //      trip, loads first, RPW rows at a time.  The input span (SPT samples per thread) is requested AFTER the
-    //      first trip's coefficients and stored after them: when the ring lives in host memory its loads are a
-    //      PCIe round trip (2-3.5 us), and loads return in order — requested first, they held every coefficient
-    //      behind them (5.0-5.7 us for the whole staging; this way 3.4-4.8 us).
-    const int64_t nfirst = n0s[0];
-    const int32_t span = (int32_t)(n0s[NO - 1] - nfirst) + T; // windows are ordered: n0 is non-decreasing in o
-    constexpr int SPT = 4;
-    IO xv[SPT];
-    bool span_loaded = false, span_stored = false;
-    auto load_span = [&]() {
-        if (span_loaded) return;
-        span_loaded = true;
-        // (unconditional loads from clamped addresses, zeroed afterwards: a load under a per-lane condition is a branch
-        //  and a conservative wait each, and the compiler then serialises what should be one round trip)
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) xv[u] = 0;
-        if (a.in_frames > 0) {
-#pragma unroll
-            for (int u = 0; u < SPT; ++u) {
-                const int64_t l = nfirst + (int32_t)threadIdx.x + u * 256;
-                const int64_t lc = l < 0 ? 0 : l >= a.in_frames ? a.in_frames - 1 : l;
-                const IO v = *sample_at(lc);
-                xv[u] = (l == lc) ? v : (IO)0;
-            }
-        }
-    };
-    auto store_span = [&]() {
-        if (span_stored) return;
-        span_stored = true;
-#pragma unroll
-        for (int u = 0; u < SPT; ++u)
-            if ((int32_t)threadIdx.x + u * 256 < span) xs[threadIdx.x + u * 256] = (Real)xv[u];
-        for (int sidx = threadIdx.x + SPT * 256; sidx < span; sidx += 256) { // (spans beyond 1024 samples: very long filters)
-            const int64_t l = nfirst + sidx;
-            xs[sidx] = (l >= 0 && l < a.in_frames) ? (Real)*sample_at(l) : (Real)0;
-        }
-    };
-    constexpr int EPT = MODE == 0 ? 12 : 8, RPW = HIPSOXR_RPW;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int o0 = wave; o0 < NO; o0 += 4 * RPW) {
-        uint64_t au[RPW];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) au[r] = aux[o0 + 4 * r < NO ? o0 + 4 * r : o0];
-        for (int j0 = lane; j0 < T; j0 += 64 * EPT) {
-            Real cv[RPW][EPT];
-            V4 pv[RPW][MODE == 0 ? 1 : EPT];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const Real *crow = MODE == 0 ? (const Real *)ca.phase_major + au[r] * (uint64_t)T : nullptr;
-                const V4 *prow = MODE == 0 ? nullptr : (const V4 *)ia.tab + (size_t)(au[r] >> 32) * T;
-#pragma unroll
-                for (int u = 0; u < EPT; ++u) { // (unconditional, clamped: see load_span)
-                    const int j = j0 + u * 64, jc = j < T ? j : T - 1;
-                    if (MODE == 0) cv[r][u] = crow[jc];
-                    else pv[r][u] = prow[jc];
-                }
-            }
-            load_span();
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-#pragma unroll
-                for (int u = 0; u < EPT; ++u) {
-                    const int j = j0 + u * 64;
-                    if (j < T && o0 + 4 * r < NO) {
-                        if (MODE != 0) {
-                            const Real xx = (Real)(uint32_t)au[r] * (Real)(1. / (double)(1ULL << SH));
-                            cv[r][u] = fma_r(fma_r(fma_r(pv[r][u].w, xx, pv[r][u].z), xx, pv[r][u].y), xx, pv[r][u].x);
-                        }
-                        cs[(size_t)(o0 + 4 * r) * RS + j] = cv[r][u];
-                    }
-                }
-            }
-        }
-    }
-    load_span(); // (waves without a row)
-    store_span();
-    __syncthreads();
-    HIPSOXR_CB_STAMP(1);
-    // ---- the half-chains: wave 0 the left halves (ascending), wave 1 the right halves (descending) — one
-    //      instruction stream per wave; taps in blocks of UNR*V with every LDS read of a block issued before
-    //      its FMAs (the chain is a dependent sequence: what can be hidden is the read latency)
-    Real *red = reinterpret_cast<Real *>(n0s); // (positions are consumed: the right halves' sums go here)
-    const int64_t my_n0 = n0s[lane < NO ? lane : 0];
-    __syncthreads();
-    Real acc = 0;
-    if (wave < 2 && lane < NO) {
-        const int o = lane;
-        const Real *row = cs + (size_t)o * RS;
-        const Real *xw = xs + (my_n0 - nfirst); // this output's window inside the shared span
-        // (blocks of UNR*V taps, all LDS reads of a block in front of its FMAs.  Reading block k+1 during the FMAs
-        //  of block k — ping-pong registers — came out slower, 3.5-4.8 vs 2.6 us for 368 taps: a wave can wait on
-        //  at most 15 outstanding LDS reads, and the compiler's schedule of the two-block body was worse)
-        constexpr int UNR = 8;
-        typedef typename VecN<Real, V>::type CV;
-        if (wave == 0) {
-            int i = 0;
-            for (; i + UNR * V <= H; i += UNR * V) {
-                Real c[UNR * V], x[UNR * V];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) *reinterpret_cast<CV *>(c + u * V) = *reinterpret_cast<const CV *>(row + i + u * V);
-#pragma unroll
-                for (int v = 0; v < UNR * V; ++v) x[v] = xw[i + v];
-#pragma unroll
-                for (int v = 0; v < UNR * V; ++v) acc = fma_r(c[v], x[v], acc);
-            }
-            for (; i < H; i += V) { // taps i .. i+V-1, ascending
-                Real c[V];
-                *reinterpret_cast<CV *>(c) = *reinterpret_cast<const CV *>(row + i);
-#pragma unroll
-                for (int v = 0; v < V; ++v) acc = fma_r(c[v], xw[i + v], acc);
-            }
-        } else {
-            int i = T - UNR * V;
-            for (; i >= H; i -= UNR * V) { // taps i+UNR*V-1 .. i, descending
-                Real c[UNR * V], x[UNR * V];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) *reinterpret_cast<CV *>(c + u * V) = *reinterpret_cast<const CV *>(row + i + u * V);
-#pragma unroll
-                for (int v = 0; v < UNR * V; ++v) x[v] = xw[i + v];
-#pragma unroll
-                for (int v = UNR * V - 1; v >= 0; --v) acc = fma_r(c[v], x[v], acc);
-            }
-            for (i += (UNR - 1) * V; i >= H; i -= V) { // taps i+V-1 .. i, descending
-                Real c[V];
-                *reinterpret_cast<CV *>(c) = *reinterpret_cast<const CV *>(row + i);
-#pragma unroll
-                for (int v = V - 1; v >= 0; --v) acc = fma_r(c[v], xw[i + v], acc);
-            }
-            red[o] = acc;
-        }
-    }
-    pre();
-    __syncthreads();
-    HIPSOXR_CB_STAMP(2);
-    if (veto && (*veto >> 63)) return;
-    if (wave == 0 && lane < NO) {
-        const int o = lane;
-        const Real accR = red[o];
-        const int64_t idx = o_base + o;
-        if (idx < a.out_frames) {
-            IO *yo = (IO *)a.out + (int64_t)clip * a.ocs + idx * a.ofs + (int64_t)ch * a.ochs;
-            store_out<Real>(yo, acc + accR, a.oc, ch, a.out_k0 + idx);
-        }
-    }
-    HIPSOXR_CB_STAMP(3);
-#undef HIPSOXR_CB_STAMP
-}
-
-template <typename IO, typename Real, int MODE>
-__global__ void __launch_bounds__(256) k_chain(ChainArgs ca)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const GatherArgs &g = ca.ia.g;
-    const ChainMsg m = {g.in_abs0, g.in_frames, g.out_k0, g.out_frames, g.d0, g.p0, ca.ia.t_hi, ca.ia.t_lo, ca.ia.s_hi, ca.ia.s_lo, ca.ia.d_hi, ca.ia.d_lo};
-    chain_body<IO, Real, MODE>(ca, m, blockIdx.x, blockIdx.y, smem_raw);
-    if (ca.done_words) {
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_store(&ca.done_words[blockIdx.y * gridDim.x + blockIdx.x], ca.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_chain_multi — k_chain over MANY INDEPENDENT STREAMS in one launch (round 5): grid.y = stream x channel, every stream
-// with its own ring, output buffer, counters and phase (ChainItem).  A stream's new chunk is read where the caller left it
-// and copied into the stream's ring by the same workgroups (share by share: nobody in this launch reads the ring region
-// they write), so a device-chunk stream call is ONE dispatch; N callers' chunks are one dispatch too.
-// ---------------------------------------------------------------------------------------------
-struct ChainMultiArgs {
-    ChainArgs ca;            // what the streams share: plan tables, geometry of a column, NO, LDS layout
-    const ChainItem *items;  // device-readable table, or nullptr: the one item below
-    ChainItem one;
-    uint32_t n_channels;
-};
-template <typename IO, typename Real, int MODE>
-__global__ void __launch_bounds__(256) k_chain_multi(ChainMultiArgs m)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t nch = m.n_channels;
-    const uint32_t item_i = __builtin_amdgcn_readfirstlane(blockIdx.y / nch), ch = __builtin_amdgcn_readfirstlane(blockIdx.y % nch);
-    const ChainItem it = m.items ? m.items[item_i] : m.one;
-    const uint32_t NO = (uint32_t)m.ca.NO;
-    const uint32_t nx = (uint32_t)((it.out_frames + NO - 1) / NO), nxc = nx ? nx : 1; // (a stream without outputs still appends its chunk)
-    if (blockIdx.x >= nxc) return;
-    if (it.chunk && it.chunk_frames > 0) { // this workgroup's share of [the frames the ring keeps, when it moves] + the chunk -> ring_dst
-        const bool moving = it.ring_dst != it.ring;
-        const size_t keep_n = moving ? (size_t)(it.split - it.keep_from) * nch : 0;
-        const size_t total = keep_n + (size_t)it.chunk_frames * nch, W = (size_t)nxc * nch, per = (total + W - 1) / W;
-        const size_t lo = ((size_t)ch * nxc + blockIdx.x) * per, hi = lo + per < total ? lo + per : total;
-        IO *dst = (IO *)it.ring_dst;
-        const IO *old = (const IO *)it.ring + (size_t)it.keep_from * nch, *src = (const IO *)it.chunk;
-        const size_t chunk_at = moving ? keep_n : (size_t)it.split * nch;
-        for (size_t e = lo + threadIdx.x; e < hi; e += 256) {
-            if (e < keep_n) dst[e] = old[e];
-            else dst[chunk_at + (e - keep_n)] = src[e - keep_n];
-        }
-    }
-    if (blockIdx.x >= nx) return;
-    ChainArgs ca = m.ca;
-    GatherArgs &g = ca.ia.g;
-    g.in = it.ring; g.out = it.out; g.n_clips = 1;
-    g.oc.clip_counter = (uint64_t *)it.clip_counter; g.oc.seed = it.dither_seed;
-    const ChainMsg msg = {it.in_abs0, it.in_frames, it.out_k0, it.out_frames, it.d0, it.p0, 0, 0, 0, 0, 0, 0};
-    chain_body<IO, Real, MODE>(ca, msg, blockIdx.x, ch, smem_raw, nullptr, NoHook(), nullptr, it.chunk, it.split);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_chain_resident — k_chain as a RESIDENT consumer: launched once, fed by messages
-// ---------------------------------------------------------------------------------------------
-// A synchronous streaming call on a small chunk costs ~31 us, of which the arithmetic is ~2: the rest is one
-// kernel launch (API ~7 us, dispatch ~4 us), the completion event and its polling.  Here the kernel stays on
-// the GPU between calls and the host talks to it through two cache lines of pinned, device-mapped host
-// memory (ResidentBox) — no HIP call per chunk at all (tools/ubench/mailbox.hip: 3.9 us for the bare round
-// trip host -> kernel -> host, 5.6 us with 1 KiB read from pinned memory on the way):
-//   host -> device  w[0..4]: the ChainMsg of the call, each 8-byte word carrying the message number in its top
-//                   16 bits (an 8-byte read is atomic whatever the load is split into: a word is either this
-//                   message's or stale, and the message is taken once all five carry the expected number);
-//                   w[5]: "instance e, leave" (between messages only);
-//   device -> host  done = number of the last message whose output is complete in pinned memory; exited = e.
-// Every workgroup polls the box itself (one wave, s_sleep between reads) and owns the same NO outputs of
-// every message as in k_chain (workgroups past the end of a short message just report in).  The input ring,
-// the result buffer and the plan are launch arguments: when one of them moves, the host retires the instance
-// and launches another.
-// Leaving.  The kernel must not outlive its host's interest (a device-wide synchronisation elsewhere in the
-// process waits for it), so an instance that hears nothing for idle_ticks leaves by itself — and all its
-// workgroups must take the SAME decision about every message, or a message would be half computed (and its
-// clipped samples counted twice when the next instance repeats it).  One word of device memory per instance
-// (ctl->dec = number of messages accepted, top bit = sealed) arbitrates: a workgroup that sees message n+1
-// does CAS(n -> n+1), one that has waited too long does CAS(n -> n|SEAL); whichever CAS lands first decides
-// for everybody (a workgroup whose seal fails because n+1 was accepted goes back for the message, one whose
-// accept fails because the instance was sealed AT n leaves; an accept that finds (n+1)|SEAL was merely late — the
-// message had been accepted before the seal — and is answered like any other).  The host, waiting for `done`, sees `exited` instead
-// and launches the next instance, which finds the message still in the box.
-// ---------------------------------------------------------------------------------------------
-// (ResidentBox, ResidentCtl: device.h)
-struct ResidentArgs {
-    ChainArgs ca;
-    ResidentBox *box;
-    const uint64_t *words; // host -> device words (box->w, or device memory the CPU stores into)
-    ResidentCtl *ctl;
-    uint32_t base_seq; // messages taken by earlier instances
-    uint32_t epoch;    // this instance
-    int64_t idle_ticks; // of wall_clock64 (100 MHz)
-    uint32_t n_wgs;
-};
-static constexpr unsigned long long kResidentSeal = 1ULL << 63;
-static constexpr uint64_t kResidentMask48 = (1ULL << 48) - 1;
-
-template <typename IO, typename Real, int MODE>
-__global__ void __launch_bounds__(256) k_chain_resident(ResidentArgs ra)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ uint64_t s_w[16];
-    constexpr int NW = MODE == 2 ? 14 : 5; // message words (the variable-rate clock rides in words 5..13); word 15 = leave
-    __shared__ unsigned long long s_old;
-    __shared__ int s_state;
-    const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
-    unsigned long long n = 0; // messages this instance has completed
-    long long t_idle = wall_clock64();
-    for (;;) {
-        if (threadIdx.x < 64) { // one wave polls
-            const int lane = threadIdx.x;
-            const uint64_t want = (uint64_t)((ra.base_seq + (uint32_t)n + 1u) & 0xffffu);
-            int state;
-            uint64_t v = 0;
-            for (;;) {
-                if (lane < 16) v = __hip_atomic_load(&ra.words[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const bool ok = lane >= NW || (v >> 48) == want;
-                const uint64_t leave = __shfl(v, 15, 64);
-                if (__all(ok)) { state = 1; break; }
-                if (leave == (uint64_t)ra.epoch) { state = 2; break; }
-                if (wall_clock64() - t_idle > ra.idle_ticks) { state = 3; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (lane < NW) s_w[lane] = v & kResidentMask48;
-            if (lane == 0) {
-                // too long without a message: try to seal the instance (the arbiter, see above)
-                if (state == 3) s_old = atomicCAS(&ra.ctl->dec, n, n | kResidentSeal);
-                s_state = state;
-            }
-        }
-        __syncthreads();
-        const int state = s_state;
-#ifdef HIPSOXR_RES_TRACE
-        const long long tr0 = wall_clock64();
-#endif
-        if (state == 2) break;                                   // told to leave
-        if (state == 3) {
-            const unsigned long long old = s_old;
-            if (old == n || (old & kResidentSeal)) break;        // sealed: everybody leaves after message n
-            __syncthreads();                                     // message n+1 was accepted by somebody: it is in the box
-            continue;
-        }
-        // message n+1 is here: accept it.  The arbiter's round trip (~1 us) runs behind the body's own loads:
-        // one lane of the last wave asks now and publishes the answer in front of the body's last barrier.
-        unsigned long long old = 0;
-        const bool asker = threadIdx.x == 192;
-        if (asker) old = atomicCAS(&ra.ctl->dec, n, n + 1);
-        // (old == (n+1)|SEAL: the others accepted message n+1, finished it and sealed after idling before this
-        //  workgroup's CAS arrived — "accepted, then sealed", not a veto: the message is partly answered already and
-        //  this workgroup owes its share; it stores, and leaves on its next poll.  Only a seal AT n withholds.)
-        auto publish = [&]() { if (asker) s_old = old == ((n + 1) | kResidentSeal) ? n + 1 : old; };
-        ChainMsg m;
-        {
-            auto uni = [](uint64_t x) {
-                return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x);
-            };
-            const uint64_t w3 = uni(s_w[3]), w4 = uni(s_w[4]);
-            m.in_abs0 = (int64_t)uni(s_w[0]); m.out_k0 = (int64_t)uni(s_w[1]); m.d0 = (int64_t)uni(s_w[2]);
-            m.p0 = (int64_t)(w3 & 0xffffffu); m.in_frames = (int64_t)(w3 >> 24);
-            m.out_frames = (int64_t)w4;
-            m.t_hi = m.t_lo = m.s_hi = m.s_lo = m.d_hi = m.d_lo = 0;
-            if (MODE == 2) { // three 128-bit numbers, each as 48 + 48 + 32 bits (low piece first)
-                auto u128 = [&](int i, uint64_t &hi, uint64_t &lo) {
-                    const uint64_t a0 = uni(s_w[i]), a1 = uni(s_w[i + 1]), a2 = uni(s_w[i + 2]);
-                    lo = a0 | (a1 << 48);
-                    hi = (a1 >> 16) | (a2 << 32);
-                };
-                u128(5, m.t_hi, m.t_lo); u128(8, m.s_hi, m.s_lo); u128(11, m.d_hi, m.d_lo);
-            }
-        }
-        if ((int64_t)blockIdx.x * ra.ca.NO < m.out_frames) {
-            chain_body<IO, Real, MODE>(ra.ca, m, blockIdx.x, blockIdx.y, smem_raw,
-#ifdef HIPSOXR_RES_TRACE
-                                       wg == 0 ? ra.box->pad + 5 : nullptr,
-#else
-                                       nullptr,
-#endif
-                                       publish, &s_old);
-        } else {
-            publish();
-            __syncthreads();
-        }
-        if (s_old & kResidentSeal) break;                        // sealed before this workgroup saw the message: nothing was stored
-#ifdef HIPSOXR_RES_TRACE
-        const long long tr1 = wall_clock64();
-#endif
-        // this workgroup's results are in host memory before its word says so (the host waits for every word:
-        // no arrival counter, no device-wide atomic on the way out)
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#ifdef HIPSOXR_RES_TRACE
-            if (wg == 0) { ra.box->pad[0] = (uint32_t)(tr0 - t_idle); ra.box->pad[1] = (uint32_t)(tr1 - tr0); ra.box->pad[2] = (uint32_t)(wall_clock64() - tr1); }
-#endif
-            __hip_atomic_store(&ra.box->done[wg], ra.base_seq + (uint32_t)n + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        ++n;
-        t_idle = wall_clock64();
-        __syncthreads(); // (s_w / s_state are rewritten by the next poll)
-    }
-    if (threadIdx.x == 0 && wg == 0) __hip_atomic_store(&ra.box->exited, ra.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_tile
-// ---------------------------------------------------------------------------------------------
-// Geometry (host-built, see build_tile_tables): the plan's period may be replicated c times so
-// that Lc = c*L >= RT; "period" below means the replicated period (Lc outputs <- Mc inputs).
-//   tile rt covers outputs r = rt*RT .. rt*RT+RT-1 of a period; for row r
-//       n_r = floor(r*M/L) - (T/2-1)   (first input, relative to the period's first input)
-//       p_r = (r*M) mod L              (phase)
-//   left  half-chain: inputs i = eL0 + ii            (ascending),  table L[ii][rr]
-//   right half-chain: inputs i = eR0 + 3 - ii        (descending), table R[ii][rr]
-//   (e-coordinates are relative to i_min, the first input sample kept in LDS.)
-struct TileArgs {
-    const void *in;
-    void *out;
-    const void *tab;     // [n_rt][2][I_h][RT] Real, constant address space
-    const int32_t *e0;   // [n_rt][2]  (eL0, eR0)
-    int64_t Lc, Mc;      // replicated period
-    int32_t n_rt, I_h, n_waves;
-    int32_t rowR, plane; // k_tile_mfma_p: plane row stride and plane stride (words)
-    unsigned long long *trace; // HIPSOXR_DEBUG_TRACE: per-wave s_memtime stamps [block][wave][16]
-    int32_t dbg; // timing ablations only (HIPSOXR_DEBUG_FLAGS): 1 no staging loads, 2 no LDS reads, 4 no coefficient loads, 8 no stores
-    int32_t pad, i_min, x_count; // LDS row padding; first staged input; samples staged per tile
-    int32_t pb;                  // k_tile: periods per slab (64, or fewer with the upper lanes idle)
-    uint32_t n_clips, n_channels;
-    int64_t ics, ifs, ichs, ocs, ofs, ochs;
-    int64_t in_abs0, in_frames;
-    int64_t out_k0, out_frames;
-    int64_t b_first;     // absolute (replicated) period index handled by lane 0 of block x = 0
-    OutCtx oc;
-    // k_tile_mfma_p with a unit split Z > 1: XCD-aware ids.  The Z workgroups of a slab stage the
-    // same input; consecutive ids go to different XCDs (private L2s), so they are laid out as
-    // id = 8*(chunk*Z + z) + xcd  <->  slab = 8*chunk + xcd: same XCD, adjacent in dispatch order.
-    int32_t xz, nx;      // Z (0: plain 3-D grid), number of slabs
-    int32_t halves, scratch_off; // k_tile_mfma: a row tile's two half-chains on two waves (sum through LDS at scratch_off, in elements)
-};
-
-// Stage the input slab of one workgroup: samples [bw*Mc + i_min, +x_count) of column (clip, ch)
-// into LDS as Real, row-padded (address n + pad*(n/Mc)), zero outside the signal.  x_count and
-// i_min are multiples of 4 (host geometry).  Each thread first ISSUES up to UNR independent
-// 4-sample loads (16-byte global loads when the source is contiguous and aligned), then converts
-// and writes them, so that the HBM latency is paid once per batch rather than once per sample.
-template <typename IO, typename Real, bool ALIGNED>
-__device__ __forceinline__ void stage_slab(const TileArgs &a, Real *xs, uint32_t clip, uint32_t ch,
-                                           int64_t bw)
-{
-    typedef IO IO4 __attribute__((ext_vector_type(4)));
-    constexpr int UNR = 4;
-    const int32_t Mc = (int32_t)a.Mc, pad = a.pad;
-    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-    const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
-    const bool vec = a.ifs == 1 && ((loc_base & 3) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(xin) & (4 * sizeof(IO) - 1)) == 0);
-    const int32_t n4 = a.x_count >> 2;
-    const int32_t stride = (int32_t)blockDim.x;
-    for (int32_t q0 = threadIdx.x; q0 < n4; q0 += stride * UNR) {
-        IO4 v[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int32_t q = q0 + u * stride;
-            v[u] = (IO4){0, 0, 0, 0};
-            if (q < n4) {
-                const int64_t l = loc_base + ((int64_t)q << 2);
-                if (vec && l >= 0 && l + 3 < a.in_frames) {
-                    v[u] = *reinterpret_cast<const IO4 *>(xin + l);
-                } else {
-                    if (l >= 0 && l < a.in_frames) v[u].x = xin[l * a.ifs];
-                    if (l + 1 >= 0 && l + 1 < a.in_frames) v[u].y = xin[(l + 1) * a.ifs];
-                    if (l + 2 >= 0 && l + 2 < a.in_frames) v[u].z = xin[(l + 2) * a.ifs];
-                    if (l + 3 >= 0 && l + 3 < a.in_frames) v[u].w = xin[(l + 3) * a.ifs];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int32_t q = q0 + u * stride;
-            if (q < n4) {
-                const int32_t n = q << 2, row = n / Mc, rem = n - row * Mc;
-                Real *dst = xs + n + pad * row;
-                if (ALIGNED) { // Mc % 4 == 0 and pad % 4 == 0: the quad never straddles a row
-                    typedef Real R4 __attribute__((ext_vector_type(4)));
-                    R4 o = {(Real)v[u].x, (Real)v[u].y, (Real)v[u].z, (Real)v[u].w};
-                    *reinterpret_cast<R4 *>(__builtin_assume_aligned(dst, 4 * sizeof(Real))) = o;
-                } else {
-                    dst[0] = (Real)v[u].x;
-                    dst[1 + (rem + 1 >= Mc ? pad : 0)] = (Real)v[u].y;
-                    dst[2 + (rem + 2 >= Mc ? pad : 0)] = (Real)v[u].z;
-                    dst[3 + (rem + 3 >= Mc ? pad : 0)] = (Real)v[u].w;
-                }
-            }
-        }
-    }
-}
-
-// 4 consecutive staged samples of this lane's row.  The aligned form is one ds_read_b128
-// (conflict-free: the row stride is 4*odd words).
-template <typename Real> struct Quad { Real v[4]; };
-__device__ __forceinline__ Quad<float> lds_quad_aligned(const float *p)
-{
-    const float4 t = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(p, 16));
-    return Quad<float>{{t.x, t.y, t.z, t.w}};
-}
-__device__ __forceinline__ Quad<double> lds_quad_aligned(const double *p)
-{
-    const double2 a = *reinterpret_cast<const double2 *>(__builtin_assume_aligned(p, 16));
-    const double2 b = *reinterpret_cast<const double2 *>(__builtin_assume_aligned(p + 2, 16));
-    return Quad<double>{{a.x, a.y, b.x, b.y}};
-}
-
-template <typename IO, typename Real, int RT, bool ALIGNED>
-__global__ void __launch_bounds__(1024) k_tile(TileArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Real *xs = reinterpret_cast<Real *>(smem_raw);
-
-    const uint32_t col = blockIdx.y;
-    // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
-    // address derived from them) on the scalar side
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    const int32_t pb = a.pb; // periods per slab: 64, or fewer (the lanes above compute a copy of the last row and store nothing)
-    const int64_t bw = a.b_first + (int64_t)blockIdx.x * pb; // first period of this workgroup
-    const int32_t Mc = (int32_t)a.Mc, pad = a.pad;
-
-    stage_slab<IO, Real, ALIGNED>(a, xs, clip, ch, bw);
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const bool live = lane < pb;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_waves = a.n_waves; // waves that compute (all of them, or the first few of a split slab's workgroup: launch_tile)
-    const Real *xl = xs + (live ? lane : pb - 1) * (Mc + pad);
-    const int64_t b = bw + lane; // this lane's period
-    typedef const __attribute__((address_space(4))) Real *CPtr;
-
-    // whole workgroup inside the requested output range? (uniform) -> stores need no per-sample test
-    const bool interior = pb == 64 && bw * a.Lc >= a.out_k0 && (bw + 64) * a.Lc <= a.out_k0 + a.out_frames;
-    IO *const yo = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs +
-                   (b * a.Lc - a.out_k0) * a.ofs; // this lane's period start (may be out of range)
-
-    // (few slabs: the row tiles of a slab are spread over gridDim.z workgroups, each staging the slab — launch_tile)
-    for (int rt_ = wave < n_waves ? wave + n_waves * (int)blockIdx.z : a.n_rt; rt_ < a.n_rt; rt_ += n_waves * (int)gridDim.z) {
-        // keep the tile index (and everything derived from it) provably wave-uniform: the
-        // coefficient loads below must be scalar (s_load), not per-lane
-        const int rt = __builtin_amdgcn_readfirstlane(rt_);
-        const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]);
-        const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
-        CPtr tL = (CPtr)((const Real *)a.tab + (size_t)(rt * 2 + 0) * a.I_h * RT);
-        CPtr tR = (CPtr)((const Real *)a.tab + (size_t)(rt * 2 + 1) * a.I_h * RT);
-        Real accL[RT], accR[RT];
-#pragma unroll
-        for (int rr = 0; rr < RT; ++rr) { accL[rr] = 0; accR[rr] = 0; }
-
-        // left half: ascending inputs
-        {
-            int32_t e = eL0, padoff = pad * (e / Mc), next = (e / Mc + 1) * Mc;
-            for (int32_t q = 0; q < a.I_h; q += 4) {
-                Quad<Real> x;
-                if (ALIGNED) {
-                    x = lds_quad_aligned(xl + e + padoff);
-                } else {
-                    // a chunk may straddle row-padding points: resolve each sample separately
-                    const int32_t e1 = e + 1, e2 = e + 2, e3 = e + 3;
-                    if (pad) {
-                        x.v[0] = xl[e + pad * (e / Mc)];
-                        x.v[1] = xl[e1 + pad * (e1 / Mc)];
-                        x.v[2] = xl[e2 + pad * (e2 / Mc)];
-                        x.v[3] = xl[e3 + pad * (e3 / Mc)];
-                    } else {
-                        x.v[0] = xl[e]; x.v[1] = xl[e1]; x.v[2] = xl[e2]; x.v[3] = xl[e3];
-                    }
-                }
-                CPtr t = tL + (size_t)q * RT;
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                    for (int rr = 0; rr < RT; ++rr) accL[rr] = fma_r(t[ii * RT + rr], x.v[ii], accL[rr]);
-                e += 4;
-                if (e >= next) { padoff += pad; next += Mc; }
-            }
-        }
-        // right half: descending inputs (chunk = 4 ascending addresses consumed high to low)
-        {
-            int32_t e = eR0, padoff = pad * (e / Mc), lo = (e / Mc) * Mc;
-            for (int32_t q = 0; q < a.I_h; q += 4) {
-                Quad<Real> x;
-                if (ALIGNED) {
-                    x = lds_quad_aligned(xl + e + padoff);
-                } else {
-                    const int32_t e1 = e + 1, e2 = e + 2, e3 = e + 3;
-                    if (pad) {
-                        x.v[0] = xl[e + pad * (e / Mc)];
-                        x.v[1] = xl[e1 + pad * (e1 / Mc)];
-                        x.v[2] = xl[e2 + pad * (e2 / Mc)];
-                        x.v[3] = xl[e3 + pad * (e3 / Mc)];
-                    } else {
-                        x.v[0] = xl[e]; x.v[1] = xl[e1]; x.v[2] = xl[e2]; x.v[3] = xl[e3];
-                    }
-                }
-                CPtr t = tR + (size_t)q * RT;
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                    for (int rr = 0; rr < RT; ++rr) accR[rr] = fma_r(t[ii * RT + rr], x.v[3 - ii], accR[rr]);
-                e -= 4;
-                if (e < lo) { padoff -= pad; lo -= Mc; }
-            }
-        }
-        // store: output k = b*Lc + rt*RT + rr
-        const int32_t r0 = rt * RT;
-        IO *const yt = yo + (int64_t)r0 * a.ofs;
-        if (interior && r0 + RT <= a.Lc) {
-#pragma unroll
-            for (int rr = 0; rr < RT; ++rr)
-                store_out<Real>(yt + rr * a.ofs, accL[rr] + accR[rr], a.oc, ch, b * a.Lc + r0 + rr);
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < RT; ++rr) {
-                const int64_t k = b * a.Lc + r0 + rr, idx = k - a.out_k0;
-                if (live && r0 + rr < a.Lc && idx >= 0 && idx < a.out_frames)
-                    store_out<Real>(yt + rr * a.ofs, accL[rr] + accR[rr], a.oc, ch, k);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_tile_mfma — f32 engine.  Same tiling as k_tile (64 periods x 16 output phases per wavefront),
-// executed on the f32-input matrix pipe: one v_mfma_f32_16x16x4_f32 adds, for 16 phases x 16
-// periods, the contributions of 4 consecutive input samples,
-//     D[r][j] += sum_{k=0..3} C'[r][e+k] * x[period j][e+k],
-// evaluated by the hardware as the k-ordered chain fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C))))
-// with one rounding per product (MI355X guide §3 "FP32-input MFMA": bit-for-bit an fmaf chain) —
-// i.e. exactly the canonical order.  The right half-chain maps k to DESCENDING input index.
-// It is used because this FIR is FMA-bound (592 flop per 8.35 algorithmic bytes, 3.6x the ridge):
-// both operands are per-lane VGPRs (coefficients: one coalesced 256-byte global load per chunk;
-// samples: four conflict-free ds_read_b32), so nothing has to squeeze through the SGPR file, and
-// the f32 MFMA rate equals the f32 VALU rate (64 FLOP/clk/SIMD) while leaving the VALU free for
-// addressing.  It is NOT a reshaping into a dense GEMM for low-precision throughput: same flops,
-// same f32 arithmetic, same results.
-// Operand layouts (16x16x4): A lane l = C'[row l&15][k = l>>4]; B lane l = x[period l&15][k = l>>4];
-// D lane l, reg v = D[row 4*(l>>4)+v][period l&15].
-// ---------------------------------------------------------------------------------------------
-// Real = double (round 3): the float64 engine (float64 / int32 I/O) on v_mfma_f64_16x16x4_f64.  The hardware evaluates it
-// as the same k-ordered fma chain, one rounding per product — bitwise equal to std::fma chains on 51 200 random elements
-// of 8 chained instructions (tools/ubench/mfma_f64_order.hip; the descending chain, pairwise sums and fma trees all
-// differ) — so the canonical order holds and the oracle's port_f64 is reproduced bit for bit.  Two differences from
-// the f32 form: the accumulator layout (lane l, register v = row (l >> 4) + 4 v, MI355X guide §3, where the f32 form
-// has row 4 (l >> 4) + v) and the slab (8 bytes per sample: NG = 4, 2 or 1 groups of 16 periods, whatever fits LDS).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-template <typename Real> struct MfmaOf;
-template <> struct MfmaOf<float> {
-    typedef f32x4 Acc;
-    static __device__ __forceinline__ Acc mac(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int kq, int v) { return 4 * kq + v; }
-};
-template <> struct MfmaOf<double> {
-    typedef f64x4 Acc;
-    static __device__ __forceinline__ Acc mac(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int kq, int v) { return kq + 4 * v; }
-};
-
-template <typename IO, typename Real = float, int NG = 4>
-__global__ void __launch_bounds__(1024) k_tile_mfma(TileArgs a)
-{
-    typedef typename MfmaOf<Real>::Acc Acc;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Real *xs = reinterpret_cast<Real *>(smem_raw);
-
-    const uint32_t col = blockIdx.y;
-    // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
-    // address derived from them) on the scalar side
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    const int64_t bw = a.b_first + (int64_t)blockIdx.x * (16 * NG);
-    const int32_t Mc = (int32_t)a.Mc, pad = a.pad, S = Mc + pad;
-
-    if (!(a.dbg & 1)) stage_slab<IO, Real, false>(a, xs, clip, ch, bw);
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int kq = lane >> 4, j = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_waves = a.n_waves;
-    const int32_t n_chunks = a.I_h >> 2;
-    const Real *xrow = xs + j * S; // period j of group 0; group g adds 16*g*S
-
-    const bool interior = bw * a.Lc >= a.out_k0 && (bw + 16 * NG) * a.Lc <= a.out_k0 + a.out_frames;
-    IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
-
-    // Small jobs (a.halves, round 3): a row tile's left and right half-chains run on TWO waves — a chain of ~440 k-steps
-    // is bound by its per-step address arithmetic, whatever the number of MFMAs it feeds, and the two halves are
-    // independent until their sum — and meet through LDS: wave 2p writes its accumulators, the workgroup synchronises,
-    // wave 2p + 1 adds its own (left + right, as ever) and stores.  Every wave then runs the same number of rounds.
-    const bool halves = a.halves != 0;
-    const int units = halves ? n_waves >> 1 : n_waves;           // row tiles per round of this workgroup
-    const int pw = halves ? wave >> 1 : wave, side = halves ? wave & 1 : 2; // side 0: left half, 1: right half, 2: both
-    const int stride_rt = units * (int)gridDim.z;
-    const int rounds = halves ? (a.n_rt + stride_rt - 1) / stride_rt : 0;
-    Real *const scratch = xs + a.scratch_off;
-    int round = 0;
-    for (int rt_ = wave < n_waves ? pw + units * (int)blockIdx.z : a.n_rt; halves ? round < rounds : rt_ < a.n_rt; rt_ += stride_rt, ++round) { // (gridDim.z: see k_tile)
-        const bool active = rt_ < a.n_rt;
-        const int rt = __builtin_amdgcn_readfirstlane(active ? rt_ : 0);
-        const int32_t eL0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]);
-        const int32_t eR0 = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
-        const size_t half_stride = (size_t)(a.I_h + 16) * 16; // + 4 chunks of prefetch slack
-        const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride; // (wave-uniform: lanes add their column in the load)
-        const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride;
-        Acc accL[NG], accR[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { accL[g] = (Acc){0, 0, 0, 0}; accR[g] = (Acc){0, 0, 0, 0}; }
-
-        // The coefficient operand of the next group of G chunks is fetched into registers while
-        // the current group's 4*G MFMAs run (one VGPR per chunk).  The prefetch pointer is made
-        // opaque so that the compiler cannot fold the software pipeline back into load-then-use.
-        constexpr int G = 4; // n_chunks is a multiple of G (host geometry); tables carry G chunks of slack
-        // One half-chain, software-pipelined one GROUP (four chunks) ahead for both operands (round 3): the B values of
-        // group q + 1 (G x NG ds_read_b32) and the A values of group q + 1 (G loads) are issued before group q's MFMAs.
-        // Before, every MFMA waited for its own LDS read (ds_read; s_waitcnt lgkmcnt(0); v_mfma — four LDS round trips
-        // per group), and the timing-ablation switches sat inside the loop as branches.
-        auto chains = [&](auto pad0_tag) {
-        constexpr bool PAD0 = decltype(pad0_tag)::value; // unpadded slab: offset == input index
-        auto half = [&](auto right_tag, Acc (&acc)[NG], const Real *tab_half, int32_t e_first) {
-            constexpr bool RIGHT = decltype(right_tag)::value;
-            // (coefficients through a buffer descriptor — scalar offsets, no vector address arithmetic: see mfma_half_chain)
-            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)tab_half, 0, 0x40000000, 0x00020000);
-            const int lane_bytes = lane * (int)sizeof(Real);
-            auto tab_at = [&](int32_t idx) -> Real {
-                if constexpr (sizeof(Real) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(trs, lane_bytes, idx * 4, 0));
-                else return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(trs, lane_bytes, idx * 8, 0));
-            };
-            // left: lane k handles input e = eL0 + 4q + k (ascending); right: chunk q covers inputs [eR0 - 4q, eR0 - 4q + 3]
-            // and lane k takes the (3-k)-th of them, so that k = 0 is the highest index (descending order)
-            int32_t e = e_first;
-            int32_t off = PAD0 ? e : e + pad * (e / Mc);
-            int32_t edge = PAD0 ? 0 : RIGHT ? (e / Mc) * Mc : (e / Mc + 1) * Mc; // next period boundary in e's direction
-            auto load_b1 = [&](Real (&b)[NG]) { // one chunk's B values, then on to the next chunk
-                const Real *px = xrow + off;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) b[g] = px[16 * g * S];
-                if (!RIGHT) { off += 4; if (!PAD0) { e += 4; if (e >= edge) { off += pad; edge += Mc; } } }
-                else { off -= 4; if (!PAD0) { e -= 4; if (e < edge) { off -= pad; edge -= Mc; } } }
-            };
-            auto load_b = [&](auto &b) {
-#pragma unroll
-                for (int u = 0; u < G; ++u) load_b1(b[u]);
-            };
-            int32_t poff = 0; // element offset of the group being prefetched (wave-uniform)
-            // (float64 with four period groups: 64 registers of accumulators leave no room for groups of B values in the
-            //  128 a 16-wave workgroup may use — there a chunk's B values are loaded in front of its own MFMAs, as before)
-            constexpr bool AHEAD = sizeof(Real) * NG <= 16;
-            Real ac[G], an[G], bc[AHEAD ? G : 1][NG], bn[AHEAD ? G : 1][NG];
-#pragma unroll
-            for (int u = 0; u < G; ++u) ac[u] = tab_at(u * 64);
-            if constexpr (AHEAD) load_b(bc);
-            for (int32_t q = 0; q < n_chunks; q += G) {
-                poff += G * 64;
-                asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
-#pragma unroll
-                for (int u = 0; u < G; ++u) an[u] = tab_at(poff + u * 64); // (tables carry G chunks of slack)
-                if constexpr (AHEAD) { if (q + G < n_chunks) load_b(bn); } // (the slab carries none: no B read past the chain's last group)
-                __builtin_amdgcn_sched_barrier(0); // the prefetches are issued BEFORE this group's MFMAs
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    if constexpr (!AHEAD) load_b1(bc[0]);
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) acc[g] = MfmaOf<Real>::mac(ac[u], bc[AHEAD ? u : 0][g], acc[g]);
-                }
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    ac[u] = an[u];
-                    if constexpr (AHEAD) {
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) bc[u][g] = bn[u][g];
-                    }
-                }
-            }
-        };
-        if (active && side != 1) half(std::false_type{}, accL, tL, eL0 + kq);
-        if (active && side != 0) half(std::true_type{}, accR, tR, eR0 + 3 - kq);
-        };
-        if (pad == 0) chains(std::true_type{}); else chains(std::false_type{});
-        if (halves) { // the left half's accumulators to the wave that holds the right half
-            if (round) __syncthreads(); // (the scratch of the round before has been read)
-            if (active && side == 0) {
-#pragma unroll
-                for (int g = 0; g < NG; ++g)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) scratch[((pw * NG + g) * 4 + v) * 64 + lane] = accL[g][v];
-            }
-            __syncthreads();
-            if (!active || side == 0) continue;
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) accL[g][v] = scratch[((pw * NG + g) * 4 + v) * 64 + lane];
-        }
-        // lane holds rows rt*16 + row(kq, v) (v = 0..3; f32: 4 kq + v, f64: kq + 4 v) of periods bw + 16g + j
-        const int32_t rbase = rt * 16;
-        if ((a.dbg & 8) && accL[0][0] != (Real)12345) continue;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int64_t b = bw + 16 * g + j;
-            const int64_t kb = b * a.Lc + rbase;
-            IO *const yt = ybase + (kb - a.out_k0) * a.ofs;
-            if (interior && rbase + 16 <= a.Lc) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int r = MfmaOf<Real>::row(kq, v);
-                    store_out<Real>(yt + r * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, kb + r);
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int r = MfmaOf<Real>::row(kq, v);
-                    const int64_t idx = kb + r - a.out_k0;
-                    if (rbase + r < a.Lc && idx >= 0 && idx < a.out_frames)
-                        store_out<Real>(yt + r * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, kb + r);
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_tile_mfma_p — the fast form of k_tile_mfma for input periods that are a multiple of 16
-// samples (48k->44.1k: Mc = 160).  Measured on MI355X (tools/ubench/mfma_rate.hip): the f32 MFMA
-// pipe sustains 145-154 TFLOP/s on its own but loses ~4 cycles per VALU instruction issued
-// beside it, so the inner loop must contain (almost) nothing but MFMAs.  Therefore:
-//   * the slab is stored K-DE-INTERLEAVED in four LDS planes (plane k holds the samples whose
-//     offset is == k mod 4), so ONE ds_read_b128 hands lane (j, k) its B operands for FOUR
-//     consecutive chunks; plane row stride R = Mc/4 + padR with R/4 odd and plane stride a
-//     multiple of 64 words makes every 16-lane read group conflict-free;
-//   * the A operands of four chunks arrive with ONE coalesced global_load_dwordx4 per lane,
-//     prefetched one group (16 MFMAs) ahead;
-//   * all offsets inside the loop are wave-uniform scalars: one v_add per 16 MFMAs.
-// Groups of 16 inputs are aligned to 16 (never straddle a slab row).  Same canonical arithmetic.
-// ---------------------------------------------------------------------------------------------
-// One half-chain of a work unit (16 phases x 32 periods), software-pipelined inside the wave:
-// the B operands (two ds_read_b128) of group g+1 and the A operand (one global_load_dwordx4) of
-// group g+2 are in flight while the 8 MFMAs of group g issue, so that a single wave per SIMD keeps
-// the matrix pipe busy.  The loop is unrolled by two groups with ping-pong registers (no copies).
-// RIGHT = false: ascending groups, chunk c uses component c; true: descending, component 3-c.
-// (round 3: the table is read through a buffer descriptor — `buffer_load_dwordx4 v, v_lane16, s[rsrc], s_offset offen`:
-//  wave-uniform base in the descriptor, the lane's 16-byte column as the one vector offset, the group as a SCALAR offset —
-//  so that an A load costs no vector-ALU instruction; as a per-lane pointer plus scalar offset every load came with a
-//  64-bit v_lshl_add, and beside a busy matrix pipe each vector-ALU instruction costs ~4 pipe cycles.  Plain pointer
-//  arithmetic does not get there: base + lane offset is hoisted out of the loop as one 64-bit per-lane pointer.)
-template <bool RIGHT>
-__device__ __forceinline__ void mfma_half_chain(f32x4 (&acc)[2], const char *tb, uint32_t lane16, const float *xb,
-                                                int32_t e0, int32_t n_groups, int32_t Mc, int32_t R,
-                                                int32_t padR)
-{
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)tb, 0, 0x40000000, 0x00020000);
-    auto t_at = [&](int32_t idx) { // element idx of the lane's column
-        // (bit_cast of the builtin's own result: assigning it to an ext_vector_type of unsigned first silently yields
-        //  four copies of its first element with this compiler)
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(trs, (int)lane16, idx * 16, 0));
-    };
-    int32_t rem = e0 % Mc, fo = (e0 / Mc) * R + (rem >> 2); // wave-uniform plane offset of the next B read
-    auto ldb = [&](float4 &b0, float4 &b1) {
-        const float *px = xb + fo;
-        b0 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px, 16));
-        b1 = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(px + 16 * R, 16));
-        if (!RIGHT) { fo += 4; rem += 16; if (rem == Mc) { rem = 0; fo += padR; } }
-        else { fo -= 4; rem -= 16; if (rem < 0) { rem += Mc; fo -= padR; } }
-    };
-#define HIPSOXR_MFMA8(AV, B0, B1)                                                              \
-    if (!RIGHT) {                                                                               \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.x, B0.x, acc[0], 0, 0, 0);             \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.x, B1.x, acc[1], 0, 0, 0);             \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.y, B0.y, acc[0], 0, 0, 0);             \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.y, B1.y, acc[1], 0, 0, 0);             \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.z, B0.z, acc[0], 0, 0, 0);             \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.z, B1.z, acc[1], 0, 0, 0);             \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.w, B0.w, acc[0], 0, 0, 0);             \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.w, B1.w, acc[1], 0, 0, 0);             \
-    } else {                                                                                    \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.x, B0.w, acc[0], 0, 0, 0);             \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.x, B1.w, acc[1], 0, 0, 0);             \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.y, B0.z, acc[0], 0, 0, 0);             \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.y, B1.z, acc[1], 0, 0, 0);             \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.z, B0.y, acc[0], 0, 0, 0);             \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.z, B1.y, acc[1], 0, 0, 0);             \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.w, B0.x, acc[0], 0, 0, 0);             \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV.w, B1.x, acc[1], 0, 0, 0);             \
-    }
-    // A operands: ring of 4 registers, each reloaded for group g+4 right after group g's MFMAs
-    // (3 groups = 24 MFMAs = 768 pipe cycles ahead of use: an L2 round trip).  B operands: one
-    // group ahead (LDS latency).  sched_barrier(0) pins "loads first, then this group's MFMAs".
-    float4 a0 = t_at(0), a1 = t_at(64), a2 = t_at(128), a3 = t_at(192);
-    float4 bE0, bE1, bO0, bO1;
-    ldb(bE0, bE1);                  // B of group 0
-    int32_t poff = 192;             // table offset (float4) of the newest A in flight
-    int32_t grp = 0;
-#define HIPSOXR_STEP(AR, BC0, BC1, BN0, BN1)                                                   \
-    ldb(BN0, BN1);                  /* B of the next group */                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-    HIPSOXR_MFMA8(AR, BC0, BC1)                                                                 \
-    poff += 64;                                                                                 \
-    asm volatile("" : "+s"(poff)); /* opaque: the pipeline must not be re-rolled */             \
-    AR = t_at(poff);                /* A of group +4 */
-    for (; grp + 3 < n_groups; grp += 4) {
-        HIPSOXR_STEP(a0, bE0, bE1, bO0, bO1)
-        HIPSOXR_STEP(a1, bO0, bO1, bE0, bE1)
-        HIPSOXR_STEP(a2, bE0, bE1, bO0, bO1)
-        HIPSOXR_STEP(a3, bO0, bO1, bE0, bE1)
-    }
-    // 0..3 remaining groups (their A operands are already in a0..a2, B of the first in bE)
-    if (grp < n_groups) {
-        ldb(bO0, bO1);
-        __builtin_amdgcn_sched_barrier(0);
-        HIPSOXR_MFMA8(a0, bE0, bE1)
-        if (grp + 1 < n_groups) {
-            ldb(bE0, bE1);
-            __builtin_amdgcn_sched_barrier(0);
-            HIPSOXR_MFMA8(a1, bO0, bO1)
-            if (grp + 2 < n_groups) {
-                __builtin_amdgcn_sched_barrier(0);
-                HIPSOXR_MFMA8(a2, bE0, bE1)
-            }
-        }
-    }
-#undef HIPSOXR_STEP
-#undef HIPSOXR_MFMA8
-}
-
-// Stage one slab of k_tile_mfma_p: sample n -> plane (n & 3), index (n / Mc) * R + (n % Mc) / 4.
-// The CU's matrix pipes are saturated by other waves while this runs, and every ordinary VALU
-// instruction queues behind 32-cycle MFMA issues, so the code is VALU-lean: interior slabs (the
-// common case) take a path with no bounds tests, no division (the (row, column) of a thread's next
-// quad advances incrementally) and 32-bit offsets from a wave-uniform base; loads are issued in
-// batches of UNR before any is consumed.
-template <typename IO, typename Real = float>
-__device__ __forceinline__ void stage_planes(const TileArgs &a, Real *xs, uint32_t clip, uint32_t ch,
-                                             int64_t bw)
-{
-    typedef IO IO4 __attribute__((ext_vector_type(4)));
-    constexpr int UNR = 4;
-    const int32_t Mc = (int32_t)a.Mc, R = a.rowR, PLANE = a.plane;
-    const IO *xin = (const IO *)a.in + (int64_t)clip * a.ics + (int64_t)ch * a.ichs;
-    const int64_t loc_base = bw * a.Mc + a.i_min - a.in_abs0;
-    const int32_t n4 = a.x_count >> 2, stride = (int32_t)blockDim.x, Mq = Mc >> 2;
-    const bool fast = a.ifs == 1 && ((loc_base & 3) == 0) && loc_base >= 0 &&
-                      loc_base + a.x_count <= a.in_frames &&
-                      ((reinterpret_cast<uintptr_t>(xin) & (4 * sizeof(IO) - 1)) == 0);
-    if (fast) {
-        const IO4 *src = reinterpret_cast<const IO4 *>(xin + loc_base); // wave-uniform base
-        const int32_t drow = stride / Mq, dcol = stride - drow * Mq;     // uniform step of (row, col)
-        int32_t q = threadIdx.x, row = q / Mq, colq = q - row * Mq;
-        while (q < n4) {
-            IO4 v[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u)
-                if (q + u * stride < n4) v[u] = src[q + u * stride];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                if (q + u * stride < n4) {
-                    const int32_t m = row * R + colq;
-                    xs[m] = (Real)v[u].x;
-                    xs[m + PLANE] = (Real)v[u].y;
-                    xs[m + 2 * PLANE] = (Real)v[u].z;
-                    xs[m + 3 * PLANE] = (Real)v[u].w;
-                }
-                row += drow; colq += dcol;
-                if (colq >= Mq) { colq -= Mq; ++row; }
-            }
-            q += stride * UNR;
-        }
-    } else {
-        for (int32_t q0 = threadIdx.x; q0 < n4; q0 += stride) {
-            const int64_t l = loc_base + ((int64_t)q0 << 2);
-            IO4 v = (IO4){0, 0, 0, 0};
-            if (l >= 0 && l < a.in_frames) v.x = xin[l * a.ifs];
-            if (l + 1 >= 0 && l + 1 < a.in_frames) v.y = xin[(l + 1) * a.ifs];
-            if (l + 2 >= 0 && l + 2 < a.in_frames) v.z = xin[(l + 2) * a.ifs];
-            if (l + 3 >= 0 && l + 3 < a.in_frames) v.w = xin[(l + 3) * a.ifs];
-            const int32_t row = q0 / Mq, m = row * R + (q0 - row * Mq);
-            xs[m] = (Real)v.x;
-            xs[m + PLANE] = (Real)v.y;
-            xs[m + 2 * PLANE] = (Real)v.z;
-            xs[m + 3 * PLANE] = (Real)v.w;
-        }
-    }
-}
-
-template <typename IO>
-__global__ void __launch_bounds__(1024, 2) k_tile_mfma_p(TileArgs a)
-{
-    typedef float Real;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int32_t Mc = (int32_t)a.Mc, R = a.rowR, PLANE = a.plane, padR = R - Mc / 4;
-    Real *xs = reinterpret_cast<Real *>(smem_raw) + R; // one row of slack below (pipelined reads run one group past the end)
-
-    const uint32_t col = blockIdx.y;
-    // run-time division goes through the vector ALU; readfirstlane keeps the results (and every
-    // address derived from them) on the scalar side
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    uint32_t bxi = blockIdx.x, bz = blockIdx.z, nz = gridDim.z;
-    if (a.xz) {
-        const uint32_t slot = blockIdx.x >> 3;
-        nz = (uint32_t)a.xz;
-        bz = __builtin_amdgcn_readfirstlane(slot % nz);
-        bxi = __builtin_amdgcn_readfirstlane((slot / nz) * 8 + (blockIdx.x & 7u));
-        if (bxi >= (uint32_t)a.nx) return; // grid.x is padded to a multiple of 8 slabs
-    }
-    const int64_t bw = a.b_first + (int64_t)bxi * a.pb; // slabs of 64 periods; of 32 for jobs of few slabs (launch_tile)
-    const int64_t k_end = a.out_k0 + a.out_frames;
-    unsigned long long *tr = a.trace ? a.trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 : nullptr;
-    int tri = 0;
-#define HIPSOXR_STAMP() do { if (tr && (threadIdx.x & 63) == 0 && tri < 16) tr[tri] = __builtin_amdgcn_s_memtime(); ++tri; } while (0)
-    HIPSOXR_STAMP();
-
-    stage_planes<IO>(a, xs, clip, ch, bw);
-    HIPSOXR_STAMP();
-    __syncthreads();
-    HIPSOXR_STAMP();
-
-    const int lane = threadIdx.x & 63;
-    const int kq = lane >> 4, j = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_waves = a.n_waves;
-    const int32_t n_groups = a.I_h >> 4;
-    const size_t half_stride = (size_t)(n_groups + 4) * 64; // float4 per half table (+4 groups of prefetch slack)
-    const Real *xL = xs + kq * PLANE + j * R;        // left : lane k reads plane k
-    const Real *xR = xs + (3 - kq) * PLANE + j * R;  // right: lane k reads plane 3-k
-    IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
-    const bool interior = bw * a.Lc >= a.out_k0 && (bw + a.pb) * a.Lc <= k_end;
-    const int hp = a.pb >> 5; // units per row tile: halves of a 64-period slab, or the one 32-period slab
-    // (rotating which waves take the odd units of a split slab with the slab index changes nothing: measured)
-
-    // Work unit = (tile, half of the 64 periods).  A workgroup runs 4 waves — exactly one per SIMD,
-    // because 10-wave workgroups land 3/3/2/2 on the SIMDs and leave 17 % of the matrix pipe idle
-    // (tools/ubench/mfma_loop.hip) — and its 2*n_rt equal units are dealt round-robin.
-    // Small jobs additionally split a slab's units over gridDim.z workgroups (each stages the slab).
-    for (int u_ = wave + n_waves * (int)bz; u_ < hp * a.n_rt; u_ += n_waves * (int)nz) {
-        const int unit = __builtin_amdgcn_readfirstlane(u_);
-        const int rt = hp == 2 ? unit >> 1 : unit, ph = hp == 2 ? unit & 1 : 0; // periods 32*ph .. 32*ph + 31
-        const int32_t wL = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]), wR = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
-        const int32_t eL0 = wL & 0xffffff, eR0 = wR & 0xffffff; // multiples of 16
-        const int32_t gL = (a.dbg & 16) ? n_groups : wL >> 24, gR = (a.dbg & 16) ? n_groups : wR >> 24; // groups this tile's half-chains need (build_mfma_planes; HIPSOXR_DEBUG_FLAGS 16: all of them)
-        const char *tL = (const char *)a.tab + (size_t)(rt * 2 + 0) * half_stride * 16; // (wave-uniform; lanes add lane * 16)
-        const char *tR = tL + half_stride * 16;
-        const uint32_t lane16 = (uint32_t)lane * 16;
-        f32x4 accL[2], accR[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) { accL[g] = (f32x4){0, 0, 0, 0}; accR[g] = (f32x4){0, 0, 0, 0}; }
-
-        mfma_half_chain<false>(accL, tL, lane16, xL + ph * 32 * R, eL0, gL, Mc, R, padR);
-        mfma_half_chain<true>(accR, tR, lane16, xR + ph * 32 * R, eR0, gR, Mc, R, padR);
-        HIPSOXR_STAMP();
-
-        const int32_t r0 = rt * 16 + 4 * kq;
-        if (interior && rt * 16 + 16 <= a.Lc && a.ofs == 1) {
-            // whole unit in range, unit stride: 32-bit offsets from the slab's first output
-            IO *const yw = ybase + (bw * a.Lc - a.out_k0);           // wave-uniform
-            const int32_t o0 = (32 * ph + j) * (int32_t)a.Lc + r0;   // this lane, group 0
-            const int64_t kw = bw * a.Lc;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int32_t o = o0 + 16 * g * (int32_t)a.Lc;
-#pragma unroll
-                for (int vv = 0; vv < 4; ++vv)
-                    store_out<Real>(yw + o + vv, accL[g][vv] + accR[g][vv], a.oc, ch, kw + o + vv);
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int64_t b = bw + 32 * ph + 16 * g + j;
-                const int64_t k0 = b * a.Lc + r0;
-                IO *const yt = ybase + (k0 - a.out_k0) * a.ofs;
-#pragma unroll
-                for (int vv = 0; vv < 4; ++vv) {
-                    const int64_t idx = k0 + vv - a.out_k0;
-                    if (r0 + vv < a.Lc && idx >= 0 && idx < a.out_frames)
-                        store_out<Real>(yt + vv * a.ofs, accL[g][vv] + accR[g][vv], a.oc, ch, k0 + vv);
-                }
-            }
-        }
-    }
-    tri = 15;
-    HIPSOXR_STAMP();
-#undef HIPSOXR_STAMP
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_tile_mfma64_p — the float64 engine (float64 / int32 I/O) in the planar form (round 3), for input periods that are
-// a multiple of 16.  Same idea as k_tile_mfma_p: the slab k-de-interleaved into four LDS planes, so that every offset
-// inside a half-chain is a wave-uniform scalar and the vector ALU — which costs the matrix pipe ~4 cycles per
-// instruction while it runs beside it — does nothing but issue MFMAs: k_tile_mfma<IO, double, NG> spends ten VALU
-// instructions per v_mfma_f64 on per-lane index bookkeeping (rocprofv3: 11.3 M VALU against 1.08 M MFMA per launch)
-// and reaches 18 TFLOP/s of the 78 the pipe sustains (tools/ubench/mfma_f64_rate.hip).  What differs from the f32 form:
-//   * v_mfma_f64_16x16x4_f64 takes 64 cycles, twice the f32 form: a slab is 32 periods (8 bytes per sample: 51 KB at
-//     48k -> 44.1k, three workgroups per CU), a work unit is one row tile across all 32 periods (2 accumulators);
-//   * a 16-byte access carries TWO samples: a group of 16 inputs is two ds_read_b128 per 16 periods and two
-//     global_load_dwordx4 of coefficients per lane, both one group (8 MFMAs = 512 pipe cycles) ahead of use;
-//   * the accumulator layout is row (lane >> 4) + 4 v (MfmaOf<double>::row).
-// Canonical order as everywhere: groups ascending (left) / descending (right), chunks and k inside them likewise.
-// ---------------------------------------------------------------------------------------------
-// NG = 2: one unit = a row tile across the slab's 32 periods (two accumulators share every coefficient load);
-// NG = 1: a unit is a row tile across 16 periods — twice as many, half as long: the four waves of a workgroup then
-// share 2 n_rt units evenly where n_rt is not a multiple of four (147 phases = 10 tiles: 3/3/2/2 -> 5/5/5/5).
-template <bool RIGHT, int NG>
-__device__ __forceinline__ void mfma64_half_chain(f64x4 (&acc)[NG], const double *tbase, uint32_t lane_bytes, const double *xb, int32_t e0,
-                                                  int32_t n_groups, int32_t Mc, int32_t R, int32_t padR)
-{
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    // (coefficients through a buffer descriptor, the group as a scalar offset: see mfma_half_chain)
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)tbase, 0, 0x40000000, 0x00020000);
-    int32_t rem = e0 % Mc, fo = (e0 / Mc) * R + (rem >> 2); // wave-uniform plane offset of the next B read
-    auto ldb = [&](d2 (&b)[2 * NG]) { // period j (and j + 16), four consecutive chunk columns each
-        const double *px = xb + fo;
-        b[0] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(px, 16));
-        b[1] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(px + 2, 16));
-        if (NG == 2) {
-            b[2 * (NG - 1)] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(px + 16 * R, 16));
-            b[2 * (NG - 1) + 1] = *reinterpret_cast<const d2 *>(__builtin_assume_aligned(px + 16 * R + 2, 16));
-        }
-        if (!RIGHT) { fo += 4; rem += 16; if (rem == Mc) { rem = 0; fo += padR; } }
-        else { fo -= 4; rem -= 16; if (rem < 0) { rem += Mc; fo -= padR; } }
-    };
-    auto lda = [&](d2 (&av)[2], int32_t off) { // this lane's coefficients of the group's four chunks
-        av[0] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(trs, (int)lane_bytes, off * 8, 0));
-        av[1] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(trs, (int)lane_bytes, off * 8 + 16, 0));
-    };
-    d2 ac[2], an[2], bc[2 * NG], bn[2 * NG];
-    lda(ac, 0);
-    ldb(bc);
-    int32_t poff = 0; // table offset (doubles) of the group whose coefficients are in flight (wave-uniform)
-    for (int32_t grp = 0; grp < n_groups; ++grp) {
-        poff += 256;
-        asm volatile("" : "+s"(poff)); // opaque: keeps the software pipeline from being re-rolled
-        lda(an, poff);                 // (the table carries four groups of slack)
-        ldb(bn);                       // (the slab carries a row of slack at either end)
-        __builtin_amdgcn_sched_barrier(0); // next group's operands are requested BEFORE this group's MFMAs
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double av = c < 2 ? ac[0][c] : ac[1][c - 2];
-            const int m = RIGHT ? 3 - c : c; // right half-chain: chunk c is plane column 3 - c (descending input index)
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const double bv = m < 2 ? bc[2 * g][m] : bc[2 * g + 1][m - 2];
-                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[g], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) ac[i] = an[i];
-#pragma unroll
-        for (int i = 0; i < 2 * NG; ++i) bc[i] = bn[i];
-    }
-}
-
-// PB = periods per slab: 32, or 16 for jobs of few slabs (half the LDS, twice the workgroups: 563 slabs of 32 periods on
-// 256 CUs leave a fifth of them with three workgroups and the rest with two — the launch waits for the fifth).
-template <typename IO, int NG, int PB>
-__global__ void __launch_bounds__(640) k_tile_mfma64_p(TileArgs a)
-{
-    typedef double Real;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int32_t Mc = (int32_t)a.Mc, R = a.rowR, PLANE = a.plane, padR = R - Mc / 4;
-    Real *xs = reinterpret_cast<Real *>(smem_raw) + R; // one row of slack below (pipelined reads run one group past the end)
-
-    const uint32_t col = blockIdx.y;
-    const uint32_t ch = __builtin_amdgcn_readfirstlane(col % a.n_channels), clip = __builtin_amdgcn_readfirstlane(col / a.n_channels);
-    uint32_t bxi = blockIdx.x, bz = blockIdx.z, nz = gridDim.z;
-    if (a.xz) { // XCD-aware ids of a unit split (see k_tile_mfma_p)
-        const uint32_t slot = blockIdx.x >> 3;
-        nz = (uint32_t)a.xz;
-        bz = __builtin_amdgcn_readfirstlane(slot % nz);
-        bxi = __builtin_amdgcn_readfirstlane((slot / nz) * 8 + (blockIdx.x & 7u));
-        if (bxi >= (uint32_t)a.nx) return; // grid.x is padded to a multiple of 8 slabs
-    }
-    const int64_t bw = a.b_first + (int64_t)bxi * PB;
-    const int64_t k_end = a.out_k0 + a.out_frames;
-
-    stage_planes<IO, Real>(a, xs, clip, ch, bw);
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int kq = lane >> 4, j = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_waves = a.n_waves;
-    const int32_t n_groups = a.I_h >> 4;
-    const size_t half_stride = (size_t)(n_groups + 4) * 256; // doubles per half table (+4 groups of prefetch slack)
-    const Real *xL = xs + kq * PLANE + j * R;        // left : lane k reads plane k
-    const Real *xR = xs + (3 - kq) * PLANE + j * R;  // right: lane k reads plane 3-k
-    IO *const ybase = (IO *)a.out + (int64_t)clip * a.ocs + (int64_t)ch * a.ochs;
-    const bool interior = bw * a.Lc >= a.out_k0 && (bw + PB) * a.Lc <= k_end;
-
-    constexpr int UPT = PB / (16 * NG); // units per row tile
-    for (int u_ = wave + n_waves * (int)bz; u_ < UPT * a.n_rt; u_ += n_waves * (int)nz) { // unit = row tile x 16 NG periods
-        const int unit = __builtin_amdgcn_readfirstlane(u_);
-        const int rt = unit / UPT, ph = unit % UPT; // periods 16 ph ..
-        const int32_t wL = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 0]), wR = __builtin_amdgcn_readfirstlane(a.e0[rt * 2 + 1]);
-        const int32_t eL0 = wL & 0xffffff, eR0 = wR & 0xffffff; // multiples of 16
-        const int32_t gL = wL >> 24, gR = wR >> 24;             // groups this tile's half-chains need (build_mfma_planes)
-        const Real *tL = (const Real *)a.tab + (size_t)(rt * 2 + 0) * half_stride; // (wave-uniform; a lane's column starts lane * 32 bytes in)
-        const Real *tR = (const Real *)a.tab + (size_t)(rt * 2 + 1) * half_stride;
-        f64x4 accL[NG], accR[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { accL[g] = (f64x4){0, 0, 0, 0}; accR[g] = (f64x4){0, 0, 0, 0}; }
-        mfma64_half_chain<false, NG>(accL, tL, (uint32_t)lane * 32, xL + ph * 16 * R, eL0, gL, Mc, R, padR);
-        mfma64_half_chain<true, NG>(accR, tR, (uint32_t)lane * 32, xR + ph * 16 * R, eR0, gR, Mc, R, padR);
-
-        const int32_t rbase = rt * 16; // this lane: rows rbase + kq + 4 v, periods bw + 16 g + j
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int64_t b = bw + 16 * (g + ph) + j;
-            const int64_t kb = b * a.Lc + rbase;
-            IO *const yt = ybase + (kb - a.out_k0) * a.ofs;
-            if (interior && rbase + 16 <= a.Lc) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int r = kq + 4 * v;
-                    store_out<Real>(yt + r * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, kb + r);
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int r = kq + 4 * v;
-                    const int64_t idx = kb + r - a.out_k0;
-                    if (rbase + r < a.Lc && idx >= 0 && idx < a.out_frames)
-                        store_out<Real>(yt + r * a.ofs, accL[g][v] + accR[g][v], a.oc, ch, kb + r);
-                }
-            }
-        }
-    }
-}
+#include "kernels_interp.h" // k_interp, k_gather_wave, k_interp_tile, k_interp_wave
+#include "kernels_chain.h"  // k_chain, k_chain_multi, k_chain_resident
+#include "kernels_tile.h"   // k_tile, k_tile_mfma, k_tile_mfma_p, k_tile_mfma64_p
 
 // ---------------------------------------------------------------------------------------------
 // host side: device tables
