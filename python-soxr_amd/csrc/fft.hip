@@ -41,7 +41,9 @@
 #include <vector>
 
 #include "device.h"
+#ifndef FFT_FORCE_PK
 #define FFT_NO_PK // (the packed-FMA forms of fft_dev.h: +8 % on k_fft_pair2 — 124 against 114 us — and -7 % on k_fft_wave, which alone uses them)
+#endif
 #include "fft_dev.h"
 
 namespace hipsoxr {
