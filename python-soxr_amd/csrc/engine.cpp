@@ -384,6 +384,20 @@ hipsoxr_error_t hipsoxr_plan_get_bank(const hipsoxr_plan_t *h, double *dst, size
     return nullptr;
 }
 
+static uint64_t bank_hash(const double *b, size_t n)
+{
+    uint64_t hsh = 1469598103934665603ULL;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(b);
+    for (size_t i = 0; i < n * sizeof(double); ++i) { hsh ^= p[i]; hsh *= 1099511628211ULL; }
+    return hsh;
+}
+// the plan's bank is about to be replaced by `src` (which differs from it): is the plan on a bank of its own afterwards?
+static void note_bank_change(Plan &p, const double *src, size_t n)
+{
+    if (!p.custom_bank && !p.have_designed_hash) { p.designed_hash = bank_hash(p.bank.data(), p.bank.size()); p.have_designed_hash = true; }
+    p.custom_bank = !p.have_designed_hash || bank_hash(src, n) != p.designed_hash;
+}
+
 hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *h, const double *src, size_t n)
 {
     if (!h || !src) return "null argument";
@@ -391,13 +405,14 @@ hipsoxr_error_t hipsoxr_plan_set_bank(hipsoxr_plan_t *h, const double *src, size
     if (h->cached) return "this plan is shared through the plan cache (it belongs to a stream); create one with hipsoxr_plan_create";
     // The bank every rank designs for itself is deterministic: installing the root's copy of it (the broadcast's usual
     // case) changes nothing and keeps every derived table.  A bank that differs becomes the plan's filter for every
-    // engine that reads `bank`; the two-stage form, which samples the analytic prototype, declines the plan from then on.
+    // engine that reads `bank`; the two-stage form, which samples the analytic prototype, declines the plan until the designed
+    // bank is installed again (its hash is kept).
     if (std::memcmp(h->p.bank.data(), src, n * sizeof(double)) == 0) return nullptr;
     device_bank_release(&h->p);
     fft_release(&h->p);
     twostage_release(&h->p);
+    note_bank_change(h->p, src, n);
     std::memcpy(h->p.bank.data(), src, n * sizeof(double));
-    h->p.custom_bank = true;
     return nullptr;
 }
 
@@ -440,8 +455,8 @@ hipsoxr_error_t hipsoxr_plan_broadcast(hipsoxr_plan_t *h, void *nccl_comm, int r
                 device_bank_release(&h->p);
                 fft_release(&h->p);
                 twostage_release(&h->p);
+                note_bank_change(h->p, got.data(), n);
                 h->p.bank.swap(got);
-                h->p.custom_bank = true;
             }
         } else if (hipStreamSynchronize(st) != hipSuccess) {
             err = "hip sync failed";
@@ -1282,7 +1297,9 @@ static bool stream_item_prepare(hipsoxr_stream *s, const void *d_in, size_t ilen
         const int64_t n0 = first_needed(s);
         const int64_t keep_from = std::min<int64_t>(std::max<int64_t>(n0, s->in_base), s->in_base + (int64_t)s->in_fill);
         const size_t keep = s->in_fill - (size_t)(keep_from - s->in_base);
-        size_t need = keep + 16 * ilen, cap = std::max<size_t>(s->in_cap, 1024);   // room for sixteen chunks: the move runs every ~16th call
+        // room for sixteen SMALL chunks (the move then runs every ~16th call), for four of the larger ones (advisor, round 5: both
+        // buffers of a stream end up at this capacity — with thousands of grouped streams the factor is memory)
+        size_t need = keep + std::min<size_t>(16 * ilen, std::max<size_t>(4 * ilen, 65536)), cap = std::max<size_t>(s->in_cap, 1024);
         if (need > ((size_t)1 << 24)) need = keep + ilen;
         while (cap < need) cap <<= 1;
         if (s->alt_cap < cap || !s->d_in_alt) {
@@ -1419,17 +1436,27 @@ static const char *arena_take(ItemArena &ar, size_t n, hipStream_t st, ChainItem
         HIP_TRY(hipMalloc((void **)&ar.mirror, 2 * kItemsHalf * sizeof(ChainItem)));
     }
     if (ar.pos + n > kItemsHalf) { // leave this half: mark what still reads it, take the other one once ITS readers are done
+        bool lost = false; // a stream of this half can no longer be asked (its owner destroyed it: C-API callers may; torch never does)
         for (hipStream_t u : ar.used[ar.half]) {
             hipEvent_t ev = nullptr;
             if (!ar.spare.empty()) { ev = ar.spare.back(); ar.spare.pop_back(); }
-            else HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(ev, u));
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); lost = true; continue; }
+            if (hipEventRecord(ev, u) != hipSuccess) { (void)hipGetLastError(); ar.spare.push_back(ev); lost = true; continue; }
             ar.pending[ar.half].push_back(ev);
         }
-        ar.used[ar.half].clear();
+        ar.used[ar.half].clear(); // (on every path: a stream that failed once is not asked again)
         ar.half ^= 1; ar.pos = 0;
-        for (hipEvent_t ev : ar.pending[ar.half]) { HIP_TRY(hipEventSynchronize(ev)); ar.spare.push_back(ev); }
+        hipError_t bad = hipSuccess;
+        for (hipEvent_t ev : ar.pending[ar.half]) { // every event goes back to the pool, whatever its wait returns
+            const hipError_t e = hipEventSynchronize(ev);
+            if (e != hipSuccess) bad = e;
+            ar.spare.push_back(ev);
+        }
         ar.pending[ar.half].clear();
+        if (lost || bad != hipSuccess) { // whoever still reads either half is waited for the blunt way, once
+            (void)hipGetLastError();
+            HIP_TRY(hipDeviceSynchronize());
+        }
     }
     if (std::find(ar.used[ar.half].begin(), ar.used[ar.half].end(), st) == ar.used[ar.half].end()) ar.used[ar.half].push_back(st);
     *host = ar.host + ar.half * kItemsHalf + ar.pos;

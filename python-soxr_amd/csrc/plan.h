@@ -47,6 +47,10 @@ struct Plan {
     // A bank installed from outside (hipsoxr_plan_set_bank / hipsoxr_plan_broadcast) that DIFFERS from the designed one:
     // engines that derive their tables from the analytic prototype instead of `bank` (the two-stage form) decline the plan.
     bool custom_bank = false;
+    // ... and what the designed bank hashed to (FNV-1a over its bytes, taken when the first differing bank is installed), so that
+    // installing the designed bank AGAIN puts the plan back on every engine (round 6: the flag used to be one-way).
+    uint64_t designed_hash = 0;
+    bool have_designed_hash = false;
     // device side (lazily built on first use, per precision: 0 = f32, 1 = f64)
     DeviceBank dev[2];
     std::mutex mu;

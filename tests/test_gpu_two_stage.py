@@ -208,3 +208,9 @@ def test_an_installed_bank_is_honoured_by_every_engine():
     zero = dev.Plan(48000, 44101.5, "VHQ")
     zero.set_bank(np.zeros_like(plan.bank()))
     assert not dev.resample_tensor(zero, x).any()
+    # round 6 (advisor): the flag is two-way — the DESIGNED bank installed again puts the plan back on the fast form, bit for bit
+    half.set_bank(plan.bank())
+    assert torch.equal(dev.resample_tensor(half, x), dev.resample_tensor(plan, x))
+    half.set_bank(0.25 * plan.bank())                                   # ... and off it again
+    got = dev.resample_tensor(half, x).double()
+    assert float((got - 0.25 * y_exact).norm() / y_exact.norm()) <= 1e-6
