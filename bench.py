@@ -909,7 +909,7 @@ def main():
                   if k in ("power_W", "sclk_MHz", "energy_mJ_per_launch", "smi_samples")})
 
     # ---- configs[3] shard: 1024 x 10 s clips over 8 GPUs -> 128 clips per GPU ----------------
-    f64_tp = None
+    f64_tp = exact_tp = None
     if not args.no_batch:
         lo, hi = shard(args.batch_clips, args.batch_gpus, rank % args.batch_gpus)
         clips = hi - lo
@@ -957,6 +957,18 @@ def main():
                                                            "note": "input re-read from the Infinity Cache: not HBM traffic"}
         # ... and the same batch at the arithmetic width libsoxr's VHQ recipe computes in (float32 I/O, float64 arithmetic):
         # the throughput figure of the `arith_f64` leg — rotating buffer sets, back to back, >= 1 s
+        # ... and on the exact (canonical-order) engine: its THROUGHPUT figure — the 60 s clip of `exact_engine` is two rounds of
+        # workgroups, a latency line like the headline (profiles/NOTES_r06.md §5)
+        exact_tp = None
+        if world == 1 and args.kernel == 0 and not args.no_sustained:
+            try:
+                en, edt, _ = sustained_leg(plan, xbs, min(1.0, args.sustained_s), device, 6)
+                eflops = 2.0 * plan.taps * b_out
+                exact_tp = {"workload": "batch_shard", "us_per_launch": edt / en * 1e6, "launches": en,
+                            "mfma_tflops": eflops / (edt / en) / 1e12, "mfma_frac": eflops / (edt / en) / 1e12 / VALU_PEAK_TFLOPS,
+                            "us_per_clip_minute": edt / en * 1e6 * (IN_RATE * 60.0) / b_in}
+            except RuntimeError as e:
+                exact_tp = {"error": str(e)}
         if world == 1 and args.kernel == 0 and not args.no_sustained:
             try:
                 fn, fdt, _ = sustained_leg(plan, xbs, min(1.5, args.sustained_s), device, 8)
@@ -1061,6 +1073,8 @@ def main():
                                   "value": n_in / ek / 1e6, "unit": "Msamples/s",
                                   "hbm_frac": algo_bytes / ek / 1e9 / HBM_PEAK_GBS,
                                   "mfma_tflops": flops / ek / 1e12, "mfma_frac": flops / ek / 1e12 / VALU_PEAK_TFLOPS}
+        if exact_tp is not None:
+            result["exact_engine"]["throughput"] = exact_tp
 
     # the headline workload at the arithmetic width libsoxr's VHQ recipe itself computes in: float32 I/O on float64
     # arithmetic (HIPSOXR_KERNEL_FFT_F64; SURVEY.md §0.3, reference src/soxr_ext.cpp:74,228)
