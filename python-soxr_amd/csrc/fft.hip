@@ -1013,7 +1013,8 @@ const char *launch_fft(Plan *p, const hipsoxr_job_t &j, void *stream, bool *hand
                     if (const char *err = get(1000 + wk.k, wk.k, &gw)) return err;
                     const int64_t pairs_w = gw.ok ? ((j.out_frames + gw.hop_out - 1) / gw.hop_out + 1) / 2 : 0;
                     const int64_t wave_min = switches().dbg_wave_min ? switches().dbg_wave_min : wk.min_pairs;
-                    if (gw.ok && gw.v0 == wk.v0 && gw.hop_out == wk.hop && gw.hop_periods == wk.hop_periods && pairs_w * (int64_t)cols_p >= wave_min && pairs_w <= 2147483647LL) {
+                    if (gw.ok && gw.v0 == wk.v0 && gw.hop_out == wk.hop && gw.hop_periods == wk.hop_periods && pairs_w * (int64_t)cols_p >= wave_min &&
+                        pairs_w * (int64_t)cols_p <= 2147483000LL) { // (item numbers are 32-bit; a larger job stays on k_fft_pair2)
                         set_geom(a, gw);
                         if (const char *e = fft_wave_launch(wk, a, (unsigned)pairs_w, (unsigned)cols_p, stream)) return e;
                         *handled = true;
