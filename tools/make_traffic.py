@@ -80,7 +80,8 @@ def pick_us(tr, sub, want_threads=None):
 def main(prof_dir, out_path):
     p1, p3, p4 = counters(_db(prof_dir, "pmc1")), counters(_db(prof_dir, "pmc3")), counters(_db(prof_dir, "pmc4"))
     tr = trace_avg_us(prof_dir)
-    threads = {"configs1": None, "batch_shard": 128 * 50 * 384, "configs2": None, "float64": None, "arith_f64": None, "exact_engine": None}
+    threads = {"configs1": None, "batch_shard": 128 * 50 * 384, "configs2": None, "float64": None, "arith_f64": None,
+               "exact_engine": 1704 * 256}   # (the 60 s clip's launches only: bench.py also runs the batch on this kernel)
     rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_INSTS_VALU passes (separate runs) of bench.py (tools/prof_bench.sh); "
                      "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE uncorrected; KiB",
            "kernel_sources": list(bench.KERNEL_SOURCES), "kernel_sources_sha16": bench.kernel_sources_sha16(), "workloads": {}}
