@@ -734,7 +734,8 @@ LINE_BUDGET = 6144
 _HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline")
 _TAIL_KEYS = ("dtype_matrix", "arith_f64", "arbitrary_ratio", "exact_engine", "batch_up", "batch_strong", "configs2", "batch_shard", "throughput_roofline")
-_DROP_KEYS = {"note", "launch_us_window", "smi_samples", "taken_on_kernel_sources_sha16", "usable_cpus", "host_cpus", "calls", "regime_note"}
+_DROP_KEYS = {"note", "launch_us_window", "smi_samples", "taken_on_kernel_sources_sha16", "usable_cpus", "host_cpus", "calls", "regime_note",
+              "launch_us_le_step", "algorithmic_bytes_per_launch", "direct_form_equiv_tflops", "buffer_sets", "launches", "seconds", "frac_of_measured_copy"}
 # context legs given up first (in this order) if a line still exceeds the budget
 _SHED_ORDER = ("host_batch", "host_api", "configs4", "hbm_ceiling", "ranks", "dtype_matrix", "arith_f64")
 
@@ -763,6 +764,10 @@ def compact_line(result, budget=LINE_BUDGET):
     """-> the JSON text bench.py prints: every contract key, `roofline` and `cpu_baseline` first, context legs in the
     middle, the roofline-bearing legs (`configs2`, `batch_shard`, `throughput_roofline`, ...) last; <= budget bytes."""
     c = {k: _compact(v, k) for k, v in result.items()}
+    if isinstance(c.get("cpu_baseline"), dict):   # the contract's `sample` stays; the context figures' own samples live in the full record
+        def strip(d):
+            return {k: (strip(v) if isinstance(v, dict) else v) for k, v in d.items() if k != "sample"}
+        c["cpu_baseline"] = {k: (strip(v) if isinstance(v, dict) else v) for k, v in c["cpu_baseline"].items()}
     order = [k for k in _HEAD_KEYS if k in c] + [k for k in c if k not in _HEAD_KEYS and k not in _TAIL_KEYS] + [k for k in _TAIL_KEYS if k in c]
     c = {k: c[k] for k in order}
     line = json.dumps(c, separators=(",", ":"))
